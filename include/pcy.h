@@ -1,0 +1,154 @@
+/* pcy.h -- C ABI of the MI355X-native ProCyon forward/generation engine (libpcy.so).
+ *
+ * The reference (mims-harvard/ProCyon) is pure Python and has no FFI; this ABI is the boundary
+ * the build introduces BELOW the reference's sub-module waist:
+ *
+ *   LlamaPostTokenization.forward   procyon/model/pmc_llama.py:546-596     -> pcy_llama_prefill / pcy_llama_decode*
+ *   ESM_PLM.forward                 procyon/model/esm.py:504-558           -> pcy_esm_encode + pcy_pool
+ *   ProteinPooler.forward           procyon/model/esm.py:131-173           -> pcy_pool
+ *   create_mlp stacks               procyon/model/model_utils.py:13-41     -> pcy_mlp_forward
+ *   _prepare_input_embeddings       procyon/model/model_unified.py:1135    -> pcy_embed_splice
+ *   _generate_sampling (greedy)     procyon/model/model_unified.py:861-921 -> pcy_llama_greedy
+ *
+ * Conventions: plain pointers and sizes only.  Every `const void*` / `void*` tensor argument is a
+ * DEVICE pointer to bf16 (raw 16-bit) data unless stated; int32 index arrays are device pointers
+ * too.  The caller owns all tensors (the engine never frees them); the engine owns only its
+ * scratch workspace.  Every call enqueues on the context's HIP stream and returns without
+ * synchronising.  Return value 0 = ok, otherwise an error code with text in pcy_last_error()
+ * (thread-local).  Nothing throws across the ABI.  One context per device/stream; a context is
+ * not thread-safe.
+ */
+#ifndef PCY_H
+#define PCY_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCY_ABI_VERSION 1
+
+typedef struct pcy_ctx pcy_ctx;
+
+/* epilogue selectors of pcy_gemm / pcy_gemv (bf16 rounding points in procyon_amd/csrc/pcy_common.h) */
+enum { PCY_EPI_STORE = 0, PCY_EPI_RESID = 1, PCY_EPI_GELU_ERF = 2, PCY_EPI_GELU_ESM = 3, PCY_EPI_SWIGLU = 4 };
+/* pooling modes of ProteinPooler (esm.py:138-149) */
+enum { PCY_POOL_MEAN = 0, PCY_POOL_MEAN_CORRECTED = 1, PCY_POOL_MAX = 2 };
+
+int pcy_abi_version(void);
+const char* pcy_last_error(void);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream */
+int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out);
+void pcy_ctx_destroy(pcy_ctx* ctx);
+int pcy_ctx_sync(pcy_ctx* ctx);
+/* HIP-event timer on the context's stream (bench.py roofline leg): start, stop -> elapsed ms */
+int pcy_timer_start(pcy_ctx* ctx);
+int pcy_timer_stop(pcy_ctx* ctx, float* ms_out);
+
+/* ---- primitive ops (unit parity tests; also what the host composes for odd shapes) ---------- */
+/* C[M,N] = epi(A[M,K] . W[N,K]^T + bias); EPI_SWIGLU: W is [N,K] with 16-row gate/up interleave, C is [M,N/2] */
+int pcy_gemm(pcy_ctx*, const void* A, int lda, const void* W, const void* bias, const void* resid, int ldr,
+             void* C, int ldc, int M, int N, int K, int epi);
+/* y[B,N] = epi(x[B,K] . W[N,K]^T); rms_w != NULL fuses RMSNorm(x)*rms_w in front (rms_cast 0: >=4.32, 1: 4.31) */
+int pcy_gemv(pcy_ctx*, const void* W, const void* x, int ldx, const void* bias, const void* resid, void* y, int ldy,
+             const void* rms_w, float rms_eps, int rms_cast, int N, int K, int B, int epi);
+int pcy_rmsnorm(pcy_ctx*, const void* x, const void* w, void* y, int rows, int d, float eps, int cast);
+int pcy_layernorm(pcy_ctx*, const void* x, const void* w, const void* b, void* y, int rows, int d, float eps);
+/* out[r] = soft_map[r] >= 0 ? soft[soft_map[r]] : table[ids[r]]   (model_unified.py:1146-1167) */
+int pcy_embed_splice(pcy_ctx*, const void* table, const int32_t* ids, const void* soft, const int32_t* soft_map,
+                     void* out, int rows, int d);
+/* pooled[i] over the token ranges rng[2*r],rng[2*r+1] = (start,len), r in [seg[i], seg[i+1])  (esm.py:131-173) */
+int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out);
+
+/* ---- create_mlp projector (model_utils.py:13-41) -------------------------------------------- */
+typedef struct {
+  int32_t n_layers;          /* 1 (bias-free Linear) or >= 2 (Linear+bias -> GELU ... -> Linear+bias) */
+  int32_t dims[9];           /* dims[0]=in, dims[i+1]=out of layer i */
+  const void* w[8];          /* [dims[i+1], dims[i]] */
+  const void* b[8];          /* [dims[i+1]] or NULL */
+} pcy_mlp_desc;
+int pcy_mlp_forward(pcy_ctx*, const pcy_mlp_desc*, const void* x, int M, void* out);
+
+/* ---- ESM2 encoder (esm.py:504-538 -> fair-esm ESM2 / HF EsmModel) ---------------------------- */
+typedef struct {
+  const void *wqkv, *bqkv;   /* [3d,d],[3d]: query,key,value rows stacked */
+  const void *wo, *bo;       /* [d,d],[d] */
+  const void *ln1_w, *ln1_b; /* attention LayerNorm */
+  const void *w1, *b1;       /* [F,d],[F] */
+  const void *w2, *b2;       /* [d,F],[d] */
+  const void *ln2_w, *ln2_b; /* FFN LayerNorm */
+} pcy_esm_layer;
+typedef struct {
+  int32_t d, n_layers, n_heads, ffn, vocab;
+  float ln_eps;
+  int32_t rope_mode;         /* 1: fp32, rounded once (HF Esm) ; 0: three bf16 roundings (fair-esm) */
+  const void* embed;         /* [vocab,d] */
+  const void *final_ln_w, *final_ln_b;
+  const void *rope_cos, *rope_sin; /* [max_len, d/n_heads] bf16 */
+  const pcy_esm_layer* layers;     /* host array [n_layers] */
+} pcy_esm_desc;
+/* Packed varlen batch: tokens[ntok], sequence q = tokens[cu[q]..cu[q+1]); pos[tok] = index inside its
+ * sequence; vt_cu[q] = sum over earlier sequences of roundup(len,32), vt_total = vt_cu[nseq].
+ * mask_pads=1: fair-esm semantics (callers pack WITHOUT pad tokens); mask_pads=0: the HF-"official"
+ * call without attention_mask (esm.py:533): pack the padded rows, pads take part as ordinary tokens.
+ * hidden_out [ntok,d] = representations[repr_layer] (post final LayerNorm). */
+int pcy_esm_encode(pcy_ctx*, const pcy_esm_desc*, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
+                   const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out);
+
+/* ---- Llama decoder (pmc_llama.py:546-596 -> HF LlamaForCausalLM) ----------------------------- */
+typedef struct {
+  const void* wqkv;          /* [(H+2Hkv)*dh, d]: q,k,v rows stacked */
+  const void* wo;            /* [d, H*dh] */
+  const void* wgu;           /* [2F, d]: gate/up interleaved in blocks of 16 rows */
+  const void* wdown;         /* [d, F] */
+  const void *ln1, *ln2;     /* [d] */
+} pcy_llama_layer;
+typedef struct {
+  int32_t vocab, d, n_layers, n_heads, n_kv_heads, head_dim, ffn, max_pos;
+  float rms_eps;
+  int32_t rms_cast;          /* 0: w*bf16(x_hat) ; 1: bf16(w*x_hat) (transformers 4.31, SURVEY App.B Q11) */
+  const void* embed;         /* [vocab,d] */
+  const void* final_norm;    /* [d] */
+  const void* lm_head;       /* [vocab,d] */
+  const void *rope_cos, *rope_sin; /* [max_pos, head_dim] bf16 (table precision is the caller's choice, Q9/Q10) */
+  const pcy_llama_layer* layers;   /* host array [n_layers] */
+} pcy_llama_desc;
+typedef struct {
+  void* k;                   /* [L,B,Hkv,Tmax,dh] bf16: layer l rows = past_key_values[l][0] */
+  void* v;                   /* same for values */
+  int32_t B, Tmax;
+} pcy_kv_cache;
+/* Prefill: embeds [B,T,d]; keep [B*T] uint8 attention_mask or NULL; pos[B*T] rotary positions
+ * (reference: arange(T) per row, Q2); cu/vt_cu [B+1] = b*T / b*roundup(T,32).
+ * logit_rows[n_logit_rows] = token rows (b*T+t) whose logits are wanted -> logits_out [n_logit_rows, vocab];
+ * hidden_out (optional) [B*T,d] = hidden_states[-1] (final-normed). K/V of slots [0,T) are written. */
+int pcy_llama_prefill(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const void* embeds, const uint8_t* keep,
+                      const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T,
+                      const int32_t* logit_rows, int n_logit_rows, void* logits_out, void* hidden_out);
+typedef struct {
+  int32_t* pos;              /* device scalar: cache length == rotary position of the next token (Q2) */
+  int32_t* step;             /* device scalar: index of the next generated token */
+  int32_t* next_tok;         /* [B] token fed to the next decode step */
+  int32_t* tokens_out;       /* [B, max_steps] */
+  float* logprob;            /* [B] running sum of log_softmax(logits)[token] */
+  void* logits;              /* [B, vocab] logits of the latest step */
+  void* logits_all;          /* optional [max_steps, B, vocab] */
+  const uint8_t* keep;       /* optional [B, Tmax] decode key mask ("clean" mode); NULL = reference quirk Q1 */
+  int32_t max_steps;
+} pcy_gen_state;
+/* one decode step: next_tok -> logits (and K/V appended at slot *pos); does not pick or advance */
+int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
+/* argmax of state->logits (lowest index on ties) -> next_tok / tokens_out[step], logprob, ++pos? no: ++step only
+ * when advance_pos == 0 (used on the prefill logits), ++pos and ++step otherwise */
+int pcy_greedy_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_gen_state*, int B, int advance_pos);
+/* n_steps x (decode + pick) with no host synchronisation; use_graph != 0 replays a captured hipGraph */
+int pcy_llama_greedy(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int n_steps,
+                     int use_graph);
+/* KV rows gather for beam search: cache[:, dst] = cache[:, src[dst]] over slots [0,t) (model_unified.py:830-832) */
+int pcy_kv_reorder(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const int32_t* src_rows, int B, int t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCY_H */

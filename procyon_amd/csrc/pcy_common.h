@@ -1,0 +1,93 @@
+// Shared device helpers for the ProCyon gfx950 engine (CDNA4, wave64).
+//
+// Numerics contract (DESIGN.md "Rounding points"): every kernel accumulates in fp32 and
+// rounds to bf16 (round-to-nearest-even, as torch does) exactly where the reference's
+// bf16 torch ops materialise a tensor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair;
+
+#define PCY_WAVE 64
+#define PCY_BF16_MIN (-3.3895313892515355e38f)  // torch.finfo(torch.bfloat16).min
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// fp32 -> bf16, round to nearest even; NaN stays NaN (c10::BFloat16 semantics)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// round-trip: the value a bf16 tensor would hold
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); red = NT/64 floats of LDS
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// torch.nn.functional.silu on a bf16 tensor: fp32 x / (1 + exp(-x)), one rounding
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// nn.GELU() (erf form) in fp32
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// fair-esm / HF-ESM gelu evaluated op by op on a bf16 tensor:
+//   x * 0.5 * (1.0 + erf(x / sqrt(2)))  -> five bf16 tensors
+__device__ __forceinline__ float gelu_esm_chain(float x /* already bf16-valued */) {
+  float t1 = rbf(x * 0.5f);
+  float t2 = rbf(x / 1.4142135623730951f);
+  float t3 = rbf(erff(t2));
+  float t4 = rbf(1.0f + t3);
+  return rbf(t1 * t4);
+}
+
+// Epilogue selectors shared by the GEMM (prefill / encoder) and GEMV (decode) kernels.
+enum PcyEpi : int {
+  EPI_STORE = 0,      // y = bf16(acc [+ bias])
+  EPI_RESID = 1,      // y = bf16( bf16(acc [+ bias]) + residual )
+  EPI_GELU_ERF = 2,   // y = bf16( gelu_erf( bf16(acc + bias) ) )            (create_mlp, nn.GELU)
+  EPI_GELU_ESM = 3,   // y = esm op-by-op gelu chain of bf16(acc + bias)     (ESM fc1)
+  EPI_SWIGLU = 4,     // y = bf16( bf16(silu(bf16(acc_gate))) * bf16(acc_up) ) (Llama MLP)
+};

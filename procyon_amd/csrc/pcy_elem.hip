@@ -1,0 +1,322 @@
+// Memory-bound glue kernels of the ProCyon path: norms, embeddings / soft-token splice, rotary,
+// KV scatter, V transpose, protein pooler, greedy pick.  All 16-byte vectorised along the feature
+// dimension, fp32 math, bf16 rounding exactly where the reference's torch ops round.
+#include "pcy_internal.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ RMSNorm (HF LlamaRMSNorm)
+__global__ __launch_bounds__(NT) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                     bf16_t* __restrict__ y, int d, float eps, int cast) {
+  __shared__ float red[NT / 64];
+  const bf16_t* xr = x + (size_t)blockIdx.x * d;
+  bf16_t* yr = y + (size_t)blockIdx.x * d;
+  float ss = 0.f;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float a = lo_bf(u[j]), b = hi_bf(u[j]); ss += a * a + b * b; }
+  }
+  ss = block_sum<NT>(ss, red);
+  const float rstd = rsqrtf(ss / (float)d + eps);
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint4 g = *reinterpret_cast<const uint4*>(w + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = lo_bf(u[j]) * rstd, b = hi_bf(u[j]) * rstd;
+      if (cast == 0) { a = rbf(a); b = rbf(b); }
+      o[j] = pack_bf(lo_bf(gg[j]) * a, hi_bf(gg[j]) * b);
+    }
+    *reinterpret_cast<uint4*>(yr + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm (nn.LayerNorm, fp32 math, one rounding)
+__global__ __launch_bounds__(NT) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                       const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int d,
+                                                       float eps) {
+  __shared__ float red[NT / 64];
+  const bf16_t* xr = x + (size_t)blockIdx.x * d;
+  bf16_t* yr = y + (size_t)blockIdx.x * d;
+  float s = 0.f;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += lo_bf(u[j]) + hi_bf(u[j]);
+  }
+  const float mean = block_sum<NT>(s, red) / (float)d;
+  float q = 0.f;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float a = lo_bf(u[j]) - mean, c = hi_bf(u[j]) - mean; q += a * a + c * c; }
+  }
+  const float rstd = rsqrtf(block_sum<NT>(q, red) / (float)d + eps);
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint4 g = *reinterpret_cast<const uint4*>(w + k);
+    const uint4 h = *reinterpret_cast<const uint4*>(b + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w}, hh[4] = {h.x, h.y, h.z, h.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf((lo_bf(u[j]) - mean) * rstd * lo_bf(gg[j]) + lo_bf(hh[j]),
+                     (hi_bf(u[j]) - mean) * rstd * hi_bf(gg[j]) + hi_bf(hh[j]));
+    *reinterpret_cast<uint4*>(yr + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------ embedding lookup + soft-token splice (A5)
+__global__ __launch_bounds__(NT) void embed_gather_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
+                                                          const bf16_t* __restrict__ soft, const int32_t* __restrict__ soft_map,
+                                                          bf16_t* __restrict__ out, int d) {
+  const int r = blockIdx.x;
+  const int sm = soft_map ? soft_map[r] : -1;
+  const bf16_t* src = sm >= 0 ? soft + (size_t)sm * d : table + (size_t)ids[r] * d;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8)
+    *reinterpret_cast<uint4*>(out + (size_t)r * d + k) = *reinterpret_cast<const uint4*>(src + k);
+}
+
+// ------------------------------------------------------------------ ESM embedding (HF EsmEmbeddings, token_dropout)
+// grid (nseq, SL): block (q, sl) handles tokens sl, sl+SL, ... of sequence q
+__global__ __launch_bounds__(NT) void esm_embed_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ toks,
+                                                       const int32_t* __restrict__ cu, bf16_t* __restrict__ out, int d,
+                                                       int mask_pads) {
+  __shared__ float red[NT / 64];
+  const int q = blockIdx.x;
+  const int t0 = cu[q], len = cu[q + 1] - t0;
+  float nmask = 0.f, nkeep = 0.f;
+  for (int j = threadIdx.x; j < len; j += NT) {
+    const int t = toks[t0 + j];
+    nmask += (t == 32) ? 1.f : 0.f;
+    nkeep += (t != 1) ? 1.f : 0.f;
+  }
+  nmask = block_sum<NT>(nmask, red);
+  nkeep = block_sum<NT>(nkeep, red);
+  const float src_len = mask_pads ? nkeep : (float)len;
+  const float denom = 1.0f - nmask / src_len;  // 1 - mask_ratio_observed (fp32)
+  for (int j = blockIdx.y; j < len; j += gridDim.y) {
+    const int t = toks[t0 + j];
+    const bool zero = (t == 32) || (mask_pads && t == 1);
+    const bf16_t* src = table + (size_t)t * d;
+    bf16_t* dst = out + (size_t)(t0 + j) * d;
+    for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (!zero) {
+        const uint4 e = *reinterpret_cast<const uint4*>(src + k);
+        const uint32_t u[4] = {e.x, e.y, e.z, e.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // bf16(x * 0.88) then fp32 / (1 - ratio) then bf16
+          o[i] = pack_bf(rbf(lo_bf(u[i]) * 0.88f) / denom, rbf(hi_bf(u[i]) * 0.88f) / denom);
+        v = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      *reinterpret_cast<uint4*>(dst + k) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ rotary on a token-major buffer
+// one block per token; thread handles (head, i) pairs (i, i+dh/2)
+__global__ __launch_bounds__(NT) void rope_kernel(bf16_t* __restrict__ buf, int ld, int col0, int nh, int dh,
+                                                  const int32_t* __restrict__ pos, const bf16_t* __restrict__ cos_t,
+                                                  const bf16_t* __restrict__ sin_t, int mode, float prescale) {
+  const int tok = blockIdx.x;
+  const int p = pos[tok];
+  const int half = dh >> 1;
+  bf16_t* row = buf + (size_t)tok * ld + col0;
+  const bf16_t* c = cos_t + (size_t)p * dh;
+  const bf16_t* s = sin_t + (size_t)p * dh;
+  for (int e = threadIdx.x; e < nh * half; e += NT) {
+    const int h = e / half, i = e - h * half;
+    bf16_t* x = row + h * dh;
+    float x1 = bf2f(x[i]), x2 = bf2f(x[i + half]);
+    if (prescale != 0.f) { x1 = rbf(x1 * prescale); x2 = rbf(x2 * prescale); }
+    const float c1 = bf2f(c[i]), c2 = bf2f(c[i + half]), s1 = bf2f(s[i]), s2 = bf2f(s[i + half]);
+    float o1, o2;
+    if (mode == 0) {  // (x*cos) + (rotate_half(x)*sin), every op a bf16 tensor
+      o1 = rbf(rbf(x1 * c1) + rbf(-x2 * s1));
+      o2 = rbf(rbf(x2 * c2) + rbf(x1 * s2));
+    } else {          // fp32, rounded once
+      o1 = x1 * c1 + (-x2) * s1;
+      o2 = x2 * c2 + x1 * s2;
+    }
+    x[i] = f2bf(o1);
+    x[i + half] = f2bf(o2);
+  }
+}
+
+// ------------------------------------------------------------------ K/V scatter into the [B,Hkv,Tmax,dh] cache
+__global__ __launch_bounds__(NT) void kv_scatter_kernel(const bf16_t* __restrict__ qkv, int ld, int kcol0, int vcol0,
+                                                        int Hkv, int dh, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                        int T, int Tmax) {
+  const int tok = blockIdx.x;
+  const int b = tok / T, t = tok - b * T;
+  const int n8 = Hkv * dh / 8;
+  for (int e = threadIdx.x; e < 2 * n8; e += NT) {
+    const int isv = e >= n8;
+    const int c = (isv ? e - n8 : e) * 8;
+    const int h = c / dh, i = c - h * dh;
+    const uint4 v = *reinterpret_cast<const uint4*>(qkv + (size_t)tok * ld + (isv ? vcol0 : kcol0) + c);
+    bf16_t* dst = (isv ? vc : kc) + (((size_t)b * Hkv + h) * Tmax + t) * dh + i;
+    *reinterpret_cast<uint4*>(dst) = v;
+  }
+}
+
+// ------------------------------------------------------------------ V transpose: token-major -> Vt[nh][dh][vt_total]
+// grid (tiles of 64 tokens, nh*dh/64, nseq); 64x64 tile through LDS
+__global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restrict__ buf, int ld, int vcol0, int dh,
+                                                         const int32_t* __restrict__ cu, const int32_t* __restrict__ vt_cu,
+                                                         bf16_t* __restrict__ vt, int vt_total) {
+  __shared__ bf16_t tile[64][66];
+  const int q = blockIdx.z;
+  const int t0 = cu[q], len = cu[q + 1] - t0;
+  const int j0 = blockIdx.x * 64;
+  if (j0 >= len) return;
+  const int f0 = blockIdx.y * 64;  // feature (h*dh + e) tile
+  const int padlen = vt_cu[q + 1] - vt_cu[q];
+  for (int e = threadIdx.x; e < 64 * 64; e += NT) {
+    const int j = e >> 6, f = e & 63;
+    tile[j][f] = (j0 + j < len) ? buf[(size_t)(t0 + j0 + j) * ld + vcol0 + f0 + f] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += NT) {
+    const int f = e >> 6, j = e & 63;
+    if (j0 + j < padlen) vt[(size_t)(f0 + f) * vt_total + vt_cu[q] + j0 + j] = tile[j][f];
+  }
+}
+
+// ------------------------------------------------------------------ ProteinPooler (A3)
+// grid (nprot, ceil(d/NT)); thread = one feature column
+__global__ __launch_bounds__(NT) void pool_kernel(const bf16_t* __restrict__ h, int d, const int32_t* __restrict__ seg,
+                                                  const int32_t* __restrict__ rng, int mode, bf16_t* __restrict__ out) {
+  const int p = blockIdx.x;
+  const int c = blockIdx.y * NT + threadIdx.x;
+  if (c >= d) return;
+  const int r0 = seg[p], r1 = seg[p + 1];
+  float acc = (mode == 2) ? -INFINITY : 0.f;
+  int cnt = 0;
+  for (int r = r0; r < r1; ++r) {
+    int st = rng[2 * r], ln = rng[2 * r + 1];
+    if (mode == 1) {  // x[1:-1] of the concatenation: drop first token of first range, last of last
+      if (r == r0) { st += 1; ln -= 1; }
+      if (r == r1 - 1) ln -= 1;
+    }
+    for (int j = 0; j < ln; ++j) {
+      const float v = bf2f(h[(size_t)(st + j) * d + c]);
+      if (mode == 2) acc = fmaxf(acc, v);
+      else if (v == v) { acc += v; ++cnt; }  // nanmean skips NaNs
+    }
+  }
+  // torch.nanmean on bf16: nansum (fp32 accumulate, rounded to bf16) / count, rounded again
+  out[(size_t)p * d + c] = (mode == 2) ? f2bf(acc) : f2bf(rbf(acc) / (float)cnt);
+}
+
+// ------------------------------------------------------------------ greedy pick (A8): argmax + log-prob + advance
+constexpr int PICK_NT = 1024;
+__global__ __launch_bounds__(PICK_NT) void greedy_pick_kernel(const bf16_t* __restrict__ logits, int V,
+                                                              int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out,
+                                                              int max_steps, float* __restrict__ logprob,
+                                                              const int32_t* __restrict__ step_dev) {
+  __shared__ float redv[PICK_NT / 64];
+  __shared__ int redi[PICK_NT / 64];
+  __shared__ float red[PICK_NT / 64];
+  const int b = blockIdx.x;
+  const bf16_t* lg = logits + (size_t)b * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += PICK_NT) {
+    const float v = bf2f(lg[i]);
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { redv[w] = best; redi[w] = bi; }
+  __syncthreads();
+  best = redv[0]; bi = redi[0];
+  for (int i = 1; i < PICK_NT / 64; ++i)
+    if (redv[i] > best || (redv[i] == best && redi[i] < bi)) { best = redv[i]; bi = redi[i]; }
+  // log_softmax in bf16 (model dtype): bf16( x - max - log(sum exp(x - max)) )
+  float se = 0.f;
+  for (int i = threadIdx.x; i < V; i += PICK_NT) se += expf(bf2f(lg[i]) - best);
+  se = block_sum<PICK_NT>(se, red);
+  if (threadIdx.x == 0) {
+    const int step = *step_dev;
+    const float lsm = rbf((bf2f(lg[bi]) - best) - logf(se));
+    logprob[b] += lsm;
+    next_tok[b] = bi;
+    tokens_out[(size_t)b * max_steps + step] = bi;
+  }
+}
+__global__ void advance_kernel(int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
+  if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev += 1; }
+}
+
+__global__ __launch_bounds__(NT) void copy_rows_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst,
+                                                       int ldd, const int32_t* __restrict__ rows, int d) {
+  const int r = blockIdx.x;
+  const int sr = rows ? rows[r] : r;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8)
+    *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + k) = *reinterpret_cast<const uint4*>(src + (size_t)sr * lds_ + k);
+}
+
+}  // namespace
+
+void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int d, float eps, int cast) {
+  if (rows > 0) hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, y, d, eps, cast);
+}
+void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps) {
+  if (rows > 0) hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, b, y, d, eps);
+}
+void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
+                             const int32_t* soft_map, bf16_t* out, int rows, int d) {
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d);
+}
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d) {
+  pcy_launch_embed_gather(s, table, ids, nullptr, nullptr, out, rows, d);
+}
+void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
+                          int max_len, bf16_t* out, int d, int mask_pads) {
+  if (nseq <= 0) return;
+  int sl = max_len < 64 ? max_len : 64;
+  if (sl < 1) sl = 1;
+  hipLaunchKernelGGL(esm_embed_kernel, dim3(nseq, sl), dim3(NT), 0, s, table, toks, cu, out, d, mask_pads);
+}
+void pcy_launch_rope(hipStream_t s, bf16_t* buf, int ld, int col0, int nh, int dh, const int32_t* pos,
+                     const bf16_t* cos_t, const bf16_t* sin_t, int ntok, int mode, float prescale) {
+  if (ntok > 0) hipLaunchKernelGGL(rope_kernel, dim3(ntok), dim3(NT), 0, s, buf, ld, col0, nh, dh, pos, cos_t, sin_t, mode, prescale);
+}
+void pcy_launch_kv_scatter(hipStream_t s, const bf16_t* qkv, int ld, int kcol0, int vcol0, int Hkv, int dh,
+                           bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax) {
+  if (B * T > 0) hipLaunchKernelGGL(kv_scatter_kernel, dim3(B * T), dim3(NT), 0, s, qkv, ld, kcol0, vcol0, Hkv, dh, kcache, vcache, T, Tmax);
+}
+void pcy_launch_transpose_v(hipStream_t s, const bf16_t* buf, int ld, int vcol0, int nh, int dh, const int32_t* cu,
+                            const int32_t* vt_cu, int nseq, int max_len, bf16_t* vt, int vt_total) {
+  if (nseq <= 0) return;
+  const int maxpad = (max_len + 31) / 32 * 32;
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((maxpad + 63) / 64, nh * dh / 64, nseq), dim3(NT), 0, s, buf, ld, vcol0, dh, cu, vt_cu, vt, vt_total);
+}
+void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, bf16_t* out) {
+  if (nprot > 0) hipLaunchKernelGGL(pool_kernel, dim3(nprot, (d + NT - 1) / NT), dim3(NT), 0, s, h, d, seg, rng, mode, out);
+}
+void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
+                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(PICK_NT), 0, s, logits, V, next_tok, tokens_out, max_steps, logprob, step_dev);
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev, advance_pos);
+}
+void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {
+  if (nrows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, dst, ldd, rows, d);
+}

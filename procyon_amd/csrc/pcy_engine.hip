@@ -1,0 +1,442 @@
+// Host side of libpcy.so: context, workspace, layer loops, hipGraph capture, and the extern "C" ABI
+// declared in include/pcy.h.  No torch types; everything is raw device pointers on one HIP stream.
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/pcy.h"
+#include "pcy_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct pcy_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // captured decode step
+  hipGraphExec_t graph = nullptr;
+  const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int graph_B = 0;
+
+  int reserve(size_t bytes) {
+    if (bytes <= ws_bytes) return 0;
+    if (ws) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipFree(ws));
+      ws = nullptr; ws_bytes = 0;
+    }
+    drop_graph();
+    bytes = align_up(bytes + (bytes >> 3), 1 << 20);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws), bytes));
+    ws_bytes = bytes;
+    return 0;
+  }
+  void drop_graph() {
+    if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+  }
+};
+
+namespace {
+
+struct Carver {
+  char* p; size_t off = 0;
+  explicit Carver(char* base) : p(base) {}
+  template <typename T> T* take(size_t n) {
+    T* r = reinterpret_cast<T*>(p + off);
+    off = align_up(off + n * sizeof(T), 256);
+    return r;
+  }
+};
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(3, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// GEMM for any M: MFMA tiles when M is large enough to fill them, the streaming GEMV otherwise
+void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* bias, const bf16_t* resid, int ldr,
+            bf16_t* C, int ldc, int M, int N, int K, int epi) {
+  if (M <= 8 && epi != EPI_SWIGLU && (resid == nullptr || ldr == ldc)) {
+    PcyGemvArgs g{};
+    g.W = W; g.x = A; g.y = C; g.bias = bias; g.resid = resid; g.rms_w = nullptr;
+    g.N = N; g.K = K; g.B = M; g.ldx = lda; g.ldy = ldc; g.epi = epi;
+    pcy_launch_gemv(s, g);
+    return;
+  }
+  PcyGemmArgs a{};
+  a.A = A; a.W = W; a.C = C; a.bias = bias; a.resid = resid;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
+  pcy_launch_gemm(s, a);
+}
+
+// ------------------------------------------------------------------ decode step (enqueue only)
+struct DecodeWs { bf16_t *x, *qkv, *ao, *act; };
+
+size_t decode_ws_bytes(const pcy_llama_desc* m, int B) {
+  const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
+         align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) + 4096;
+}
+
+void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+  hipStream_t s = c->stream;
+  const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
+  const int qkvw = (H + 2 * Hkv) * dh;
+  Carver cv(c->ws);
+  bf16_t* x = cv.take<bf16_t>((size_t)B * d);
+  bf16_t* qkv = cv.take<bf16_t>((size_t)B * qkvw);
+  bf16_t* ao = cv.take<bf16_t>((size_t)B * H * dh);
+  bf16_t* act = cv.take<bf16_t>((size_t)B * F);
+  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
+  const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const pcy_llama_layer& L = m->layers[l];
+    PcyGemvArgs g{};
+    g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
+    g.rms_cast = m->rms_cast; g.N = qkvw; g.K = d; g.B = B; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
+    pcy_launch_gemv(s, g);
+    PcyDecAttnArgs t{};
+    t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
+    t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
+    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = nullptr; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
+    t.scale = 1.0f / sqrtf((float)dh);
+    pcy_launch_attn_decode(s, t);
+    PcyGemvArgs o{};
+    o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
+    pcy_launch_gemv(s, o);
+    PcyGemvArgs u{};
+    u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
+    u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
+    pcy_launch_gemv(s, u);
+    PcyGemvArgs w{};
+    w.W = (const bf16_t*)L.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.B = B; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
+    pcy_launch_gemv(s, w);
+  }
+  PcyGemvArgs h{};
+  h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
+  h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = B; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
+  pcy_launch_gemv(s, h);
+}
+
+__global__ void store_logits_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ all, const int32_t* step_dev, size_t n) {
+  const size_t base = (size_t)(*step_dev) * n;
+  for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) all[base + i] = logits[i];
+}
+void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos) {
+  hipStream_t s = c->stream;
+  if (st->logits_all)
+    hipLaunchKernelGGL(store_logits_kernel, dim3(64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)st->logits_all,
+                       st->step, (size_t)B * m->vocab);
+  pcy_launch_greedy_pick(s, (const bf16_t*)st->logits, B, m->vocab, st->next_tok, st->tokens_out, st->max_steps,
+                         st->logprob, st->pos, st->step, advance_pos);
+}
+
+__global__ void kv_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ rows,
+                                 int Hkv, int Tmax, int t, int dh, int to_tmp) {
+  // grid (B, Hkv); to_tmp: dst(tmp,[B,Hkv,t,dh]) = src(cache)[rows[b]] ; else dst(cache)[b] = src(tmp)[b]
+  const int b = blockIdx.x, h = blockIdx.y;
+  const size_t n8 = (size_t)t * dh / 8;
+  const uint4* sp; uint4* dp;
+  if (to_tmp) {
+    sp = reinterpret_cast<const uint4*>(src + ((size_t)rows[b] * Hkv + h) * Tmax * dh);
+    dp = reinterpret_cast<uint4*>(dst + ((size_t)b * Hkv + h) * t * dh);
+  } else {
+    sp = reinterpret_cast<const uint4*>(src + ((size_t)b * Hkv + h) * t * dh);
+    dp = reinterpret_cast<uint4*>(dst + ((size_t)b * Hkv + h) * Tmax * dh);
+  }
+  for (size_t i = threadIdx.x; i < n8; i += blockDim.x) dp[i] = sp[i];
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+extern "C" {
+
+int pcy_abi_version(void) { return PCY_ABI_VERSION; }
+const char* pcy_last_error(void) { return g_err; }
+
+int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out) {
+  if (!out) return fail(1, "pcy_ctx_create: out is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device_id < 0 || device_id >= n) return fail(1, "pcy_ctx_create: device %d of %d", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  pcy_ctx* c = new pcy_ctx();
+  c->device = device_id;
+  c->stream = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  *out = c;
+  return 0;
+}
+void pcy_ctx_destroy(pcy_ctx* c) {
+  if (!c) return;
+  hipStreamSynchronize(c->stream);
+  c->drop_graph();
+  if (c->ws) hipFree(c->ws);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  delete c;
+}
+int pcy_ctx_sync(pcy_ctx* c) { HIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
+int pcy_timer_start(pcy_ctx* c) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); return 0; }
+int pcy_timer_stop(pcy_ctx* c, float* ms) {
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+int pcy_gemm(pcy_ctx* c, const void* A, int lda, const void* W, const void* bias, const void* resid, int ldr, void* C,
+             int ldc, int M, int N, int K, int epi) {
+  if (K % 64 != 0) return fail(1, "pcy_gemm: K=%d must be a multiple of 64", K);
+  if (epi == EPI_SWIGLU && N % 32 != 0) return fail(1, "pcy_gemm: SwiGLU needs N %% 32 == 0");
+  if (epi == EPI_RESID && !resid) return fail(1, "pcy_gemm: EPI_RESID without residual");
+  PcyGemmArgs a{};
+  a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = (const bf16_t*)bias; a.resid = (const bf16_t*)resid;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
+  pcy_launch_gemm(c->stream, a);
+  return check_launch("pcy_gemm");
+}
+
+int pcy_gemv(pcy_ctx* c, const void* W, const void* x, int ldx, const void* bias, const void* resid, void* y, int ldy,
+             const void* rms_w, float rms_eps, int rms_cast, int N, int K, int B, int epi) {
+  if (K % 8 != 0 || ldx % 8 != 0) return fail(1, "pcy_gemv: K and ldx must be multiples of 8");
+  if (rms_w && !(epi == EPI_STORE || epi == EPI_SWIGLU)) return fail(1, "pcy_gemv: fused RMSNorm only with STORE/SWIGLU");
+  if (rms_w && (size_t)K * 2 * (B < 4 ? B : 4) > 65536) return fail(1, "pcy_gemv: fused RMSNorm needs x to fit LDS");
+  PcyGemvArgs g{};
+  g.W = (const bf16_t*)W; g.x = (const bf16_t*)x; g.y = (bf16_t*)y; g.bias = (const bf16_t*)bias; g.resid = (const bf16_t*)resid;
+  g.rms_w = (const bf16_t*)rms_w; g.rms_eps = rms_eps; g.rms_cast = rms_cast; g.N = N; g.K = K; g.B = B; g.ldx = ldx; g.ldy = ldy; g.epi = epi;
+  pcy_launch_gemv(c->stream, g);
+  return check_launch("pcy_gemv");
+}
+
+int pcy_rmsnorm(pcy_ctx* c, const void* x, const void* w, void* y, int rows, int d, float eps, int cast) {
+  if (d % 8) return fail(1, "pcy_rmsnorm: d %% 8 != 0");
+  pcy_launch_rmsnorm(c->stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rows, d, eps, cast);
+  return check_launch("pcy_rmsnorm");
+}
+int pcy_layernorm(pcy_ctx* c, const void* x, const void* w, const void* b, void* y, int rows, int d, float eps) {
+  if (d % 8) return fail(1, "pcy_layernorm: d %% 8 != 0");
+  pcy_launch_layernorm(c->stream, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, d, eps);
+  return check_launch("pcy_layernorm");
+}
+int pcy_embed_splice(pcy_ctx* c, const void* table, const int32_t* ids, const void* soft, const int32_t* soft_map, void* out,
+                     int rows, int d) {
+  if (d % 8) return fail(1, "pcy_embed_splice: d %% 8 != 0");
+  pcy_launch_embed_gather(c->stream, (const bf16_t*)table, ids, (const bf16_t*)soft, soft_map, (bf16_t*)out, rows, d);
+  return check_launch("pcy_embed_splice");
+}
+int pcy_pool(pcy_ctx* c, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out) {
+  if (mode < 0 || mode > 2) return fail(1, "pcy_pool: mode %d", mode);
+  pcy_launch_pool(c->stream, (const bf16_t*)hidden, d, seg, rng, nprot, mode, (bf16_t*)out);
+  return check_launch("pcy_pool");
+}
+
+int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
+  if (m->n_layers < 1 || m->n_layers > 8) return fail(1, "pcy_mlp_forward: n_layers %d", m->n_layers);
+  int maxw = 0;
+  for (int i = 0; i <= m->n_layers; ++i) {
+    if (m->dims[i] % 8) return fail(1, "pcy_mlp_forward: dims must be multiples of 8");
+    if (i > 0 && i < m->n_layers && m->dims[i] > maxw) maxw = m->dims[i];
+  }
+  if (int r = c->reserve(2 * align_up((size_t)M * (maxw + 8) * 2, 256) + 4096)) return r;
+  Carver cv(c->ws);
+  bf16_t* t[2] = {cv.take<bf16_t>((size_t)M * (maxw + 8)), cv.take<bf16_t>((size_t)M * (maxw + 8))};
+  const bf16_t* cur = (const bf16_t*)x;
+  for (int i = 0; i < m->n_layers; ++i) {
+    const bool last = i == m->n_layers - 1;
+    bf16_t* dst = last ? (bf16_t*)out : t[i & 1];
+    const int K = m->dims[i], N = m->dims[i + 1];
+    if (M > 8 && K % 64 != 0) return fail(1, "pcy_mlp_forward: K=%d must be a multiple of 64 for M>8", K);
+    linear(c->stream, cur, K, (const bf16_t*)m->w[i], (const bf16_t*)m->b[i], nullptr, 0, dst, N, M, N, K,
+           last ? EPI_STORE : EPI_GELU_ERF);
+    cur = dst;
+  }
+  return check_launch("pcy_mlp_forward");
+}
+
+int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
+                   const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {
+  const int d = m->d, H = m->n_heads, F = m->ffn;
+  if (d % H) return fail(1, "pcy_esm_encode: d %% heads");
+  const int dh = d / H;
+  if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_esm_encode: head_dim %d unsupported (32/64/128)", dh);
+  if (d % 64 || F % 64) return fail(1, "pcy_esm_encode: d and ffn must be multiples of 64");
+  if (ntok <= 0) return 0;
+  const size_t need = align_up((size_t)ntok * d * 2, 256) * 3 + align_up((size_t)ntok * 3 * d * 2, 256) +
+                      align_up((size_t)ntok * F * 2, 256) + align_up((size_t)d * vt_total * 2, 256) + 4096;
+  if (int r = c->reserve(need)) return r;
+  Carver cv(c->ws);
+  bf16_t* x = cv.take<bf16_t>((size_t)ntok * d);
+  bf16_t* xn = cv.take<bf16_t>((size_t)ntok * d);
+  bf16_t* ao = cv.take<bf16_t>((size_t)ntok * d);
+  bf16_t* qkv = cv.take<bf16_t>((size_t)ntok * 3 * d);
+  bf16_t* act = cv.take<bf16_t>((size_t)ntok * F);
+  bf16_t* vt = cv.take<bf16_t>((size_t)d * vt_total);
+  hipStream_t s = c->stream;
+  pcy_launch_esm_embed(s, (const bf16_t*)m->embed, tokens, cu, nseq, max_len, x, d, mask_pads);
+  const float qscale = 1.0f / sqrtf((float)dh);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const pcy_esm_layer& L = m->layers[l];
+    pcy_launch_layernorm(s, x, (const bf16_t*)L.ln1_w, (const bf16_t*)L.ln1_b, xn, ntok, d, m->ln_eps);
+    linear(s, xn, d, (const bf16_t*)L.wqkv, (const bf16_t*)L.bqkv, nullptr, 0, qkv, 3 * d, ntok, 3 * d, d, EPI_STORE);
+    pcy_launch_rope(s, qkv, 3 * d, 0, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, qscale);
+    pcy_launch_rope(s, qkv, 3 * d, d, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, 0.f);
+    pcy_launch_transpose_v(s, qkv, 3 * d, 2 * d, H, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
+    PcyAttnArgs t{};
+    t.q = qkv; t.ldq = 3 * d; t.qcol0 = 0; t.k = qkv; t.ldk = 3 * d; t.kcol0 = d; t.vt = vt; t.vt_total = vt_total;
+    t.o = ao; t.ldo = d; t.cu = cu; t.vt_cu = vt_cu; t.keep = nullptr; t.nseq = nseq; t.max_len = max_len; t.H = H; t.Hkv = H;
+    t.dh = dh; t.causal = 0; t.scale = 1.0f;
+    pcy_launch_attn(s, t);
+    linear(s, ao, d, (const bf16_t*)L.wo, (const bf16_t*)L.bo, x, d, x, d, ntok, d, d, EPI_RESID);
+    pcy_launch_layernorm(s, x, (const bf16_t*)L.ln2_w, (const bf16_t*)L.ln2_b, xn, ntok, d, m->ln_eps);
+    linear(s, xn, d, (const bf16_t*)L.w1, (const bf16_t*)L.b1, nullptr, 0, act, F, ntok, F, d, EPI_GELU_ESM);
+    linear(s, act, F, (const bf16_t*)L.w2, (const bf16_t*)L.b2, x, d, x, d, ntok, d, F, EPI_RESID);
+  }
+  pcy_launch_layernorm(s, x, (const bf16_t*)m->final_ln_w, (const bf16_t*)m->final_ln_b, (bf16_t*)hidden_out, ntok, d, m->ln_eps);
+  return check_launch("pcy_esm_encode");
+}
+
+int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
+                      const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
+                      int n_logit_rows, void* logits_out, void* hidden_out) {
+  const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
+  if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_llama_prefill: head_dim %d unsupported (32/64/128)", dh);
+  if (d % 64 || F % 64 || (H * dh) % 64 || (Hkv * dh) % 64) return fail(1, "pcy_llama_prefill: d, ffn, H*dh, Hkv*dh must be multiples of 64");
+  if (F % 16) return fail(1, "pcy_llama_prefill: ffn %% 16");
+  if (B > kv->B || T > kv->Tmax) return fail(1, "pcy_llama_prefill: B=%d T=%d exceed cache (%d,%d)", B, T, kv->B, kv->Tmax);
+  if (T > m->max_pos) return fail(1, "pcy_llama_prefill: T=%d exceeds rope table %d", T, m->max_pos);
+  const int M = B * T, qkvw = (H + 2 * Hkv) * dh, Tp = (T + 31) / 32 * 32;
+  const int vt_total = B * Tp;
+  const size_t need = align_up((size_t)M * d * 2, 256) * 2 + align_up((size_t)M * qkvw * 2, 256) + align_up((size_t)M * H * dh * 2, 256) +
+                      align_up((size_t)M * F * 2, 256) + align_up((size_t)Hkv * dh * vt_total * 2, 256) +
+                      align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + 4096;
+  if (int r = c->reserve(need)) return r;
+  Carver cv(c->ws);
+  bf16_t* x = cv.take<bf16_t>((size_t)M * d);
+  bf16_t* xn = cv.take<bf16_t>((size_t)M * d);
+  bf16_t* qkv = cv.take<bf16_t>((size_t)M * qkvw);
+  bf16_t* ao = cv.take<bf16_t>((size_t)M * H * dh);
+  bf16_t* act = cv.take<bf16_t>((size_t)M * F);
+  bf16_t* vt = cv.take<bf16_t>((size_t)Hkv * dh * vt_total);
+  bf16_t* lastx = cv.take<bf16_t>((size_t)(n_logit_rows + 1) * d);
+  hipStream_t s = c->stream;
+  HIP_TRY(hipMemcpyAsync(x, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const pcy_llama_layer& L = m->layers[l];
+    pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
+    linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE);
+    pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
+    pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
+                          (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
+    pcy_launch_transpose_v(s, qkv, qkvw, (H + Hkv) * dh, Hkv, dh, cu, vt_cu, B, T, vt, vt_total);
+    PcyAttnArgs t{};
+    t.q = qkv; t.ldq = qkvw; t.qcol0 = 0; t.k = qkv; t.ldk = qkvw; t.kcol0 = H * dh; t.vt = vt; t.vt_total = vt_total;
+    t.o = ao; t.ldo = H * dh; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = B; t.max_len = T; t.H = H; t.Hkv = Hkv; t.dh = dh;
+    t.causal = 1; t.scale = 1.0f / sqrtf((float)dh);
+    pcy_launch_attn(s, t);
+    linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID);
+    pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
+    if (M <= 8) {
+      PcyGemvArgs u{};
+      u.W = (const bf16_t*)L.wgu; u.x = xn; u.y = act; u.N = F; u.K = d; u.B = M; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
+      pcy_launch_gemv(s, u);
+    } else {
+      linear(s, xn, d, (const bf16_t*)L.wgu, nullptr, nullptr, 0, act, F, M, 2 * F, d, EPI_SWIGLU);
+    }
+    linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID);
+  }
+  if (hidden_out) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, (bf16_t*)hidden_out, M, d, m->rms_eps, m->rms_cast);
+  if (n_logit_rows > 0 && logits_out) {
+    pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
+    PcyGemvArgs h{};
+    h.W = (const bf16_t*)m->lm_head; h.x = lastx; h.y = (bf16_t*)logits_out; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
+    h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = n_logit_rows; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
+    pcy_launch_gemv(s, h);
+  }
+  return check_launch("pcy_llama_prefill");
+}
+
+int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+  if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
+  if (int r = c->reserve(decode_ws_bytes(m, B))) return r;
+  enqueue_decode(c, m, kv, st, B);
+  return check_launch("pcy_llama_decode");
+}
+
+int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos) {
+  enqueue_pick(c, m, st, B, advance_pos);
+  return check_launch("pcy_greedy_pick");
+}
+
+int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
+                     int use_graph) {
+  if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
+  if (int r = c->reserve(decode_ws_bytes(m, B))) return r;
+  if (!use_graph) {
+    for (int i = 0; i < n_steps; ++i) {
+      enqueue_decode(c, m, kv, st, B);
+      enqueue_pick(c, m, st, B, 1);
+    }
+    return check_launch("pcy_llama_greedy");
+  }
+  const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != B) {
+    c->drop_graph();
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_decode(c, m, kv, st, B);
+    enqueue_pick(c, m, st, B, 1);
+    HIP_TRY(hipStreamEndCapture(c->stream, &g));
+    HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    memcpy(c->graph_key, key, sizeof(key));
+    c->graph_B = B;
+  }
+  for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
+  return 0;
+}
+
+int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t) {
+  const int Hkv = m->n_kv_heads, dh = m->head_dim;
+  if (t <= 0) return 0;
+  const size_t tmp_elems = (size_t)B * Hkv * t * dh;
+  if (int r = c->reserve(decode_ws_bytes(m, B) + align_up(tmp_elems * 2, 256) + 4096)) return r;
+  bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B), 256));
+  const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  for (int l = 0; l < m->n_layers; ++l)
+    for (int which = 0; which < 2; ++which) {
+      bf16_t* cache = (bf16_t*)(which ? kv->v : kv->k) + l * layer_stride;
+      hipLaunchKernelGGL(kv_gather_kernel, dim3(B, Hkv), dim3(256), 0, c->stream, cache, tmp, src_rows, Hkv, kv->Tmax, t, dh, 1);
+      hipLaunchKernelGGL(kv_gather_kernel, dim3(B, Hkv), dim3(256), 0, c->stream, tmp, cache, src_rows, Hkv, kv->Tmax, t, dh, 0);
+    }
+  return check_launch("pcy_kv_reorder");
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// bf16 MFMA GEMM for the compute-bound side of the path (ESM2 encoder, Llama prefill; rows A2/A6):
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  A and W both K-contiguous (activations x nn.Linear).
+//
+// gfx950 design (round 1: the "128x128, 2-barrier" structure of the CDNA4 guide):
+//   * 128x128x64 tile per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32 tiles)
+//   * global -> LDS by `global_load_lds_dwordx4` (16 B/lane, LDS image lane-linear), double buffered;
+//     the XOR bank swizzle is applied on the per-lane SOURCE address and on the ds_read_b128 address
+//   * operands are fed swapped (W rows as the MFMA "A" operand) so every lane ends up with 4
+//     consecutive output features of one token -> 8-byte epilogue loads/stores
+//   * fused epilogues reproduce the reference's bf16 rounding points (bias, residual add, erf-GELU,
+//     ESM op-by-op GELU, SwiGLU on 16-row interleaved gate/up weights)
+//   * any M and N (row clamping + predicated stores), K % 64 == 0
+#include "pcy_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+// stage a [128 rows][64 k] bf16 tile: 16 wave-instructions of 1 KiB; wave w issues 4 of them.
+// LDS byte (row, chunk') = row*128 + chunk'*16 holds global chunk = chunk' ^ (row & 7).
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
+                                           char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int inst = wave * 4 + i;
+    const int r = inst * 8 + (lane >> 3);
+    const int cp = lane & 7;
+    const int c = cp ^ (r & 7);
+    int gr = row0 + r;
+    gr = gr < nrows_valid ? gr : nrows_valid - 1;
+    const bf16_t* src = g + (size_t)gr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128*64] bf16 = 64 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of tiles that share A/W panels in its private L2 (bijective remap).
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  f32x4 acc[4][4];  // [n-sub][m-sub]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  constexpr int TILE_B = BM * BK * 2;  // 16 KiB; buffer b: A at b*2*TILE_B, W right after it
+
+  stage_tile(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile(a.W, a.K, n0, a.N, 0, smem + TILE_B, wave, lane);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* Acur = smem + cur * 2 * TILE_B;
+    const char* Wcur = Acur + TILE_B;
+    if (kt + 1 < nk) {
+      char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
+      stage_tile(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 xf[4], wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = lds_frag(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = lds_frag(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile
+  const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= a.M) continue;
+    if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {  // tile i = gate, i+1 = up of the same 16 features
+        const int nrow = n0 + wn * 64 + i * 16;         // packed row of the gate tile
+        const int f = (nrow >> 5) * 16 + fq * 4;        // output feature
+        if (nrow + 16 + fq * 4 >= a.N) continue;
+        bf16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = rbf(acc[i][j][r]), u = rbf(acc[i + 1][j][r]);
+          o[r] = f2bf(rbf(silu_f(g)) * u);
+        }
+        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) =
+            make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = (n + r) < a.N ? (n + r) : a.N - 1;
+          v[r] = rbf(acc[i][j][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
+        }
+        if (EPI == EPI_RESID) {
+          if (vec_ok) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
+            v[0] = rbf(v[0] + lo_bf(rr.x)); v[1] = rbf(v[1] + hi_bf(rr.x));
+            v[2] = rbf(v[2] + lo_bf(rr.y)); v[3] = rbf(v[3] + hi_bf(rr.y));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < a.N) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)m * a.ldr + n + r]));
+          }
+        }
+        if (EPI == EPI_GELU_ERF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
+        }
+        if (EPI == EPI_GELU_ESM) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_esm_chain(v[r]);
+        }
+        if (vec_ok) {
+          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) a.C[(size_t)m * a.ldc + n + r] = f2bf(v[r]);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+void launch(hipStream_t s, const PcyGemmArgs& a) {
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_kernel<EPI>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+}
+
+}  // namespace
+
+void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a) {
+  if (a.M <= 0 || a.N <= 0) return;
+  switch (a.epi) {
+    case EPI_STORE: launch<EPI_STORE>(s, a); break;
+    case EPI_RESID: launch<EPI_RESID>(s, a); break;
+    case EPI_GELU_ERF: launch<EPI_GELU_ERF>(s, a); break;
+    case EPI_GELU_ESM: launch<EPI_GELU_ESM>(s, a); break;
+    case EPI_SWIGLU: launch<EPI_SWIGLU>(s, a); break;
+  }
+}

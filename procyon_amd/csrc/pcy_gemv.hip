@@ -1,0 +1,229 @@
+// Decode-step weight-streaming GEMV for gfx950 (row A7 of SURVEY.md section 8a).
+//
+//   y[b][n] = epilogue( sum_k x[b][k] * W[n][k] ),  b < B <= 8, W in nn.Linear layout [N,K].
+//
+// HBM-bound: every weight byte is read exactly once per step (15.0 GB/token for Llama-3-8B).
+// Design:
+//   * 256-thread workgroup = 4 waves; each wave owns 4 output rows (8 weight rows for SwiGLU)
+//     and streams them with 16-byte non-temporal loads, 64 lanes x 16 B = 1 KiB contiguous
+//     per row per instruction (perfect coalescing), all loads of a K-pass issued before use.
+//   * x is staged once per workgroup in LDS as bf16 (optionally RMS-normalised in the prologue
+//     with the reference's rounding points) and re-read with ds_read_b128 -- LDS traffic is
+//     1/rows of the HBM traffic.
+//   * v_dot2c_f32_bf16 accumulates in fp32; one xor-shuffle tree per output at the end.
+//   * epilogues reproduce the reference's bf16 materialisation points (residual add, SwiGLU,
+//     bias+GELU), see pcy_common.h.
+#include "pcy_internal.h"
+
+namespace {
+
+constexpr int GEMV_THREADS = 256;
+constexpr int GEMV_WAVES = 4;
+constexpr int XS_BYTES_MAX = 65536;
+
+__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.x), __builtin_bit_cast(bf16pair, x.x), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.y), __builtin_bit_cast(bf16pair, x.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.z), __builtin_bit_cast(bf16pair, x.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.w), __builtin_bit_cast(bf16pair, x.w), acc, false);
+  return acc;
+}
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// RW = weight rows per wave (4, or 8 = 4 gate + 4 up for SwiGLU); UN = K-iterations in flight
+template <int NB, int EPI, bool RMS, int UN>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int KC) {
+  constexpr int RW = (EPI == EPI_SWIGLU) ? 8 : 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);              // [NB][KC]
+  float* red = reinterpret_cast<float*>(smem + (size_t)NB * KC * 2);  // [GEMV_WAVES]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.K;
+
+  // rows owned by this wave
+  int rows[RW];
+  bool rvalid[RW];
+  if (EPI == EPI_SWIGLU) {
+    const int f0 = blockIdx.x * 16 + wave * 4;  // first of 4 features; gate/up interleaved by 16 rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = f0 + i;
+      rvalid[i] = rvalid[i + 4] = f < a.N;
+      const int fc = f < a.N ? f : a.N - 1;
+      rows[i] = (fc >> 4) * 32 + (fc & 15);
+      rows[i + 4] = rows[i] + 16;
+    }
+  } else {
+    const int r0 = blockIdx.x * 16 + wave * 4;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      rvalid[i] = (r0 + i) < a.N;
+      rows[i] = rvalid[i] ? r0 + i : a.N - 1;
+    }
+  }
+  const bf16_t* wrow[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) wrow[i] = a.W + (size_t)rows[i] * K;
+
+  float acc[RW][NB];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
+
+  float rstd[NB];
+  if (RMS) {
+    // sum of squares over the whole row (RMS implies KC == K)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float ss = 0.f;
+      for (int k = threadIdx.x * 8; k < K; k += GEMV_THREADS * 8) {
+        uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k);
+        float f;
+        f = lo_bf(v.x); ss += f * f; f = hi_bf(v.x); ss += f * f;
+        f = lo_bf(v.y); ss += f * f; f = hi_bf(v.y); ss += f * f;
+        f = lo_bf(v.z); ss += f * f; f = hi_bf(v.z); ss += f * f;
+        f = lo_bf(v.w); ss += f * f; f = hi_bf(v.w); ss += f * f;
+      }
+      ss = block_sum<GEMV_THREADS>(ss, red);
+      rstd[b] = rsqrtf(ss / (float)K + a.rms_eps);
+    }
+  }
+
+  for (int kc0 = 0; kc0 < K; kc0 += KC) {
+    const int kc = (K - kc0) < KC ? (K - kc0) : KC;
+    __syncthreads();
+    // stage x[:, kc0:kc0+kc] into LDS
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      for (int k = threadIdx.x * 8; k < kc; k += GEMV_THREADS * 8) {
+        uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + kc0 + k);
+        if (RMS) {
+          const uint4 g = *reinterpret_cast<const uint4*>(a.rms_w + kc0 + k);
+          const uint32_t xin[4] = {v.x, v.y, v.z, v.w};
+          const uint32_t gin[4] = {g.x, g.y, g.z, g.w};
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x0 = lo_bf(xin[j]) * rstd[b], x1 = hi_bf(xin[j]) * rstd[b];
+            float w0 = lo_bf(gin[j]), w1 = hi_bf(gin[j]);
+            if (a.rms_cast == 0) { x0 = rbf(x0); x1 = rbf(x1); }
+            o[j] = pack_bf(w0 * x0, w1 * x1);
+          }
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<uint4*>(xs + (size_t)b * KC + k) = v;
+      }
+    }
+    __syncthreads();
+    const int nit = (kc + 511) >> 9;  // 512 elements per wave-iteration
+    for (int it0 = 0; it0 < nit; it0 += UN) {
+      uint4 wv[UN][RW];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int k = ((it0 + u) * 64 + lane) * 8;
+        const bool ok = k < kc;
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+          wv[u][i] = ok ? ldg_nt(wrow[i] + kc0 + k) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int k = ((it0 + u) * 64 + lane) * 8;
+        if (k < kc) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(xs + (size_t)b * KC + k);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) acc[i][b] = dot8(wv[u][i], xv, acc[i][b]);
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[i][b] = wave_sum(acc[i][b]);
+
+  if (lane == 0) {
+    if (EPI == EPI_SWIGLU) {
+      const int f0 = blockIdx.x * 16 + wave * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!rvalid[i]) continue;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float g = rbf(acc[i][b]), u = rbf(acc[i + 4][b]);
+          const float s = rbf(silu_f(g));
+          a.y[(size_t)b * a.ldy + f0 + i] = f2bf(s * u);
+        }
+      }
+    } else {
+      const int r0 = blockIdx.x * 16 + wave * 4;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        if (!rvalid[i]) continue;
+        const int n = r0 + i;
+        const float bias = a.bias ? bf2f(a.bias[n]) : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float v = rbf(acc[i][b] + bias);
+          if (EPI == EPI_RESID) v = rbf(v + bf2f(a.resid[(size_t)b * a.ldy + n]));
+          if (EPI == EPI_GELU_ERF) v = rbf(gelu_erf_f(v));
+          if (EPI == EPI_GELU_ESM) v = gelu_esm_chain(v);
+          a.y[(size_t)b * a.ldy + n] = f2bf(v);
+        }
+      }
+    }
+  }
+}
+
+template <int NB, int EPI, bool RMS>
+void launch_nb(hipStream_t s, const PcyGemvArgs& a) {
+  int KC = a.K;
+  if ((size_t)NB * KC * 2 > XS_BYTES_MAX) KC = (XS_BYTES_MAX / (NB * 2)) & ~511;
+  const size_t smem = (size_t)NB * KC * 2 + 64;
+  const int blocks = (a.N + 15) / 16;
+  constexpr int UN = (EPI == EPI_SWIGLU) ? 2 : 4;
+  hipLaunchKernelGGL((gemv_kernel<NB, EPI, RMS, UN>), dim3(blocks), dim3(GEMV_THREADS), smem, s, a, KC);
+}
+
+template <int NB>
+void launch_epi(hipStream_t s, const PcyGemvArgs& a) {
+  const bool rms = a.rms_w != nullptr;
+  switch (a.epi) {
+    case EPI_STORE: rms ? launch_nb<NB, EPI_STORE, true>(s, a) : launch_nb<NB, EPI_STORE, false>(s, a); break;
+    case EPI_RESID: launch_nb<NB, EPI_RESID, false>(s, a); break;
+    case EPI_GELU_ERF: launch_nb<NB, EPI_GELU_ERF, false>(s, a); break;
+    case EPI_GELU_ESM: launch_nb<NB, EPI_GELU_ESM, false>(s, a); break;
+    case EPI_SWIGLU: rms ? launch_nb<NB, EPI_SWIGLU, true>(s, a) : launch_nb<NB, EPI_SWIGLU, false>(s, a); break;
+  }
+}
+
+}  // namespace
+
+void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a0) {
+  // batch rows in groups of <= 4 (weights are re-streamed per group; the skinny-MFMA path for
+  // larger decode batches is a TODO tracked in DESIGN.md)
+  for (int b0 = 0; b0 < a0.B; b0 += 4) {
+    PcyGemvArgs a = a0;
+    const int nb = (a0.B - b0) < 4 ? (a0.B - b0) : 4;
+    a.x = a0.x + (size_t)b0 * a0.ldx;
+    a.y = a0.y + (size_t)b0 * a0.ldy;
+    if (a0.resid) a.resid = a0.resid + (size_t)b0 * a0.ldy;
+    a.B = nb;
+    switch (nb) {
+      case 1: launch_epi<1>(s, a); break;
+      case 2: launch_epi<2>(s, a); break;
+      case 3: launch_epi<3>(s, a); break;
+      default: launch_epi<4>(s, a); break;
+    }
+  }
+}

@@ -1,0 +1,79 @@
+// Internal launcher prototypes shared by the engine translation units.
+#pragma once
+#include "pcy_common.h"
+
+struct PcyGemvArgs {
+  const bf16_t* W;      // [N,K] row-major (nn.Linear layout); EPI_SWIGLU: [2N,K], 16-row gate/up interleave
+  const bf16_t* x;      // [B,K] (ldx elements between rows)
+  bf16_t* y;            // [B,N] (ldy)
+  const bf16_t* bias;   // [N] or null
+  const bf16_t* resid;  // [B,N] (ldy) or null (EPI_RESID); may alias y
+  const bf16_t* rms_w;  // non-null: x is the raw hidden state; RMSNorm(x)*rms_w is fused in the prologue
+  float rms_eps;
+  int rms_cast;         // 0: w * bf16(x_hat) (transformers>=4.32) ; 1: bf16(w * x_hat) (4.31)
+  int N, K, B, ldx, ldy, epi;
+};
+void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
+
+struct PcyGemmArgs {
+  const bf16_t* A;      // [M,K] lda
+  const bf16_t* W;      // [N,K] row-major; EPI_SWIGLU: N counts interleaved gate/up rows (output width N/2)
+  bf16_t* C;            // [M,N] ldc (or [M,N/2])
+  const bf16_t* bias;   // [N] or null
+  const bf16_t* resid;  // [M,N] ldr or null; may alias C
+  int M, N, K, lda, ldc, ldr, epi;
+};
+void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
+
+void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int d, float eps, int cast);
+void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps);
+void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
+                             const int32_t* soft_map, bf16_t* out, int rows, int d);
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d);
+void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
+                          int max_len, bf16_t* out, int d, int mask_pads);
+// rope on heads [0,nh) located at column col0 of a token-major buffer; pos[tok] = rotary position.
+// mode 0: three roundings in bf16 (HF Llama); mode 1: fp32 once (HF ESM). prescale != 0: x = bf16(x*prescale) first.
+void pcy_launch_rope(hipStream_t s, bf16_t* buf, int ld, int col0, int nh, int dh, const int32_t* pos,
+                     const bf16_t* cos_t, const bf16_t* sin_t, int ntok, int mode, float prescale);
+// scatter roped K and V of a token-major qkv buffer into the [B,Hkv,Tmax,dh] cache at slots [0,T)
+void pcy_launch_kv_scatter(hipStream_t s, const bf16_t* qkv, int ld, int kcol0, int vcol0, int Hkv, int dh,
+                           bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax);
+// V (token-major, column vcol0, nh heads) -> Vt[nh][dh][vt_total], sequence q occupies columns vt_cu[q]+j
+void pcy_launch_transpose_v(hipStream_t s, const bf16_t* buf, int ld, int vcol0, int nh, int dh, const int32_t* cu,
+                            const int32_t* vt_cu, int nseq, int max_len, bf16_t* vt, int vt_total);
+
+struct PcyAttnArgs {
+  const bf16_t* q; int ldq; int qcol0;   // token-major, head h at column qcol0 + h*dh
+  const bf16_t* k; int ldk; int kcol0;   // token-major, kv head at kcol0 + kvh*dh
+  const bf16_t* vt; int vt_total;        // [Hkv][dh][vt_total]
+  bf16_t* o; int ldo;                    // token-major [ntok, H*dh]
+  const int32_t* cu; const int32_t* vt_cu;  // [nseq+1]
+  const uint8_t* keep;                   // per token key-keep flag (attention_mask) or null
+  int nseq, max_len, H, Hkv, dh, causal;
+  float scale;                           // multiplied into bf16 scores, then rounded (1.0 = none)
+};
+void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a);
+
+struct PcyDecAttnArgs {
+  bf16_t* qkv; int ld;            // [B, (H+2Hkv)*dh] un-roped projections of the new token
+  bf16_t* kcache; bf16_t* vcache; // [B,Hkv,Tmax,dh]
+  bf16_t* o; int ldo;             // [B, H*dh]
+  const int32_t* pos_dev;         // device scalar: cache length t == rotary position of the new token
+  const bf16_t* cos_t; const bf16_t* sin_t;  // [max_pos, dh]
+  const uint8_t* keep; int ld_keep;  // optional [B,Tmax] key-keep mask ("clean" mode) or null (reference quirk Q1)
+  float* scratch;                 // [B*H*Tmax] fp32 probabilities workspace
+  int B, H, Hkv, dh, Tmax; float scale;
+};
+void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
+
+// pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
+void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot,
+                     int mode, bf16_t* out);
+// per-row argmax (lowest index on ties) over bf16 logits [B,V]; accumulates log_softmax(logits)[tok] into
+// logprob[B] (bf16 log-softmax, fp32 running sum), appends tok to tokens_out[b*max_steps + step], writes
+// next_tok[b], then (one thread) ++*step and, if advance_pos, ++*pos.
+void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
+                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos);
+void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
+                          int nrows, int d);

@@ -1,0 +1,452 @@
+"""Host wrappers over the C ABI (include/pcy.h): weight packing, descriptors, KV cache, packing of
+varlen protein batches.  torch is plumbing only -- device memory, streams, index arithmetic; all
+model arithmetic runs in libpcy.so's HIP kernels.  No fallback path exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == BF16 and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
+
+
+class Context:
+    """One engine context per (device, stream).  Launches go to torch's current stream."""
+    _cache = {}
+
+    def __init__(self, device=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.PcyError("no HIP device visible: the ProCyon engine needs an MI355X (no CPU fallback)")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = dev
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        h = C.c_void_p()
+        L.check(self.lib.pcy_ctx_create(dev.index or 0, C.c_void_p(stream), C.byref(h)), "pcy_ctx_create")
+        self.h = h
+
+    @classmethod
+    def get(cls, device=None):
+        L.load()
+        if not torch.cuda.is_available():
+            raise L.PcyError("no HIP device visible: the ProCyon engine needs an MI355X (no CPU fallback)")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+        if key not in cls._cache:
+            cls._cache[key] = Context(dev)
+        return cls._cache[key]
+
+    def sync(self):
+        L.check(self.lib.pcy_ctx_sync(self.h), "sync")
+
+    def timer_start(self):
+        L.check(self.lib.pcy_timer_start(self.h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        L.check(self.lib.pcy_timer_stop(self.h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    # ---- primitive ops -------------------------------------------------------------------------
+    def gemm(self, A, W, bias=None, resid=None, epi=L.EPI_STORE, out=None):
+        _chk_bf16(A, W, bias, resid)
+        M, K = A.shape
+        N = W.shape[0]
+        Nout = N // 2 if epi == L.EPI_SWIGLU else N
+        out = torch.empty(M, Nout, dtype=BF16, device=A.device) if out is None else out
+        L.check(self.lib.pcy_gemm(self.h, _p(A), K, _p(W), _p(bias), _p(resid), 0 if resid is None else resid.shape[1],
+                                  _p(out), Nout, M, N, K, epi), "pcy_gemm")
+        return out
+
+    def gemv(self, W, x, bias=None, resid=None, epi=L.EPI_STORE, rms_w=None, rms_eps=1e-5, rms_cast=0, out=None):
+        _chk_bf16(W, x, bias, resid, rms_w)
+        B, K = x.shape
+        N = W.shape[0] // 2 if epi == L.EPI_SWIGLU else W.shape[0]
+        out = torch.empty(B, N, dtype=BF16, device=x.device) if out is None else out
+        L.check(self.lib.pcy_gemv(self.h, _p(W), _p(x), K, _p(bias), _p(resid), _p(out), N, _p(rms_w), rms_eps, rms_cast,
+                                  N, K, B, epi), "pcy_gemv")
+        return out
+
+    def rmsnorm(self, x, w, eps=1e-5, cast=0):
+        _chk_bf16(x, w)
+        y = torch.empty_like(x)
+        L.check(self.lib.pcy_rmsnorm(self.h, _p(x), _p(w), _p(y), x.numel() // x.shape[-1], x.shape[-1], eps, cast), "rmsnorm")
+        return y
+
+    def layernorm(self, x, w, b, eps=1e-5):
+        _chk_bf16(x, w, b)
+        y = torch.empty_like(x)
+        L.check(self.lib.pcy_layernorm(self.h, _p(x), _p(w), _p(b), _p(y), x.numel() // x.shape[-1], x.shape[-1], eps), "layernorm")
+        return y
+
+    def embed_splice(self, table, ids, soft=None, soft_map=None):
+        """ids int32 [rows]; soft_map int32 [rows] (-1 = take table row)."""
+        _chk_bf16(table, soft)
+        rows, d = ids.numel(), table.shape[1]
+        out = torch.empty(rows, d, dtype=BF16, device=table.device)
+        L.check(self.lib.pcy_embed_splice(self.h, _p(table), _p(ids), _p(soft), _p(soft_map), _p(out), rows, d), "embed_splice")
+        return out
+
+    def pool(self, hidden, seg, rng, nprot, mode):
+        _chk_bf16(hidden)
+        d = hidden.shape[-1]
+        out = torch.empty(nprot, d, dtype=BF16, device=hidden.device)
+        L.check(self.lib.pcy_pool(self.h, _p(hidden), d, _p(seg), _p(rng), nprot, mode, _p(out)), "pool")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class MlpEngine:
+    """`create_mlp` projector (reference procyon/model/model_utils.py:13-41), eval mode."""
+
+    def __init__(self, layers, ctx=None):
+        self.ctx = ctx or Context.get()
+        self.layers = [(w.contiguous(), None if b is None else b.contiguous()) for w, b in layers]
+        n = len(self.layers)
+        assert 1 <= n <= 8
+        d = L.MlpDesc()
+        d.n_layers = n
+        d.dims[0] = self.layers[0][0].shape[1]
+        for i, (w, b) in enumerate(self.layers):
+            _chk_bf16(w, b)
+            d.dims[i + 1] = w.shape[0]
+            d.w[i] = w.data_ptr()
+            d.b[i] = 0 if b is None else b.data_ptr()
+        self.desc = d
+        self.in_features, self.out_features = d.dims[0], d.dims[n]
+
+    def __call__(self, x):
+        shape = x.shape
+        x = x.reshape(-1, shape[-1]).contiguous()
+        _chk_bf16(x)
+        out = torch.empty(x.shape[0], self.out_features, dtype=BF16, device=x.device)
+        if x.shape[0]:
+            L.check(self.ctx.lib.pcy_mlp_forward(self.ctx.h, C.byref(self.desc), _p(x), x.shape[0], _p(out)), "pcy_mlp_forward")
+        return out.reshape(*shape[:-1], self.out_features)
+
+
+# ------------------------------------------------------------------------------------------------
+def rope_tables(dh, theta, n_pos, device, inv_freq_bf16=False):
+    """cos/sin [n_pos, dh] bf16.  Default: fp32 inv_freq, table rounded once (transformers 4.31's cached
+    tables).  inv_freq_bf16=True reproduces transformers 5.x after `.bfloat16()`."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    if inv_freq_bf16:
+        inv_freq = inv_freq.to(BF16).float()
+    pos = torch.arange(n_pos, dtype=torch.float32)
+    freqs = (inv_freq[:, None] @ pos[None, :]).transpose(0, 1)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(BF16).to(device).contiguous(), emb.sin().to(BF16).to(device).contiguous()
+
+
+@dataclass
+class LlamaConfig:
+    vocab: int
+    d: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    ffn: int
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0   # reference-compat default (App. B Q9); Llama-3's own value is 500000
+    max_pos: int = 8192
+    rms_cast: str = "hf5"         # 'hf5' (>=4.32) or 'hf431'
+    rope_inv_freq_bf16: bool = False
+
+    @property
+    def head_dim(self):
+        return self.d // self.n_heads
+
+
+def interleave_gate_up(gate, up):
+    """[F,d],[F,d] -> [2F,d] with 16-row gate/up interleave (layout the SwiGLU epilogues expect)."""
+    F_, d = gate.shape
+    assert F_ % 16 == 0
+    return torch.stack([gate.view(F_ // 16, 16, d), up.view(F_ // 16, 16, d)], dim=1).reshape(2 * F_, d).contiguous()
+
+
+class KVCache:
+    """[L,B,Hkv,Tmax,dh] x2; `layer(l)` gives the reference's past_key_values[l] views."""
+
+    def __init__(self, cfg: LlamaConfig, B, Tmax, device):
+        self.k = torch.zeros(cfg.n_layers, B, cfg.n_kv_heads, Tmax, cfg.head_dim, dtype=BF16, device=device)
+        self.v = torch.zeros_like(self.k)
+        self.B, self.Tmax = B, Tmax
+        self.c = L.KvCache(self.k.data_ptr(), self.v.data_ptr(), B, Tmax)
+
+    def layer(self, l, t):
+        return self.k[l, :, :, :t], self.v[l, :, :, :t]
+
+
+class GenState:
+    def __init__(self, B, vocab, max_steps, device, keep_logits=False, keep=None):
+        self.pos = torch.zeros(1, dtype=torch.int32, device=device)
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        self.next_tok = torch.zeros(B, dtype=torch.int32, device=device)
+        self.tokens_out = torch.zeros(B, max_steps, dtype=torch.int32, device=device)
+        self.logprob = torch.zeros(B, dtype=torch.float32, device=device)
+        self.logits = torch.empty(B, vocab, dtype=BF16, device=device)
+        self.logits_all = torch.empty(max_steps, B, vocab, dtype=BF16, device=device) if keep_logits else None
+        self.keep = keep
+        self.c = L.GenState(self.pos.data_ptr(), self.step.data_ptr(), self.next_tok.data_ptr(), self.tokens_out.data_ptr(),
+                            self.logprob.data_ptr(), self.logits.data_ptr(),
+                            0 if self.logits_all is None else self.logits_all.data_ptr(),
+                            0 if keep is None else keep.data_ptr(), max_steps)
+
+
+class LlamaEngine:
+    """HF-Llama-architecture decoder behind `LlamaPostTokenization.forward` (pmc_llama.py:546-596)."""
+
+    def __init__(self, sd, cfg: LlamaConfig, device=None, ctx=None, free_source=False):
+        self.ctx = ctx or Context.get(device)
+        self.cfg = cfg
+        dev = self.ctx.device
+        self.device = dev
+        g = lambda k: sd[k].to(dev, BF16).contiguous()
+        self.embed = g("model.embed_tokens.weight")
+        self.final_norm = g("model.norm.weight")
+        self.lm_head = g("lm_head.weight")
+        self.cos, self.sin = rope_tables(cfg.head_dim, cfg.rope_theta, cfg.max_pos, dev, cfg.rope_inv_freq_bf16)
+        self._keep = []
+        arr = (L.LlamaLayer * cfg.n_layers)()
+        for l in range(cfg.n_layers):
+            p = f"model.layers.{l}."
+            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                              g(p + "self_attn.v_proj.weight")], 0).contiguous()
+            wo = g(p + "self_attn.o_proj.weight")
+            wgu = interleave_gate_up(g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"))
+            wdown = g(p + "mlp.down_proj.weight")
+            ln1, ln2 = g(p + "input_layernorm.weight"), g(p + "post_attention_layernorm.weight")
+            self._keep.append((wqkv, wo, wgu, wdown, ln1, ln2))
+            arr[l] = L.LlamaLayer(*[t.data_ptr() for t in (wqkv, wo, wgu, wdown, ln1, ln2)])
+            if free_source:
+                for k in [k for k in sd if k.startswith(p)]:
+                    del sd[k]
+        self._arr = arr
+        self.desc = L.LlamaDesc(cfg.vocab, cfg.d, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim, cfg.ffn,
+                                cfg.max_pos, cfg.rms_eps, 0 if cfg.rms_cast == "hf5" else 1, self.embed.data_ptr(),
+                                self.final_norm.data_ptr(), self.lm_head.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
+                                C.cast(arr, C.POINTER(L.LlamaLayer)))
+
+    def new_cache(self, B, Tmax):
+        return KVCache(self.cfg, B, Tmax, self.device)
+
+    def embed_tokens(self, ids, soft=None, soft_map=None):
+        """ids [B,T] int -> [B,T,d]; soft-token splice of `_prepare_input_embeddings` if soft_map given."""
+        B, T = ids.shape
+        i32 = ids.to(self.device, torch.int32).contiguous().view(-1)
+        sm = None if soft_map is None else soft_map.to(self.device, torch.int32).contiguous().view(-1)
+        return self.ctx.embed_splice(self.embed, i32, soft, sm).view(B, T, self.cfg.d)
+
+    def prefill(self, embeds, attn_mask, cache: KVCache, logit_rows="last", want_hidden=False):
+        """embeds [B,T,d] bf16; attn_mask [B,T] (0/1) or None.  Returns (logits [n,V], hidden [B,T,d]|None)."""
+        B, T, d = embeds.shape
+        embeds = embeds.contiguous()
+        _chk_bf16(embeds)
+        dev = self.device
+        keep = None
+        if attn_mask is not None and not bool((attn_mask != 0).all()):
+            keep = (attn_mask != 0).to(dev, torch.uint8).contiguous()
+        pos = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        Tp = (T + 31) // 32 * 32
+        cu = torch.arange(B + 1, dtype=torch.int32, device=dev) * T
+        vt_cu = torch.arange(B + 1, dtype=torch.int32, device=dev) * Tp
+        if isinstance(logit_rows, str) and logit_rows == "last":
+            rows = (torch.arange(B, dtype=torch.int32, device=dev) + 1) * T - 1
+        elif logit_rows is None:
+            rows = torch.zeros(0, dtype=torch.int32, device=dev)
+        else:
+            rows = logit_rows.to(dev, torch.int32).contiguous()
+        n = rows.numel()
+        logits = torch.empty(n, self.cfg.vocab, dtype=BF16, device=dev)
+        hidden = torch.empty(B, T, d, dtype=BF16, device=dev) if want_hidden else None
+        L.check(self.ctx.lib.pcy_llama_prefill(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(embeds), _p(keep), _p(pos),
+                                               _p(cu), _p(vt_cu), B, T, _p(rows), n, _p(logits), _p(hidden)), "pcy_llama_prefill")
+        return logits, hidden
+
+    def decode(self, cache: KVCache, st: GenState, B):
+        L.check(self.ctx.lib.pcy_llama_decode(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode")
+
+    def pick(self, st: GenState, B, advance_pos):
+        L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(st.c), B, int(advance_pos)), "pcy_greedy_pick")
+
+    def greedy_steps(self, cache, st, B, n_steps, use_graph=True):
+        L.check(self.ctx.lib.pcy_llama_greedy(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, n_steps,
+                                              int(use_graph)), "pcy_llama_greedy")
+
+    def kv_reorder(self, cache, src_rows, t):
+        src = src_rows.to(self.device, torch.int32).contiguous()
+        L.check(self.ctx.lib.pcy_kv_reorder(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(src), src.numel(), t), "pcy_kv_reorder")
+
+    def generate_greedy(self, embeds, attn_mask, max_len, keep_logits=False, clean_decode_mask=False, use_graph=True):
+        """`_generate_sampling(greedy=True)` (model_unified.py:861-921): prefill, then max_len-1 cached decode
+        steps with no mask and position = cache length (Q1/Q2); no EOS stop.  Everything stays on the device;
+        returns (tokens [B,max_len] int64, logprob [B] fp32, logits [B,max_len,V] bf16 | None, state)."""
+        B, T, _ = embeds.shape
+        cache = self.new_cache(B, T + max_len)
+        keep = None
+        if clean_decode_mask and attn_mask is not None:
+            keep = torch.ones(B, T + max_len, dtype=torch.uint8, device=self.device)
+            keep[:, :T] = (attn_mask != 0).to(self.device, torch.uint8)
+        st = GenState(B, self.cfg.vocab, max_len, self.device, keep_logits, keep)
+        logits, _ = self.prefill(embeds, attn_mask, cache, "last")
+        st.logits.copy_(logits)
+        st.pos.fill_(T)
+        self.pick(st, B, advance_pos=False)
+        if max_len > 1:
+            self.greedy_steps(cache, st, B, max_len - 1, use_graph)
+        la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
+        return st.tokens_out.long(), st.logprob, la, (st, cache)
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class EsmConfig:
+    d: int
+    n_layers: int
+    n_heads: int
+    ffn: int
+    vocab: int = 33
+    ln_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    rope_math: str = "fp32_once"   # HF Esm; 'model_dtype' = fair-esm's three roundings
+    rope_inv_freq_bf16: bool = False
+    max_len: int = 1026
+
+    @property
+    def head_dim(self):
+        return self.d // self.n_heads
+
+
+PAD_ID, CLS_ID, EOS_ID, MASK_ID = 1, 0, 2, 32
+
+
+def batched_split_long_seq(toks, padding_idx=1, eos_idx=2, max_protein_len=1024):
+    """Host mirror of `batched_split_long_seq(..., "split")` (procyon/training/train_utils.py:1497-1571),
+    non-mutating.  toks int64 CPU [B,W] -> (rows [B',max_protein_len+2], keys [B'])."""
+    toks = toks.clone()
+    W = toks.shape[1]
+    cls_idx = int(toks[0, 0])
+    add, keys = [], list(range(toks.shape[0]))
+    for i in range(toks.shape[0]):
+        e = int((toks[i] == eos_idx).nonzero(as_tuple=True)[0][0])
+        if e <= max_protein_len + 1:
+            continue
+        n_add = e // (max_protein_len + 1)
+        for j in range(n_add):
+            bot = (j + 1) * max_protein_len + 1
+            row = torch.full((1, W), padding_idx, dtype=torch.int64)
+            tail = toks[i, bot:]
+            row[0, 1:tail.shape[0] + 1] = tail
+            row[0, 0] = cls_idx
+            if j < n_add - 1:
+                row[0, max_protein_len + 1] = eos_idx
+                row[0, max_protein_len + 2:] = 1
+            add.append(row)
+            keys.append(i)
+        toks[i, max_protein_len + 2:] = padding_idx
+        toks[i, max_protein_len + 1] = eos_idx
+    new = torch.cat([toks] + add, dim=0)[:, : max_protein_len + 2]
+    return new, torch.tensor(keys, dtype=torch.int64)
+
+
+class EsmEngine:
+    """ESM2 encoder + ProteinPooler behind `ESM_PLM.forward` (procyon/model/esm.py:504-558)."""
+
+    def __init__(self, sd, cfg: EsmConfig, device=None, ctx=None):
+        self.ctx = ctx or Context.get(device)
+        self.cfg = cfg
+        dev = self.ctx.device
+        self.device = dev
+        g = lambda k: sd[k].to(dev, BF16).contiguous()
+        self.embed = g("esm.embeddings.word_embeddings.weight")
+        self.fw, self.fb = g("esm.encoder.emb_layer_norm_after.weight"), g("esm.encoder.emb_layer_norm_after.bias")
+        self.cos, self.sin = rope_tables(cfg.head_dim, cfg.rope_theta, cfg.max_len, dev, cfg.rope_inv_freq_bf16)
+        self._keep = []
+        arr = (L.EsmLayer * cfg.n_layers)()
+        for l in range(cfg.n_layers):
+            p = f"esm.encoder.layer.{l}."
+            wqkv = torch.cat([g(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")], 0).contiguous()
+            bqkv = torch.cat([g(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")], 0).contiguous()
+            ts = (wqkv, bqkv, g(p + "attention.output.dense.weight"), g(p + "attention.output.dense.bias"),
+                  g(p + "attention.LayerNorm.weight"), g(p + "attention.LayerNorm.bias"),
+                  g(p + "intermediate.dense.weight"), g(p + "intermediate.dense.bias"),
+                  g(p + "output.dense.weight"), g(p + "output.dense.bias"), g(p + "LayerNorm.weight"), g(p + "LayerNorm.bias"))
+            self._keep.append(ts)
+            arr[l] = L.EsmLayer(*[t.data_ptr() for t in ts])
+        self._arr = arr
+        self.desc = L.EsmDesc(cfg.d, cfg.n_layers, cfg.n_heads, cfg.ffn, cfg.vocab, cfg.ln_eps,
+                              1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
+                              self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
+
+    # ---- packing ---------------------------------------------------------------------------------
+    @staticmethod
+    def pack(rows, mask_pads=True):
+        """rows int64 CPU [B',S] (right-padded) -> packed tokens + index arrays (all CPU int32).
+        mask_pads=True packs only the non-pad prefix of each row; False keeps pads as tokens (Q12)."""
+        Bp, S = rows.shape
+        lens = (rows != PAD_ID).sum(1) if mask_pads else torch.full((Bp,), S, dtype=torch.int64)
+        real = (rows != PAD_ID).sum(1)
+        cu = torch.zeros(Bp + 1, dtype=torch.int64)
+        cu[1:] = lens.cumsum(0)
+        vt_cu = torch.zeros(Bp + 1, dtype=torch.int64)
+        vt_cu[1:] = ((lens + 31) // 32 * 32).cumsum(0)
+        idx = torch.arange(S)[None, :] < lens[:, None]
+        tokens = rows[idx]
+        pos = torch.arange(S)[None, :].expand(Bp, S)[idx]
+        return dict(tokens=tokens.to(torch.int32), pos=pos.to(torch.int32), cu=cu.to(torch.int32), vt_cu=vt_cu.to(torch.int32),
+                    lens=lens, real=real, ntok=int(cu[-1]), nseq=Bp, max_len=int(lens.max()), vt_total=int(vt_cu[-1]))
+
+    def encode_packed(self, pk, mask_pads=True):
+        dev = self.device
+        if pk["max_len"] > self.cfg.max_len:
+            raise ValueError(f"sequence of {pk['max_len']} tokens exceeds the rotary table ({self.cfg.max_len})")
+        t = {k: pk[k].to(dev) for k in ("tokens", "pos", "cu", "vt_cu")}
+        hidden = torch.empty(pk["ntok"], self.cfg.d, dtype=BF16, device=dev)
+        L.check(self.ctx.lib.pcy_esm_encode(self.ctx.h, C.byref(self.desc), _p(t["tokens"]), _p(t["pos"]), _p(t["cu"]), _p(t["vt_cu"]),
+                                            pk["ntok"], pk["nseq"], pk["max_len"], pk["vt_total"], int(mask_pads), _p(hidden)),
+                "pcy_esm_encode")
+        self._last = t  # keep index tensors alive until the stream has consumed them
+        return hidden
+
+    def hidden_states(self, rows, mask_pads=True):
+        """rows int64 [B',S] -> padded [B',S,d] representations (pad slots zero-filled; test helper)."""
+        pk = self.pack(rows.cpu(), mask_pads)
+        h = self.encode_packed(pk, mask_pads)
+        Bp, S = rows.shape
+        out = torch.zeros(Bp, S, self.cfg.d, dtype=BF16, device=self.device)
+        idx = (torch.arange(S)[None, :] < pk["lens"][:, None]).to(self.device)
+        out[idx] = h
+        return out
+
+    def forward(self, tokens, pooling="mean", correction=False, mask_pads=True, max_protein_len=1024):
+        """`ESM_PLM.forward(tokens, aggregate=True)`: split long proteins, encode, pool per original protein."""
+        rows, keys = batched_split_long_seq(tokens.cpu().long(), max_protein_len=max_protein_len)
+        pk = self.pack(rows, mask_pads)
+        h = self.encode_packed(pk, mask_pads)
+        nprot = int(keys.max()) + 1
+        seg = [0]
+        rng = []
+        for i in range(nprot):
+            for r in (keys == i).nonzero(as_tuple=True)[0].tolist():  # chunk rows in batch order (esm.py:168-170)
+                rng += [int(pk["cu"][r]), int(pk["real"][r])]          # pads never enter the pool (esm.py:171-173)
+            seg.append(len(rng) // 2)
+        mode = {"mean": L.POOL_MEAN_CORRECTED if correction else L.POOL_MEAN, "max": L.POOL_MAX}[pooling]
+        seg_t = torch.tensor(seg, dtype=torch.int32, device=self.device)
+        rng_t = torch.tensor(rng, dtype=torch.int32, device=self.device)
+        return self.ctx.pool(h, seg_t, rng_t, nprot, mode)

@@ -1,0 +1,154 @@
+"""GPU parity: every primitive of libpcy.so (called through the C ABI) against the oracle's torch-CPU
+restatement on the same seeded inputs.  Tolerance (stated once): bf16 outputs of two fp32-accumulating
+implementations must agree except for rare 1-ulp flips -> `assert_bf16_close` (<= 2 bf16 ulp anywhere,
+<= 2% of elements different) and norm-wise relative error <= 1e-3 (BASELINE.json north_star)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_bf16_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from procyon_amd.engine import Context
+    return Context.get()
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(BF)
+
+
+def esm_gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def ref_linear(A, W, bias, resid, epi):
+    y = F.linear(A, W, bias)
+    if epi == 1:
+        y = y + resid
+    if epi == 2:
+        y = F.gelu(y)
+    if epi == 3:
+        y = esm_gelu(y)
+    return y
+
+
+GEMM_SHAPES = [(200, 384, 256), (1026, 1280, 1280), (130, 1001, 128), (17, 256, 5120), (640, 3840, 1280)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm(ctx, M, N, K, epi):
+    A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=0.05), rnd(N, seed=3, std=0.1), rnd(M, N, seed=4)
+    out = ctx.gemm(A.cuda(), W.cuda(), b.cuda(), r.cuda() if epi == 1 else None, epi).cpu()
+    ref = ref_linear(A, W, b, r, epi)
+    assert_bf16_close(out, ref, f"gemm {M}x{N}x{K} epi{epi}")
+    assert rel_err(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize("M,F_,K", [(200, 256, 256), (1026, 512, 128), (33, 1792, 512)])
+def test_gemm_swiglu(ctx, M, F_, K):
+    from procyon_amd.engine import interleave_gate_up
+    A, g, u = rnd(M, K, seed=1), rnd(F_, K, seed=2, std=0.1), rnd(F_, K, seed=3, std=0.1)
+    W = interleave_gate_up(g, u)
+    out = ctx.gemm(A.cuda(), W.cuda(), None, None, 4).cpu()
+    ref = F.silu(F.linear(A, g)) * F.linear(A, u)
+    assert_bf16_close(out, ref, "gemm swiglu")
+
+
+def test_gemm_transpose_detecting(ctx):
+    """A = I with an asymmetric W (CDNA guide G9): catches a transposed or permuted output tile."""
+    K = 128
+    A = torch.eye(K).to(BF)
+    W = ((torch.arange(256 * K).view(256, K) * 7) % 97 - 48).float().to(BF)
+    out = ctx.gemm(A.cuda(), W.cuda()).cpu()
+    assert torch.equal(out, W.t().contiguous())
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 14336), (1000, 1280), (130, 136)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemv(ctx, B, N, K, epi):
+    x, W, b, r = rnd(B, K, seed=1), rnd(N, K, seed=2, std=0.05), rnd(N, seed=3, std=0.1), rnd(B, N, seed=4)
+    out = ctx.gemv(W.cuda(), x.cuda(), b.cuda(), r.cuda() if epi == 1 else None, epi).cpu()
+    ref = ref_linear(x, W, b, r, epi)
+    assert_bf16_close(out, ref, f"gemv B{B} {N}x{K} epi{epi}")
+
+
+@pytest.mark.parametrize("B", [1, 4])
+@pytest.mark.parametrize("cast", [0, 1])
+def test_gemv_fused_rms_and_swiglu(ctx, B, cast):
+    from oracle.llama_ref import rms_norm
+    from procyon_amd.engine import interleave_gate_up
+    K, Fh = 4096, 1024
+    x, w = rnd(B, K, seed=1), (1 + 0.02 * torch.randn(K)).to(BF)
+    g, u = rnd(Fh, K, seed=2, std=0.03), rnd(Fh, K, seed=3, std=0.03)
+    xn = rms_norm(x, w, 1e-5, "hf5" if cast == 0 else "hf431")
+    out = ctx.gemv(interleave_gate_up(g, u).cuda(), x.cuda(), epi=4, rms_w=w.cuda(), rms_eps=1e-5, rms_cast=cast).cpu()
+    ref = F.silu(F.linear(xn, g)) * F.linear(xn, u)
+    assert_bf16_close(out, ref, "gemv rms+swiglu")
+    Wq = rnd(768, K, seed=5, std=0.03)
+    out = ctx.gemv(Wq.cuda(), x.cuda(), epi=0, rms_w=w.cuda(), rms_eps=1e-5, rms_cast=cast).cpu()
+    assert_bf16_close(out, F.linear(xn, Wq), "gemv rms+store")
+
+
+@pytest.mark.parametrize("d", [4096, 1280, 136])
+def test_norms(ctx, d):
+    from oracle.llama_ref import rms_norm
+    x, w, b = rnd(37, d, seed=1, std=2.0), (1 + 0.02 * torch.randn(d)).to(BF), (0.02 * torch.randn(d)).to(BF)
+    for cast, nm in ((0, "hf5"), (1, "hf431")):
+        assert_bf16_close(ctx.rmsnorm(x.cuda(), w.cuda(), 1e-5, cast).cpu(), rms_norm(x, w, 1e-5, nm), f"rms {nm}", max_frac=0.005)
+    assert_bf16_close(ctx.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5).cpu(), F.layer_norm(x, (d,), w, b, 1e-5), "ln", max_frac=0.005)
+
+
+def test_embed_splice(ctx, golden):
+    from oracle.procyon_ref import prepare_input_embeddings
+    g = golden("g4_pad_splice")
+    table = rnd(40, 64, seed=1)
+    ids = g["ids"]
+    soft = rnd(3, 64, seed=2)
+    ref, _ = prepare_input_embeddings(table, ids, 31, soft)
+    m = (ids == 31).view(-1)
+    soft_map = torch.full((ids.numel(),), -1, dtype=torch.int32)
+    soft_map[m] = torch.arange(int(m.sum()), dtype=torch.int32)
+    out = ctx.embed_splice(table.cuda(), ids.to(torch.int32).view(-1).cuda(), soft.cuda(), soft_map.cuda()).cpu()
+    assert torch.equal(out.view(3, 10, 64), ref)
+
+
+def test_pool_matches_reference_pooler(ctx, golden):
+    """ProteinPooler golden (the reference's own class): mean / corrected / max incl. multi-chunk proteins."""
+    g = golden("g2_pool")
+    z, keys, pad = g["z_bf16"], g["keys"], g["pad"]
+    Bp, S, D = z.shape
+    lens = (~pad).sum(1)
+    cu = torch.zeros(Bp + 1, dtype=torch.int64)
+    cu[1:] = lens.cumsum(0)
+    packed = z[~pad]
+    seg, rng = [0], []
+    for i in range(int(keys.max()) + 1):
+        for r in (keys == i).nonzero(as_tuple=True)[0].tolist():
+            rng += [int(cu[r]), int(lens[r])]
+        seg.append(len(rng) // 2)
+    for mode, key in ((0, "mean_0"), (1, "mean_1"), (2, "max_0")):
+        out = ctx.pool(packed.cuda().contiguous(), torch.tensor(seg, dtype=torch.int32).cuda(),
+                       torch.tensor(rng, dtype=torch.int32).cuda(), 3, mode).cpu()
+        assert_bf16_close(out, g[f"out_bf16_{key}"], f"pool {key}", max_frac=0.05)
+
+
+def test_mlp(ctx):
+    from oracle.procyon_ref import mlp_forward
+    from procyon_amd import synth
+    from procyon_amd.engine import MlpEngine
+    for nl, M in ((3, 2), (3, 40), (1, 5)):
+        layers = synth.mlp_layers(nl, 1280, 4096, 2560, seed_off=10)
+        x = rnd(M, 1280, seed=7)
+        eng = MlpEngine([(w.cuda(), None if b is None else b.cuda()) for w, b in layers])
+        assert_bf16_close(eng(x.cuda()).cpu(), mlp_forward(x, layers), f"mlp{nl} M{M}")
