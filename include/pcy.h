@@ -58,6 +58,17 @@ int pcy_layernorm(pcy_ctx*, const void* x, const void* w, const void* b, void* y
 /* out[r] = soft_map[r] >= 0 ? soft[soft_map[r]] : table[ids[r]]   (model_unified.py:1146-1167) */
 int pcy_embed_splice(pcy_ctx*, const void* table, const int32_t* ids, const void* soft, const int32_t* soft_map,
                      void* out, int rows, int d);
+/* In-place rotary on heads [0,nh) at column col0 of a token-major buffer [ntok, ld]; pos[tok] = position.
+ * mode 0: (x*cos)+(rotate_half(x)*sin) with every op rounded to bf16 (HF Llama); mode 1: fp32, rounded once
+ * (HF Esm).  prescale != 0 multiplies (and rounds) first: ESM's q * head_dim^-0.5. */
+int pcy_rope(pcy_ctx*, void* buf, int ld, int col0, int nh, int dh, const int32_t* pos, const void* cos_t,
+             const void* sin_t, int ntok, int mode, float prescale);
+/* Exact-rounding eager attention over packed sequences (cu/vt_cu as in pcy_esm_encode): q,k,v token-major with
+ * head h at column col0 + h*dh; O = bf16( bf16(softmax_fp32( bf16(bf16(QK^T)*scale) + mask )) . V ).
+ * keep: per-token key mask (attention_mask) or NULL; causal != 0 adds the causal mask; GQA when Hkv < H. */
+int pcy_attention(pcy_ctx*, const void* q, int ldq, int qcol0, const void* k, int ldk, int kcol0, const void* v, int ldv,
+                  int vcol0, void* o, int ldo, const int32_t* cu, const int32_t* vt_cu, const uint8_t* keep, int nseq,
+                  int max_len, int vt_total, int H, int Hkv, int dh, int causal, float scale);
 /* pooled[i] over the token ranges rng[2*r],rng[2*r+1] = (start,len), r in [seg[i], seg[i+1])  (esm.py:131-173) */
 int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out);
 

@@ -33,6 +33,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct pcy_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t cap_stream = nullptr;  // capture needs a non-legacy stream; replays go to `stream`
   char* ws = nullptr;
   size_t ws_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -190,6 +191,7 @@ int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out) {
   c->stream = reinterpret_cast<hipStream_t>(stream);
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
   *out = c;
   return 0;
 }
@@ -200,6 +202,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->cap_stream) hipStreamDestroy(c->cap_stream);
   delete c;
 }
 int pcy_ctx_sync(pcy_ctx* c) { HIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
@@ -255,6 +258,29 @@ int pcy_pool(pcy_ctx* c, const void* hidden, int d, const int32_t* seg, const in
   if (mode < 0 || mode > 2) return fail(1, "pcy_pool: mode %d", mode);
   pcy_launch_pool(c->stream, (const bf16_t*)hidden, d, seg, rng, nprot, mode, (bf16_t*)out);
   return check_launch("pcy_pool");
+}
+
+int pcy_rope(pcy_ctx* c, void* buf, int ld, int col0, int nh, int dh, const int32_t* pos, const void* cos_t, const void* sin_t,
+             int ntok, int mode, float prescale) {
+  if (dh % 2) return fail(1, "pcy_rope: odd head_dim");
+  pcy_launch_rope(c->stream, (bf16_t*)buf, ld, col0, nh, dh, pos, (const bf16_t*)cos_t, (const bf16_t*)sin_t, ntok, mode, prescale);
+  return check_launch("pcy_rope");
+}
+
+int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, int ldk, int kcol0, const void* v, int ldv,
+                  int vcol0, void* o, int ldo, const int32_t* cu, const int32_t* vt_cu, const uint8_t* keep, int nseq,
+                  int max_len, int vt_total, int H, int Hkv, int dh, int causal, float scale) {
+  if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_attention: head_dim %d unsupported (32/64/128)", dh);
+  if ((Hkv * dh) % 64 || H % Hkv) return fail(1, "pcy_attention: Hkv*dh must be a multiple of 64 and Hkv | H");
+  if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + 4096)) return r;
+  bf16_t* vt = reinterpret_cast<bf16_t*>(c->ws);
+  pcy_launch_transpose_v(c->stream, (const bf16_t*)v, ldv, vcol0, Hkv, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
+  PcyAttnArgs t{};
+  t.q = (const bf16_t*)q; t.ldq = ldq; t.qcol0 = qcol0; t.k = (const bf16_t*)k; t.ldk = ldk; t.kcol0 = kcol0; t.vt = vt;
+  t.vt_total = vt_total; t.o = (bf16_t*)o; t.ldo = ldo; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = nseq; t.max_len = max_len;
+  t.H = H; t.Hkv = Hkv; t.dh = dh; t.causal = causal; t.scale = scale;
+  pcy_launch_attn(c->stream, t);
+  return check_launch("pcy_attention");
 }
 
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
@@ -410,10 +436,16 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != B) {
     c->drop_graph();
     hipGraph_t g = nullptr;
-    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_decode(c, m, kv, st, B);
-    enqueue_pick(c, m, st, B, 1);
-    HIP_TRY(hipStreamEndCapture(c->stream, &g));
+    hipStream_t user = c->stream;
+    c->stream = c->cap_stream;
+    hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e0 == hipSuccess) {
+      enqueue_decode(c, m, kv, st, B);
+      enqueue_pick(c, m, st, B, 1);
+      e0 = hipStreamEndCapture(c->cap_stream, &g);
+    }
+    c->stream = user;
+    if (e0 != hipSuccess) return fail(2, "decode-step graph capture failed: %s", hipGetErrorString(e0));
     HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
     hipGraphDestroy(g);
     memcpy(c->graph_key, key, sizeof(key));

@@ -103,6 +103,28 @@ class Context:
         L.check(self.lib.pcy_embed_splice(self.h, _p(table), _p(ids), _p(soft), _p(soft_map), _p(out), rows, d), "embed_splice")
         return out
 
+    def rope_(self, buf, col0, nh, dh, pos, cos_t, sin_t, mode=0, prescale=0.0):
+        """in place on a token-major [ntok, ld] buffer"""
+        _chk_bf16(buf, cos_t, sin_t)
+        L.check(self.lib.pcy_rope(self.h, _p(buf), buf.shape[1], col0, nh, dh, _p(pos), _p(cos_t), _p(sin_t), buf.shape[0],
+                                  mode, prescale), "pcy_rope")
+        return buf
+
+    def attention(self, q, k, v, lens, H, Hkv, dh, causal, scale, keep=None):
+        """q [ntok,H*dh], k,v [ntok,Hkv*dh] packed sequences of lengths `lens` (list)."""
+        _chk_bf16(q, k, v)
+        lens_t = torch.tensor(lens, dtype=torch.int64)
+        cu = torch.zeros(len(lens) + 1, dtype=torch.int64)
+        cu[1:] = lens_t.cumsum(0)
+        vt_cu = torch.zeros(len(lens) + 1, dtype=torch.int64)
+        vt_cu[1:] = ((lens_t + 31) // 32 * 32).cumsum(0)
+        cu_d, vt_d = cu.to(q.device, torch.int32), vt_cu.to(q.device, torch.int32)
+        o = torch.empty(q.shape[0], H * dh, dtype=BF16, device=q.device)
+        L.check(self.lib.pcy_attention(self.h, _p(q), q.shape[1], 0, _p(k), k.shape[1], 0, _p(v), v.shape[1], 0, _p(o), H * dh,
+                                       _p(cu_d), _p(vt_d), _p(keep), len(lens), int(lens_t.max()), int(vt_cu[-1]), H, Hkv, dh,
+                                       int(causal), scale), "pcy_attention")
+        return o
+
     def pool(self, hidden, seg, rng, nprot, mode):
         _chk_bf16(hidden)
         d = hidden.shape[-1]

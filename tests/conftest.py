@@ -28,17 +28,23 @@ def load_golden(name):
     return out
 
 
-def assert_bf16_close(a, b, what="", max_frac=0.02, ulps=2):
-    """bf16 tensors produced by two fp32-accumulating implementations: identical except for
-    rare 1-ulp rounding flips where the fp32 sums straddle a bf16 rounding boundary."""
+def assert_bf16_close(a, b, what="", max_frac=0.02, ulps=1, inter=None):
+    """bf16 tensors produced by two fp32-accumulating implementations: identical except for rare
+    1-ulp rounding flips where the fp32 sums straddle a bf16 rounding boundary.  Near-zero outputs
+    (cancellation, GELU/SiLU tails) carry an absolute fp32-accumulation error instead, bounded here by
+    1e-4 x rms(reference)."""
     assert a.shape == b.shape, (what, a.shape, b.shape)
     if torch.equal(a, b):
         return
     af, bf = a.float(), b.float()
     diff = (af - bf).abs()
-    tol = ulps * 2.0 ** -8 * torch.maximum(af.abs(), bf.abs()) + 1e-30
+    tol = ulps * 2.0 ** -7 * torch.maximum(af.abs(), bf.abs()) + 1e-4 * bf.pow(2).mean().sqrt()
+    if inter is not None:  # a bf16 intermediate (e.g. the Linear output before a residual add) may flip by its own ulp
+        tol = tol + 2.0 ** -7 * inter.float().abs()
     frac = (diff > 0).float().mean().item()
-    assert bool((diff <= tol).all()), f"{what}: max diff {diff.max().item()} beyond {ulps} bf16 ulp"
+    bad = diff > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())} elements beyond {ulps} bf16 ulp (+abs term); "
+                                 f"worst {diff[bad].max().item():.3e} at |v|={bf[bad][diff[bad].argmax()].abs().item():.3e}")
     assert frac <= max_frac, f"{what}: {frac:.4f} of elements differ"
 
 
@@ -56,3 +62,35 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+class alt_accumulation:
+    """Context manager: run the oracle with a DIFFERENT fp32 accumulation order for every Linear
+    (float matmul kernel instead of the bf16 one; same math, same single rounding).  The distance
+    between the oracle and this twin is the reproducibility floor of the reference's own bf16
+    pipeline: two exact-class CPU implementations already differ by ~1.7e-3 (norm-wise) after ONE
+    ESM2-650M layer because every 1-ulp flip is re-amplified by the next bf16 materialisation
+    (DESIGN.md "Noise floor").  GPU-vs-oracle bars for multi-layer stacks are stated relative to it."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig = F, F.linear
+
+        def alt(x, w, b=None):
+            y = x.float() @ w.float().T
+            if b is not None:
+                y = y + b.float()
+            return y.to(x.dtype)
+        F.linear = alt
+        return self
+
+    def __exit__(self, *a):
+        self.F.linear = self.orig
+
+
+def parity_bar(floor, base=5e-3, k=2.0):
+    """Bar for MULTI-LAYER bf16 stacks: k x the measured CPU-vs-CPU floor, but never below 5e-3 -- on tiny models
+    a single twin run is chaotic (it lands on exactly 0 or on ~4e-3 depending on whether any 1-ulp flip occurred),
+    and stacks of a few layers sit at 2-6e-3 between exact-class CPU implementations.  Single ops use the strict
+    elementwise bar instead (assert_bf16_close)."""
+    return max(base, k * floor)
