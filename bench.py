@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- ProCyon-Full phenotype generation on MI355X (BASELINE.json configs[1]).
+
+Workload (one "step" = one whole job): ESM2-650M encodes one 1024-residue protein (S=1026) -> mean pool ->
+3-layer token projector -> soft-token splice into a 512-token prompt (2 <|protein|> slots + [ANSWER]) ->
+Llama-3-8B prefill -> 256 greedy tokens with KV-cached decode (no EOS stop), bf16, batch 1, through the
+`UnifiedProCyon.generate(method="greedy")` mirror.  Synthetic random-init weights of the real architecture,
+inputs resident in HBM.  value = generated tokens / wall time of the timed steps (end to end: encoder + prefill
++ decode), whole job over all ranks; N > 1 runs N independent replicas (generation rows are independent,
+SURVEY.md section 8e: "replicas only") plus a DP-sharded retrieval leg with ONE RCCL all-gather.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the decode gate/up SwiGLU GEMV, algorithmic bytes /
+HIP-event time measured live), `cpu_baseline` (the oracle on this box's host cores, bounded sample), `phases`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--residues", type=int, default=1024)
+    ap.add_argument("--prompt", type=int, default=512)
+    ap.add_argument("--geometry", default="full")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--retrieval-proteins", type=int, default=64, help="proteins per rank in the retrieval leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(tokens, residues, prompt):
+    """Oracle (oracle/, kind "port") on the host cores: 2 of 33 ESM2-650M layers at S=residues+2, 2 of 32 Llama-3-8B
+    layers for prefill (T=prompt) and 4 cached decode steps + the lm_head, scaled to the full depth."""
+    from oracle import esm_ref as ER
+    from oracle import llama_ref as LR
+    from procyon_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    cores = torch.get_num_threads()
+    ek = dict(d=1280, n_layers=2, n_heads=20, ffn=5120)
+    esd = synth.esm_state_dict(**ek)
+    toks = synth.protein_tokens([residues], seed=0)
+    t0 = time.perf_counter()
+    ER.esm_forward(esd, ER.EsmGeom(**ek), toks)
+    t_esm = (time.perf_counter() - t0) * 33 / 2
+    lk = dict(vocab=128263, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
+    lsd = synth.llama_state_dict(**lk)
+    geom = LR.LlamaGeom(**lk)
+    emb = (torch.randn(1, prompt, 4096) * 0.02).bfloat16()
+    t0 = time.perf_counter()
+    r = LR.llama_forward(lsd, geom, inputs_embeds=emb, attn_mask=torch.ones(1, prompt), logits_rows="last")
+    t_pre_layers = time.perf_counter() - t0
+    past, tok = r["past_kv"], r["logits"][:, -1].argmax(-1, keepdim=True)
+    t0 = time.perf_counter()
+    nd = 4
+    for _ in range(nd):
+        r = LR.llama_forward(lsd, geom, input_ids=tok, attn_mask=None, past_kv=past, logits_rows="last")
+        past, tok = r["past_kv"], r["logits"][:, -1].argmax(-1, keepdim=True)
+    t_dec = (time.perf_counter() - t0) / nd
+    # lm_head cost appears once per call in both timings; layers scale x16
+    h = torch.randn(1, 1, 4096).bfloat16()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch.nn.functional.linear(h, lsd["lm_head.weight"])
+    t_head = (time.perf_counter() - t0) / 3
+    t_prefill = (t_pre_layers - t_head) * 16 + t_head
+    t_step = (t_dec - t_head) * 16 + t_head
+    total = t_esm + t_prefill + (tokens - 1) * t_step
+    return {"value": round(tokens / total, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU bf16): 2/33 ESM2-650M layers S={residues + 2}, 2/32 Llama-3-8B layers prefill T={prompt} "
+                      f"+ {nd} decode steps + lm_head, scaled to full depth; esm {t_esm:.2f}s prefill {t_prefill:.2f}s "
+                      f"decode {t_step * 1e3:.0f} ms/token"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group(backend="nccl", device_id=dev)
+
+    from procyon_amd import synth
+    from procyon_amd import synthetic_model as SM
+    from procyon_amd.engine import Context
+
+    model = SM.build(a.geometry, device=dev, max_new_tokens=a.tokens)
+    ctx = Context.get(dev)
+    eng = model.text_encoder.engine
+    cfg = eng.cfg
+    prot = synth.protein_tokens([a.residues], seed=0)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    phases = {}
+
+    def one_step(record=False):
+        inputs = SM.caption_inputs(model, prot, n_prompt_words=a.prompt - 2, n_slots=2, seed=0)
+        if record:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            emb, ids, mask, *_ = model._preprocessing(inputs, crop_off=True, no_pad=True, left_pad=True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            assert emb.shape[1] == a.prompt, emb.shape
+            cache = eng.new_cache(1, a.prompt + a.tokens)
+            logits, _ = eng.prefill(emb, mask, cache, "last")
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            phases.update(encode_project_splice_ms=(t1 - t0) * 1e3, prefill_ms=(t2 - t1) * 1e3)
+        toks, lp, logits, text = model.generate(inputs, max_len=a.tokens, method="greedy")
+        assert toks.shape == (1, 1, a.tokens)
+        return toks
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        toks = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t)
+    value = world * a.tokens * a.steps / dt
+
+    # ---- phases + decode-only rate (outside the timed region) --------------------------------------
+    one_step(record=True)
+    inputs = SM.caption_inputs(model, prot, n_prompt_words=a.prompt - 2, n_slots=2, seed=0)
+    emb, ids, mask, *_ = model._preprocessing(inputs, crop_off=True, no_pad=True, left_pad=True)
+    from procyon_amd.engine import GenState
+    cache = eng.new_cache(1, a.prompt + a.tokens)
+    st = GenState(1, cfg.vocab, a.tokens, dev)
+    logits, _ = eng.prefill(emb, mask, cache, "last")
+    st.logits.copy_(logits); st.pos.fill_(a.prompt)
+    eng.pick(st, 1, advance_pos=False)
+    eng.greedy_steps(cache, st, 1, 8)          # warm the graph
+    ctx.timer_start()
+    nsteps = a.tokens - 16
+    eng.greedy_steps(cache, st, 1, nsteps)
+    dec_ms = ctx.timer_stop() / nsteps
+    step_bytes = 2 * (cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d
+                                      + 3 * cfg.d * cfg.ffn + 2 * cfg.d) + cfg.d + cfg.vocab * cfg.d)
+    kv_bytes = 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2 * (a.prompt + a.tokens // 2)
+    phases.update(decode_ms_per_token=dec_ms, decode_tokens_per_s=1e3 / dec_ms,
+                  decode_step_algorithmic_GB=(step_bytes + kv_bytes) / 1e9,
+                  decode_step_GBps=(step_bytes + kv_bytes) / 1e9 / (dec_ms / 1e3))
+
+    # ---- roofline of the dominant kernel: gate/up SwiGLU GEMV, one launch per layer per token -------
+    x = torch.randn(1, cfg.d, device=dev).bfloat16()
+    outb = torch.empty(1, cfg.ffn, device=dev, dtype=torch.bfloat16)
+    wl = [k[2] for k in eng._keep]   # packed gate/up weights of every layer (7.5 GB: defeats the 256 MiB L3)
+    ln = [k[5] for k in eng._keep]
+    for i in range(len(wl)):
+        ctx.gemv(wl[i], x, epi=4, rms_w=ln[i], out=outb)
+    reps = 4
+    ctx.timer_start()
+    for _ in range(reps):
+        for i in range(len(wl)):
+            ctx.gemv(wl[i], x, epi=4, rms_w=ln[i], out=outb)
+    k_ms = ctx.timer_stop() / (reps * len(wl))
+    k_bytes = 2 * cfg.ffn * cfg.d * 2
+    roofline = {"bound": "hbm", "kernel": "gemv_kernel<1,EPI_SWIGLU,RMS> (Llama gate/up, 32 launches/token)",
+                "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": None,
+                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
+
+    # ---- retrieval leg (config 3 shape): DP-sharded forward_sequences + ONE all-gather --------------
+    from procyon_amd.distributed import embed_sharded
+    nprot = a.retrieval_proteins * world
+    plen = a.residues if a.geometry == "full" else 100
+    barrier(); t0 = time.perf_counter()
+    allz = embed_sharded(model, lambda idx: synth.protein_tokens([plen] * len(idx), seed=1000 + (idx[0] if len(idx) else 0)),
+                         nprot, batch_size=16)
+    barrier(); rt = time.perf_counter() - t0
+    assert allz.shape[0] == nprot
+    retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": 16}
+
+    if rank == 0:
+        out = {"metric": "phenotype-gen tokens/sec (ProCyon-Full greedy generation, end to end)", "value": round(value, 2),
+               "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"configs[1]: ProCyon-Full (ESM2-650M + Llama-3-8B geometry={a.geometry}) bf16 batch=1, "
+                                      f"{a.residues}-residue protein, {a.prompt}-token prompt, {a.tokens}-token greedy generation",
+                          "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+               "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
+        if not a.no_cpu_baseline and a.geometry == "full":
+            out["cpu_baseline"] = cpu_baseline(a.tokens, a.residues, a.prompt)
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

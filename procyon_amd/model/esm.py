@@ -1,0 +1,53 @@
+"""Mirror of `ESM_PLM` (/root/reference/procyon/model/esm.py:318-558) over the HIP ESM2 engine."""
+from __future__ import annotations
+
+import torch
+
+from ..engine import EsmConfig, EsmEngine
+
+# layer counts / widths from esm.py:378-421; heads / FFN from the public ESM2 cards
+ESM2_GEOMETRY = {
+    "8m": dict(d=320, n_layers=6, n_heads=20, ffn=1280),
+    "35m": dict(d=480, n_layers=12, n_heads=20, ffn=1920),
+    "150m": dict(d=640, n_layers=30, n_heads=20, ffn=2560),
+    "650m": dict(d=1280, n_layers=33, n_heads=20, ffn=5120),
+    "3b": dict(d=2560, n_layers=36, n_heads=40, ffn=10240),
+    "15b": dict(d=5120, n_layers=48, n_heads=40, ffn=20480),
+}
+
+
+class ESM_PLM:
+    """forward(tokens, aggregate=True) -> (z [B,D], logits=None).
+
+    pooling_method / protein_pooling_correction_option / long_protein_strategy / max_protein_len keep the
+    reference's meaning (esm.py:318-376, training_args_IT.py:65-103).  `official=True` reproduces the
+    HF-"official" call that passes no attention mask (esm.py:533, quirk Q12).  The masked-LM logits the
+    reference also returns are never consumed on the inference path (model_unified.py:1060) and are not
+    computed: `logits` is None.  aggregate=False (per-residue states, MLM path) is out of scope."""
+
+    def __init__(self, state_dict, cfg: EsmConfig, pooling_method="max", protein_pooling_correction_option=False,
+                 long_protein_strategy="split", max_protein_len=1024, official=False, device=None):
+        if long_protein_strategy != "split":
+            raise NotImplementedError("only long_protein_strategy='split' is on the hot path (llama3-full.yml)")
+        self.engine = EsmEngine(state_dict, cfg, device)
+        self.embedding_size = cfg.d
+        self.repr_layer = cfg.n_layers
+        self.pooling_method = pooling_method.lower()
+        if self.pooling_method not in ("mean", "max"):
+            raise NotImplementedError(f"Protein pooling method {pooling_method} is not implemented")
+        self.correction = protein_pooling_correction_option
+        self.max_protein_len = max_protein_len
+        self.official = official
+        self.padding_idx, self.eos_idx = 1, 2
+
+    def eval(self):
+        return self
+
+    def forward(self, tokens, aggregate=True):
+        if not aggregate:
+            raise NotImplementedError("aggregate=False (MLM / per-residue) is outside the north-star path")
+        z = self.engine.forward(tokens, pooling=self.pooling_method, correction=self.correction,
+                                mask_pads=not self.official, max_protein_len=self.max_protein_len)
+        return z, None
+
+    __call__ = forward

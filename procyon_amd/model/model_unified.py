@@ -1,0 +1,482 @@
+"""Mirror of `UnifiedProCyon`'s inference API (/root/reference/procyon/model/model_unified.py) over the
+MI355X engine: `forward` (QA / retrieval), `generate` (greedy / sampling / nucleus / diverse beam),
+`forward_sequences`, plus the host-side text preparation that sits between them and the kernels.
+
+Same method names, argument meaning, in-place side effects and exceptions as the reference, so the callers in
+SURVEY.md section 8b (scripts/, evaluate/framework/procyon.py, inference/) can switch by import path
+(INTEGRATION.md).  Training-only branches (contrastive loss, MLM, LoRA groups, freezing) are out of scope.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from itertools import chain
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from ..engine import BF16, MlpEngine
+from .model_utils import left_pad_tensors
+
+
+@dataclass
+class ProCyonConfig:
+    """The `ModelArgs` fields that shape the inference path (training_args_IT.py:27-651; shipped values
+    configs/llama3-full.yml:29-68)."""
+    text_encoder_fname: str = "llama-3-8b"
+    use_aaseq_embeddings: bool = False
+    protein_pooling_opt: str = "mean"
+    protein_pooling_correction_option: bool = False
+    long_protein_strategy: str = "split"
+    max_protein_len: int = 1024
+    max_text_len: int = 2048
+    ret_token_access: str = "last"
+    roll_num: int = 0
+    use_protein_struct: bool = False
+    protein_struct_dropout: float = 0.0
+    use_drug_embeddings: bool = False
+    protein_task_spc_lora: bool = False
+    lora_specific_style: str = "none"
+
+
+def mask_before(full_labels, answer_idx, before_last_answer=False):
+    """`mask_before` (model_unified.py:39-60)."""
+    answer_found = (full_labels == answer_idx).nonzero()
+    if not before_last_answer:
+        if torch.any((full_labels == answer_idx).sum(dim=1) > 1):
+            raise ValueError('More than one {} token detected in an input'.format(answer_idx))
+        found_map = answer_found
+    else:
+        found_map = torch.tensor([(i, int(answer_found[answer_found[:, 0] == i, 1].max()))
+                                  for i in range(full_labels.shape[0])], device=full_labels.device)
+    ar = torch.arange(full_labels.shape[1], device=full_labels.device).unsqueeze(0).repeat(full_labels.shape[0], 1)
+    ind = found_map[:, 1].unsqueeze(1).repeat(1, full_labels.shape[1])
+    return ind >= ar
+
+
+def multi_replace_tokens(a, b, replace_token, eval=False):
+    """`multi_replace_tokens` (model_unified.py:83-108): splice the token lists `b` over the occurrences of
+    `replace_token` in `a` ([EXT] slots); eval=True leaves the last slot empty."""
+    occ = [i for i, t in enumerate(a) if t == replace_token]
+    if len(occ) != len(b):
+        raise ValueError("Number of occurrences of replace_token does not match the length of b")
+    if len(occ) == 0:
+        return a
+    result = a[:occ[0]]
+    for i, o in enumerate(occ):
+        if not (i == len(occ) - 1 and eval):
+            result += b[i]
+        result += a[o + 1:] if i == len(occ) - 1 else a[o + 1:occ[i + 1]]
+    return result
+
+
+class UnifiedProCyon:
+    def __init__(self, config: ProCyonConfig, text_encoder, tokenizer, protein_seq_encoder=None, token_projectors=None,
+                 aaseq_shared_projector: Optional[MlpEngine] = None, aaseq_lm_projector: Optional[MlpEngine] = None,
+                 protein_seq_embeddings=None, domain_embeddings=None, peptide_embeddings=None,
+                 protein_struct_embeddings=None, drug_structure_embeddings=None):
+        self.config = config
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        self.protein_seq_encoder = protein_seq_encoder
+        self.token_projectors = token_projectors or {}
+        self.aaseq_shared_projector = aaseq_shared_projector
+        self.aaseq_lm_projector = aaseq_lm_projector
+        self.protein_seq_embeddings = protein_seq_embeddings
+        self.domain_embeddings = domain_embeddings
+        self.peptide_embeddings = peptide_embeddings
+        self.protein_struct_embeddings = protein_struct_embeddings
+        self.drug_structure_embeddings = drug_structure_embeddings
+        self.input_embeddings = SimpleNamespace(weight=text_encoder.get_input_embeddings())
+        self.device = text_encoder.engine.device
+        self.training = False
+        self.use_llama_tokenizer = True
+        self.train_qa_full_lm = False
+        self.struct_dropout_prob = config.protein_struct_dropout
+        # special tokens, registered in the order of `_init_tokenizer` (model_unified.py:1100-1133)
+        t = tokenizer
+        self.prot_replacement_idx = t.convert_tokens_to_ids("<|protein|>")
+        self.prot_retrieval_idx = t.convert_tokens_to_ids("[PROT]")
+        self.answer_idx = t.convert_tokens_to_ids("[ANSWER]")
+        self.struct_idx = t.convert_tokens_to_ids("<|struct|>")
+        self.drug_idx = t.convert_tokens_to_ids("<|drug|>")
+        self.ext_idx = t.convert_tokens_to_ids("[EXT]")
+        if "llama-3" in config.text_encoder_fname.lower():  # model_unified.py:342-347
+            self.yes_token = t.encode(" yes", add_special_tokens=False)[0]
+            self.no_token = t.encode(" no", add_special_tokens=False)[0]
+        else:
+            self.yes_token = t.encode("yes", add_special_tokens=False)[0]
+            self.no_token = t.encode("no", add_special_tokens=False)[0]
+
+    # nn.Module protocol used by the callers (retrieval_utils.py:90-101, procyon.py:64-67)
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def bfloat16(self):
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    # ------------------------------------------------------------------------------------------
+    def _embed_table(self, aaseq_type):
+        tab = {"protein": self.protein_seq_embeddings, "domain": self.domain_embeddings,
+               "peptide": self.peptide_embeddings}[aaseq_type]
+        if tab is None:
+            raise ValueError(f"no embedding table for aaseq_type={aaseq_type}")
+        return tab
+
+    def _encode_aaseq(self, seq, aaseq_type):
+        if self.config.use_aaseq_embeddings:
+            return self._embed_table(aaseq_type)[seq.to(self.device).long()]
+        z, _ = self.protein_seq_encoder(seq, aggregate=True)
+        return z
+
+    def _preprocessing(self, inputs, aaseq_type='protein', exclude_protein_structure=False, crop_off=False,
+                       no_pad=False, retrieval=False, left_pad=False):
+        """`_preprocessing` (model_unified.py:352-481)."""
+        aaseq_token_embeddings = aaseq_ret_embeddings = None
+        if inputs["data"]["seq"] is not None:
+            aaseq_token_embeddings = aaseq_ret_embeddings = self._encode_aaseq(inputs["data"]["seq"], aaseq_type)
+        if inputs["input"]["seq"] is not None:
+            full_index = list(chain.from_iterable(inputs["input"]["seq"]))
+            pz_inputs = aaseq_token_embeddings[torch.tensor(full_index, dtype=torch.long, device=self.device)]
+            protein_soft_tokens = self.token_projectors['aaseq'](pz_inputs)
+        else:
+            protein_soft_tokens = None
+        if self.config.use_drug_embeddings and (inputs["data"]["drug"] is not None):
+            full_index = list(chain.from_iterable(inputs["input"]["drug"]))
+            drug_z = self.drug_structure_embeddings[inputs["data"]["drug"].to(self.device).long()][full_index]
+            drug_soft_tokens = self.token_projectors["drug"](drug_z)
+        else:
+            drug_soft_tokens = None
+        text_inputs = [[inputs["data"]["text"][i] for i in inp_list] for inp_list in inputs["input"]["text"]]
+        instruction_list = inputs['instructions']
+        protein_struct_tokens = []
+        if (not exclude_protein_structure) and self.config.use_protein_struct and inputs["input"]["seq"]:
+            # mutates inputs["instructions"] in place and draws from the global torch RNG, as the reference
+            # does (model_unified.py:422,433-437; quirk Q6)
+            include_mask = torch.bernoulli(torch.full((len(instruction_list),), 1 - self.struct_dropout_prob))
+            all_row_indices = []
+            for i in include_mask.nonzero(as_tuple=True)[0].tolist():
+                instruction_list[i] = instruction_list[i].replace("<|protein|>", "<|protein|> <|struct|>")
+                all_row_indices.append(torch.cat([inputs["data"]["seq_idx"][j].unsqueeze(0) for j in inputs["input"]["seq"][i]]))
+            all_row_indices = torch.stack(all_row_indices, dim=0)
+            ari_unique, ari_inverse = all_row_indices.unique(return_inverse=True)
+            if aaseq_type == "protein":
+                struct_z = self.protein_struct_embeddings[ari_unique.to(self.device).long()]
+            else:
+                struct_z = torch.zeros(ari_unique.shape[0], self.protein_struct_embeddings.shape[1], dtype=BF16, device=self.device)
+            token_z_expand = self.token_projectors["prot_structure"](struct_z)[ari_inverse.to(self.device)]
+            for i, val in enumerate(include_mask):
+                protein_struct_tokens.append(token_z_expand[i, ...] if val else [])
+        input_ids, attn_masks = self._prepare_text_inputs_and_tokenize(
+            instruction_list, text_inputs, crop_off=crop_off, retrieval=retrieval, no_pad=no_pad, left_pad=left_pad)
+        input_embeds, ret_output_indices = self._prepare_input_embeddings(
+            input_ids, protein_soft_tokens=protein_soft_tokens, protein_struct_tokens=protein_struct_tokens,
+            drug_soft_tokens=drug_soft_tokens)
+        return input_embeds, input_ids, attn_masks, ret_output_indices, aaseq_token_embeddings, aaseq_ret_embeddings
+
+    def _prepare_text_inputs_and_tokenize(self, instructions: List[str], text_input_list: List[List[str]], crop_off=False,
+                                          retrieval=False, no_pad=False, left_pad=False):
+        """`_prepare_text_inputs_and_tokenize` (model_unified.py:1177-1293), eval path (no crop sampling)."""
+        tk = self.tokenizer
+        assert all([t[-1] != tk.sep_token for t in instructions])
+        instruction_tokens = tk(instructions, padding=False, truncation=True, add_special_tokens=True,
+                                max_length=self.config.max_text_len)['input_ids']
+        max_len = max(len(l) for l in instruction_tokens)
+        joint_tokens, attention_masks = [], []
+        for i, text_input in enumerate(text_input_list):
+            n_txt = len(text_input)
+            if n_txt != 0:
+                for j in range(n_txt):
+                    if not isinstance(text_input[j], str):
+                        text_input[j] = "null"
+                toks = tk(text_input, padding=False, truncation=False, add_special_tokens=False)['input_ids']
+                max_len_for_sample = (self.config.max_text_len - max_len) // n_txt
+                for j in range(len(toks)):
+                    drug_add = None
+                    if self.drug_idx in toks[j]:
+                        where_drug = toks[j].index(self.drug_idx) - 3
+                        drug_add = toks[j][(where_drug - 3):]
+                        toks[j] = toks[j][:(where_drug - 3)]
+                    end_i = max_len_for_sample - (len(drug_add) if drug_add is not None else 0)
+                    toks[j] = toks[j][0:end_i]
+                    if drug_add is not None:
+                        toks[j] = toks[j] + drug_add
+            else:
+                toks = []
+            Lt = multi_replace_tokens(list(instruction_tokens[i]), toks, self.ext_idx, eval=False)
+            if no_pad:
+                Lt = torch.tensor(Lt)
+            else:
+                Lt = torch.tensor(Lt + [tk.eos_token_id] + [tk.pad_token_id] * max(self.config.max_text_len - len(Lt) - 1, 0))
+            joint_tokens.append(Lt)
+            attention_masks.append((Lt != tk.pad_token_id).int())
+            assert not torch.any(Lt == self.ext_idx), 'ERROR [EXT] found in input'
+        if left_pad:
+            return left_pad_tensors(joint_tokens, pad_value=tk.pad_token_id)
+        return torch.stack(joint_tokens, dim=0), torch.stack(attention_masks, dim=0)
+
+    def _prepare_input_embeddings(self, input_ids, protein_soft_tokens=None, protein_struct_tokens=[], drug_soft_tokens=None):
+        """`_prepare_input_embeddings` (model_unified.py:1135-1175): embedding lookup with the soft tokens written
+        over the <|protein|> / <|struct|> / <|drug|> rows, in row-major order, by ONE gather kernel."""
+        ids = input_ids.long()
+        flat = ids.reshape(-1)
+        soft_map = torch.full((flat.numel(),), -1, dtype=torch.int32)
+        pieces, base = [], 0
+        if protein_soft_tokens is not None:
+            m = flat == self.prot_replacement_idx
+            assert int(m.sum()) == protein_soft_tokens.shape[0]
+            soft_map[m] = torch.arange(int(m.sum()), dtype=torch.int32) + base
+            pieces.append(protein_soft_tokens)
+            base += protein_soft_tokens.shape[0]
+        if len(protein_struct_tokens) > 0:
+            ms = ids == self.struct_idx
+            for i in range(ids.shape[0]):
+                n = int(ms[i].sum())
+                if n > 0:
+                    assert n == protein_struct_tokens[i].shape[0], f"expected: {n} got: {protein_struct_tokens[i].shape[0]}"
+                    row = torch.zeros_like(ids, dtype=torch.bool)
+                    row[i] = ms[i]
+                    soft_map[row.reshape(-1)] = torch.arange(n, dtype=torch.int32) + base
+                    pieces.append(protein_struct_tokens[i])
+                    base += n
+        if drug_soft_tokens is not None:
+            m = flat == self.drug_idx
+            assert int(m.sum()) == drug_soft_tokens.shape[0], f"expected: {int(m.sum())} got: {drug_soft_tokens.shape[0]}"
+            soft_map[m] = torch.arange(int(m.sum()), dtype=torch.int32) + base
+            pieces.append(drug_soft_tokens)
+        soft = torch.cat(pieces, 0).contiguous() if pieces else None
+        z = self.text_encoder.engine.embed_tokens(ids, soft, soft_map if pieces else None)
+        ret = ids == self.prot_retrieval_idx
+        if self.config.roll_num != 0:
+            ret = ret.roll(self.config.roll_num, 1)
+        return z, ret
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, inputs, return_mlm=False, retrieval=False, get_full_labels=False, aaseq_type='protein',
+                exclude_protein_structure=False, crop_off=False, output_attentions=False):
+        """`forward` (model_unified.py:483-581), inference branches.  QA: logits only at the position the QA readers
+        use (last [ANSWER] index, data/inference_utils.py:582-604) -> outputs.logits [B,1,V] and
+        out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D]."""
+        if return_mlm:
+            raise NotImplementedError("return_mlm is a training path (model_unified.py:505-509)")
+        input_embeds, input_ids, attn_masks, ret_idx, tok_emb, ret_emb = self._preprocessing(
+            inputs, aaseq_type=aaseq_type, crop_off=crop_off, retrieval=retrieval, exclude_protein_structure=False)
+        full_labels = None
+        B = input_ids.shape[0]
+        # the reference right-pads every row to max_text_len (Q13); causal rows are unaffected by trailing pads,
+        # so only the columns up to the last real token are run
+        real = int(attn_masks.sum(1).max())
+        emb = input_embeds[:, :real].contiguous()
+        answer_pos = None
+        if not retrieval:
+            pad_id = self.tokenizer.pad_token_id
+            full_labels = input_ids.clone()
+            all_masks = (full_labels == pad_id) | (full_labels == self.prot_replacement_idx) | \
+                (full_labels == self.prot_retrieval_idx) | (full_labels == self.drug_idx) | (full_labels == self.struct_idx)
+            if self.use_llama_tokenizer:
+                all_masks[:, -1] = True
+            if not self.train_qa_full_lm:
+                all_masks |= mask_before(full_labels, self.answer_idx, before_last_answer=True)
+            full_labels = torch.where(all_masks, -100, full_labels)
+            answer_pos = torch.tensor([int((input_ids[i] == self.answer_idx).nonzero()[:, 0].max()) for i in range(B)])
+        outputs = self.text_encoder(input_embeds=emb, attn_masks=attn_masks[:, :real], full_labels=full_labels,
+                                    logit_positions=answer_pos if not retrieval else torch.zeros(B, dtype=torch.long),
+                                    want_hidden=retrieval)
+        out = {'outputs': outputs, 'text_toks': input_ids, 'full_labels': full_labels if get_full_labels else None,
+               'contrastive_out': None, 'contrastive_loss': None, 'answer_positions': answer_pos}
+        if retrieval:
+            if self.config.ret_token_access != 'last':
+                raise NotImplementedError("ret_token_access='all' (sum of all hidden states) is not built; shipped "
+                                          "ProCyon-Full uses 'last' (configs/llama3-full.yml:53)")
+            hidden = outputs.hidden_states[-1]
+            extracted = hidden[ret_idx[:, :real].to(hidden.device)]
+            shared_lm = self.aaseq_lm_projector(extracted)
+            c = {"positive": {}, "negative": {}}
+            if inputs["target"]["text"] is None:
+                c["positive"]["text"] = shared_lm
+            else:
+                c["positive"]["text"] = shared_lm[inputs["target"]["text"]["positive"]]
+                if inputs["target"]["text"]["negative"] is not None:
+                    raise NotImplementedError
+            if inputs["target"]["seq"] is not None:
+                shared_plm = self.aaseq_shared_projector(ret_emb)
+                c["positive"]["sequence"] = shared_plm[inputs["target"]["seq"]["positive"]]
+                if inputs['target']["seq"]["negative"] is not None:
+                    raise NotImplementedError
+            out['contrastive_out'] = c
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_sequences(self, seq_input, get_soft_tokens=False, aaseq_type="protein"):
+        """`forward_sequences` (model_unified.py:1029-1086)."""
+        if isinstance(seq_input, dict):
+            seq_input = seq_input["data"]
+        z = self._encode_aaseq(seq_input, aaseq_type)
+        out = {"original": z, "shared": self.aaseq_shared_projector(z), "token": None}
+        if get_soft_tokens:
+            out["token"] = self.token_projectors['aaseq'](z)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _get_nucleus_mask(self, probs, nucleus_prob):
+        """`_get_nucleus_mask` (model_unified.py:844-858)."""
+        sorted_vals, indices = probs.sort(dim=-1, descending=False)
+        keep_idxs = (sorted_vals.cumsum(dim=-1) >= (1 - nucleus_prob)).nonzero(as_tuple=True)
+        mask = torch.zeros_like(probs)
+        mask[keep_idxs[0], indices[keep_idxs]] = 1
+        return mask
+
+    @torch.no_grad()
+    def _generate_sampling(self, input_embeds, attn_masks, max_len=64, num_text_per_instance=1, temperature=1.0,
+                           greedy=False, nucleus_prob=None):
+        """`_generate_sampling` (model_unified.py:861-921).  Greedy runs entirely on the device (hipGraph-replayed
+        decode steps, fused argmax + log-prob); sampling draws `torch.multinomial` on the host from the same
+        pre-sampling probability vector the reference forms."""
+        assert nucleus_prob is None or (0 < nucleus_prob < 1)
+        eng = self.text_encoder.engine
+        B = len(input_embeds)
+        out_list, lp_list, logit_list = [], [], []
+        for _ in range(num_text_per_instance):
+            if greedy:
+                tok, lp, lg, _ = eng.generate_greedy(input_embeds, attn_masks, max_len, keep_logits=True)
+                out_list.append(tok.cpu())
+                lp_list.append(lp.cpu().clone())
+                logit_list.append(lg.cpu())
+                continue
+            out, past, logits_all = None, None, []
+            total = torch.zeros(B)
+            enc = self.text_encoder
+            keep_new = enc.max_new_tokens
+            enc.max_new_tokens = max(keep_new, max_len)
+            for i in range(max_len):
+                if i == 0:
+                    o = enc(input_embeds=input_embeds, attn_masks=attn_masks, use_cache=True,
+                            logit_positions=torch.full((B,), input_embeds.shape[1] - 1), want_hidden=False)
+                else:
+                    o = enc(input_ids=out[:, -1:], use_cache=True, past_key_values=past)
+                past = o.past_key_values
+                logits = o.logits[:, -1, :].cpu()
+                logits_all.append(logits.clone())
+                log_probs = torch.log_softmax(logits, dim=-1)
+                if nucleus_prob is not None:
+                    probs = logits.softmax(dim=-1)
+                    probs *= self._get_nucleus_mask(probs, nucleus_prob)
+                else:
+                    probs = (logits / temperature).softmax(dim=-1)
+                nxt = torch.multinomial(probs.float(), 1)
+                total += log_probs[torch.arange(B), nxt.squeeze(-1)].float()
+                out = nxt if out is None else torch.cat([out, nxt], dim=-1)
+            enc.max_new_tokens = keep_new
+            out_list.append(out)
+            lp_list.append(total)
+            logit_list.append(torch.stack(logits_all, 1))
+        return torch.stack(out_list, dim=1), torch.stack(lp_list).T, torch.stack(logit_list, dim=1)
+
+    @torch.no_grad()
+    def _generate_beam_search(self, input_embeds, attn_mask, max_len=64, beam_size=5, beam_group_size=5,
+                              diversity_penalty=0.8):
+        """`_generate_beam_search` (model_unified.py:702-842): diverse beam search with the reference's exact
+        bookkeeping (step-0 single-beam top-g, in-place Hamming penalty carried in the score, bf16 log-softmax +
+        fp32 running score, EOS-anywhere stop).  The transformer steps run on the engine; the per-step
+        O(B x groups) bookkeeping runs on the host like the reference's."""
+        B = input_embeds.shape[0]
+        BB = B * beam_size
+        V = self.text_encoder.model.vocab_size
+        if beam_size % beam_group_size != 0:
+            raise ValueError("beam_group_size must evenly divide beam_size, got: "
+                             f"{beam_size} % {beam_group_size} != 0")
+        groups = beam_size // beam_group_size
+        emb_rep = torch.repeat_interleave(input_embeds, repeats=beam_size, dim=0)
+        mask_rep = torch.repeat_interleave(attn_mask, repeats=beam_size, dim=0)
+        cur = torch.zeros((BB,))
+        out = torch.zeros(BB, max_len, dtype=torch.int64)
+        enc = self.text_encoder
+        keep_new = enc.max_new_tokens
+        enc.max_new_tokens = max(keep_new, max_len)
+        past, out_logits = None, None
+        eng = enc.engine
+        for i in range(max_len):
+            if i == 0:
+                o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
+                        logit_positions=torch.full((BB,), emb_rep.shape[1] - 1), want_hidden=False)
+            else:
+                o = enc(input_ids=out[:, i - 1].unsqueeze(-1), use_cache=True, past_key_values=past)
+            past = o.past_key_values
+            logits = o.logits[:, -1, :].cpu()
+            it = logits.clone().unsqueeze(1)
+            out_logits = it if out_logits is None else torch.cat([out_logits, it], dim=1)
+            log_probs = torch.log_softmax(logits, dim=-1) + cur[:, None]
+            src = torch.arange(BB)
+            for b in range(B):
+                bs0 = b * beam_size
+                for k in range(groups):
+                    inc = 1 if i == 0 else beam_group_size
+                    gs = bs0 + k * beam_group_size
+                    ge = gs + beam_group_size
+                    lp = log_probs[gs:gs + inc]
+                    if k != 0:
+                        lp -= diversity_penalty * torch.bincount(out[bs0:gs, i], minlength=V)
+                    top_v, top_i = lp.ravel().topk(beam_group_size)
+                    orig = (top_i // V) + gs
+                    out[gs:ge] = out[orig]
+                    out[torch.arange(gs, ge), i] = top_i % V
+                    cur[gs:ge] = top_v
+                    out_logits[gs:ge] = out_logits[orig]
+                    src[gs:ge] = orig
+            if not torch.equal(src, torch.arange(BB)):
+                eng.kv_reorder(past.cache, src, past.t)  # one gather per layer instead of per-group row copies
+            if torch.all((out == self.tokenizer.eos_token_id).any(dim=1)).item():
+                break
+        enc.max_new_tokens = keep_new
+        return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
+
+    @torch.no_grad()
+    def generate(self, inputs, max_len=64, aaseq_type='protein', method="sampling", temperature=1.0, greedy=False,
+                 num_text_per_instance=1, return_all_internals=False, beam_size=5, beam_group_size=5,
+                 diversity_penalty=0.8, exclude_protein_structure=False, nucleus_prob=0.9, truncate_on_eos=True):
+        """`generate` (model_unified.py:924-1027).  The non-beam call site of the reference mis-binds its positional
+        arguments (:998-1005, quirk Q8); the evident intent -- the same names bound by keyword -- is implemented, which
+        means `nucleus_prob` (default 0.9) reaches `_generate_sampling` for every non-beam method, as written there;
+        pass nucleus_prob=None for plain temperature sampling."""
+        assert method in ["sampling", "temperature", "greedy", "beam", "nucleus"]
+        if method == "beam":
+            num_text_per_instance = beam_size
+        elif method == "greedy":
+            greedy = True
+        elif method in ["sampling", "nucleus"]:
+            temperature = 1
+        if temperature < 1e-8:
+            greedy = True
+        input_embeds, input_ids, attn_masks, _, _, _ = self._preprocessing(
+            inputs, aaseq_type=aaseq_type, crop_off=True, no_pad=True,
+            exclude_protein_structure=exclude_protein_structure, left_pad=True)
+        whole_instructions = self.tokenizer.batch_decode(input_ids)
+        gt_text = [inputs["data"]["text"][i] for i in inputs["target"]["text"]] if inputs["target"]["text"] is not None else None
+        batch_size = input_embeds.shape[0]
+        if method == "beam":
+            tokens, log_probs, logits = self._generate_beam_search(
+                input_embeds, attn_masks, max_len=max_len, beam_size=beam_size, diversity_penalty=diversity_penalty,
+                beam_group_size=beam_group_size)
+        else:
+            tokens, log_probs, logits = self._generate_sampling(
+                input_embeds, attn_masks, max_len=max_len, num_text_per_instance=num_text_per_instance,
+                temperature=temperature, greedy=greedy, nucleus_prob=nucleus_prob)
+        flattened = torch.flatten(tokens, start_dim=0, end_dim=1)
+        text = self.tokenizer.batch_decode(flattened)
+        if truncate_on_eos:
+            text = [x.split(self.tokenizer.eos_token)[0].strip() for x in text]
+        text = [text[i * num_text_per_instance:(i + 1) * num_text_per_instance] for i in range(batch_size)]
+        if return_all_internals:
+            return {"out_tokens": tokens, "out_logits": logits, "out_log_probs": log_probs, "text": text,
+                    "input_instructions": whole_instructions, "ground_truth_text": gt_text,
+                    "text_references": inputs["reference_indices"]["target"]["text"],
+                    "seq_references": [inputs["reference_indices"]["input"]["seq"][j][-1] for j, _ in enumerate(inputs["input"]["seq"])]}
+        return tokens, log_probs, logits, text

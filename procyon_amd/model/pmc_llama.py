@@ -1,0 +1,78 @@
+"""Mirror of `LlamaPostTokenization` (/root/reference/procyon/model/pmc_llama.py:415-596) over the HIP engine."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from ..engine import GenState, KVCache, LlamaConfig, LlamaEngine
+
+
+class _Past(list):
+    """past_key_values: indexable [layer][0|1] -> [B,Hkv,t,dh] VIEWS of the engine cache, so the in-place row
+    re-indexing the reference's beam search performs (model_unified.py:830-832) acts on the live cache."""
+
+    def __init__(self, cache: KVCache, t: int):
+        super().__init__([[cache.k[l, :, :, :t], cache.v[l, :, :, :t]] for l in range(cache.k.shape[0])])
+        self.cache, self.t = cache, t
+
+
+class LlamaPostTokenization:
+    """forward(input_embeds|input_ids, attn_masks, full_labels, past_key_values, use_cache, output_attentions)
+    -> object with .logits, .past_key_values, .hidden_states, .loss   (pmc_llama.py:546-596).
+
+    Exactly one of input_embeds / input_ids (:562).  Differences, all documented in DESIGN.md:
+      * `logit_positions` (extension): LongTensor [B] -> logits only at those positions ([B,1,V]); the
+        reference always materialises [B,T,V] (1 GB per 2048-token row).  None = all rows.
+      * .hidden_states holds only the final (post-norm) state, as [-1] (ret_token_access='last',
+        llama3-full.yml:53); the 33-tuple the reference builds is not materialised.
+      * full_labels / loss / output_attentions: training-side, not computed (loss=None).
+      * max_new_tokens: KV capacity reserved beyond the prompt when use_cache=True.
+    """
+
+    def __init__(self, state_dict, cfg: LlamaConfig, device=None, max_new_tokens=256):
+        self.engine = LlamaEngine(state_dict, cfg, device)
+        self.cfg = cfg
+        self.max_new_tokens = max_new_tokens
+        self.model = SimpleNamespace(vocab_size=cfg.vocab, config=SimpleNamespace(hidden_size=cfg.d))
+        self._state = None
+
+    def eval(self):
+        return self
+
+    def get_input_embeddings(self):
+        return self.engine.embed
+
+    def forward(self, input_embeds=None, input_ids=None, attn_masks=None, full_labels=None, past_key_values=None,
+                use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True):
+        assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
+        eng = self.engine
+        if past_key_values is None:
+            if input_embeds is None:
+                input_embeds = eng.embed_tokens(input_ids)
+            B, T, _ = input_embeds.shape
+            cache = eng.new_cache(B, T + (self.max_new_tokens if use_cache else 0))
+            if logit_positions is None:
+                rows = torch.arange(B * T, dtype=torch.int32)
+            else:
+                rows = (torch.arange(B) * T + logit_positions.cpu().long()).to(torch.int32)
+            logits, hidden = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden)
+            logits = logits.view(B, -1, self.cfg.vocab)
+            past = _Past(cache, T) if use_cache else None
+            return SimpleNamespace(logits=logits, past_key_values=past, hidden_states=(hidden,), loss=None)
+        # cached decode: one new token per row, no mask, position = cache length (quirks Q1/Q2)
+        assert input_ids is not None and input_ids.shape[1] == 1, "cached decode takes input_ids [B,1]"
+        cache, t = past_key_values.cache, past_key_values.t
+        B = input_ids.shape[0]
+        if t + 1 > cache.Tmax:
+            raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
+        if self._state is None or self._state.next_tok.shape[0] != B:
+            self._state = GenState(B, self.cfg.vocab, 1, eng.device)
+        st = self._state
+        st.pos.fill_(t)
+        st.next_tok.copy_(input_ids.view(-1).to(torch.int32))
+        eng.decode(cache, st, B)
+        return SimpleNamespace(logits=st.logits.clone().view(B, 1, -1), past_key_values=_Past(cache, t + 1),
+                               hidden_states=None, loss=None)
+
+    __call__ = forward
