@@ -44,7 +44,9 @@ def cpu_baseline(tokens, residues, prompt):
     from oracle import esm_ref as ER
     from oracle import llama_ref as LR
     from procyon_amd import synth
-    torch.set_num_threads(os.cpu_count())
+    # torch-CPU bf16 is fastest at ~32 threads on the GPU box's EPYC host (tools/cpu_threads_probe.py: 8/32/64/128/256
+    # threads -> 11.7/9.4/29.9/35.2/3334 ms per decode layer), so the baseline is not handicapped by oversubscription
+    torch.set_num_threads(min(32, os.cpu_count()))
     cores = torch.get_num_threads()
     ek = dict(d=1280, n_layers=2, n_heads=20, ffn=5120)
     esd = synth.esm_state_dict(**ek)
@@ -148,7 +150,7 @@ def main():
     st = GenState(1, cfg.vocab, a.tokens, dev)
     logits, _ = eng.prefill(emb, mask, cache, "last")
     st.logits.copy_(logits); st.pos.fill_(a.prompt)
-    eng.pick(st, 1, advance_pos=False)
+    eng.pick(cache, st, 1, advance_pos=False)
     eng.greedy_steps(cache, st, 1, 8)          # warm the graph
     ctx.timer_start()
     nsteps = a.tokens - 16

@@ -152,7 +152,7 @@ typedef struct {
 int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
 /* argmax of state->logits (lowest index on ties) -> next_tok / tokens_out[step], logprob, ++pos? no: ++step only
  * when advance_pos == 0 (used on the prefill logits), ++pos and ++step otherwise */
-int pcy_greedy_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_gen_state*, int B, int advance_pos);
+int pcy_greedy_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int advance_pos);
 /* n_steps x (decode + pick) with no host synchronisation; use_graph != 0 replays a captured hipGraph */
 int pcy_llama_greedy(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int n_steps,
                      int use_graph);

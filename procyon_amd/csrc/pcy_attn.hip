@@ -9,7 +9,7 @@
 //     16-row MFMA tiles so that every lane ends with 8 CONSECUTIVE keys of one query; those 8
 //     probabilities are exactly the lane's A-operand fragment of the P.V MFMA (no LDS, no shuffles),
 //     and the matching B operand is one 16-byte load from a pre-transposed V (Vt[d][key]).
-// (2) attn_decode_kernel<DH,G>: one new token per row against the KV cache, RoPE + cache append fused.
+// (2) attn_dec_scores / attn_dec_pv: one new token per row against the KV cache, RoPE + cache append fused.
 #include "pcy_internal.h"
 
 namespace {
@@ -127,141 +127,147 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decode attention.  grid (Hkv, B), 256 threads.  LDS: qs[G][DH] f32 | kn[DH] f32 | vn[DH] f32 |
-// red[NG][G][DH] f32 | stats | sc[G][Tmax+1] f32
+// Decode attention (row A7): one new token per row against the KV cache, exact softmax rounding.
+// Two launches so that the work spreads over the chip instead of Hkv*B workgroups:
+//   (A) attn_dec_scores: grid (key chunks of 64, Hkv, B).  Every block ropes the G query heads of its kv head in
+//       registers (three bf16 roundings, HF Llama), streams its 64 cached keys with 16 lanes x 16 B per key row,
+//       writes s = bf16(bf16(q.k)*scale) as fp32 to scratch[B,H,Tmax+1].  The block that owns slot t also ropes the
+//       new key, appends K and V to the cache and scores it from registers.
+//   (B) attn_dec_pv: grid (DH/16 column slices, Hkv, B).  Every block re-reads the G score rows (a few KB, L2),
+//       computes max / sum / p = bf16(exp(s-m)/l) in LDS, then accumulates P.V for its 16 output columns over all keys
+//       (fp32), reduces across its key groups in LDS and rounds once -> no cross-workgroup reduction.
+template <int DH>
+__device__ __forceinline__ void rope8(const bf16_t* __restrict__ x, const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
+                                      int e0, float (&out)[8]) {
+  // elements e0..e0+7 of one head; partner = e +- DH/2
+  constexpr int HALF = DH / 2;
+  const bool lo = e0 < HALF;
+  const int p0 = lo ? e0 + HALF : e0 - HALF;
+  const uint4 a = *reinterpret_cast<const uint4*>(x + e0);
+  const uint4 b = *reinterpret_cast<const uint4*>(x + p0);
+  const uint4 c = *reinterpret_cast<const uint4*>(cs + e0);
+  const uint4 s = *reinterpret_cast<const uint4*>(sn + e0);
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, cw[4] = {c.x, c.y, c.z, c.w}, sw[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = lo_bf(aw[i]), x1 = hi_bf(aw[i]);
+    float r0 = lo_bf(bw[i]), r1 = hi_bf(bw[i]);   // rotate_half partner: -x2 for the low half, +x1 for the high half
+    if (lo) { r0 = -r0; r1 = -r1; }
+    out[2 * i] = rbf(rbf(x0 * lo_bf(cw[i])) + rbf(r0 * lo_bf(sw[i])));
+    out[2 * i + 1] = rbf(rbf(x1 * hi_bf(cw[i])) + rbf(r1 * hi_bf(sw[i])));
+  }
+}
+
 template <int DH, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(PcyDecAttnArgs a) {
-  constexpr int LPK = DH / 8;        // lanes per key row (16 B each)
-  constexpr int NG = 256 / LPK;      // key groups per block
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* qs = reinterpret_cast<float*>(smem);
-  float* kn = qs + G * DH;
-  float* vn = kn + DH;
-  float* red = vn + DH;              // [NG][G][DH]
-  float* stat = red + NG * G * DH;   // [G][2]
-  float* wred = stat + 2 * G;        // [4] block reduce scratch
-  float* sc = wred + 8;              // [G][Tmax+1]
-  const int kvh = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int t = *a.pos_dev;          // cache length; new token's slot and rotary position
-  const int nk = t + 1;
-  const int scld = a.Tmax + 1;
-  bf16_t* row = a.qkv + (size_t)b * a.ld;
+__global__ __launch_bounds__(256) void attn_dec_scores_kernel(PcyDecAttnArgs a) {
+  constexpr int LPK = DH / 8;    // lanes per key row
+  constexpr int NG = 256 / LPK;  // key groups per block
+  constexpr int CH = 64;         // keys per block
+  const int t = *a.pos_dev;
+  const int j0 = blockIdx.x * CH;
+  if (j0 > t) return;
+  const int kvh = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, grp = tid / LPK, sub = tid % LPK;
+  const bf16_t* row = a.qkv + (size_t)b * a.ld;
   bf16_t* kc = a.kcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH;
   bf16_t* vc = a.vcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH;
   const bf16_t* cs = a.cos_t + (size_t)t * DH;
   const bf16_t* sn = a.sin_t + (size_t)t * DH;
-  constexpr int HALF = DH / 2;
-  // RoPE (three bf16 roundings, HF Llama) on the G query heads and the new key; append K,V
-  for (int e = tid; e < (G + 1) * HALF; e += 256) {
-    const int hh = e / HALF, i = e - hh * HALF;
-    const bf16_t* x = (hh < G) ? row + (kvh * G + hh) * DH : row + (a.H + kvh) * DH;
-    const float x1 = bf2f(x[i]), x2 = bf2f(x[i + HALF]);
-    const float o1 = rbf(rbf(x1 * bf2f(cs[i])) + rbf(-x2 * bf2f(sn[i])));
-    const float o2 = rbf(rbf(x2 * bf2f(cs[i + HALF])) + rbf(x1 * bf2f(sn[i + HALF])));
-    if (hh < G) { qs[hh * DH + i] = o1; qs[hh * DH + i + HALF] = o2; }
-    else {
-      kn[i] = o1; kn[i + HALF] = o2;
-      kc[(size_t)t * DH + i] = f2bf(o1); kc[(size_t)t * DH + i + HALF] = f2bf(o2);
-    }
-  }
-  for (int e = tid; e < DH; e += 256) {
-    const bf16_t v = row[(a.H + a.Hkv + kvh) * DH + e];
-    vn[e] = bf2f(v);
-    vc[(size_t)t * DH + e] = v;
-  }
-  __syncthreads();
-
-  const int grp = tid / LPK, sub = tid % LPK;
+  float q[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) rope8<DH>(row + (kvh * G + g) * DH, cs, sn, sub * 8, q[g]);
   const uint8_t* keep = a.keep ? a.keep + (size_t)b * a.ld_keep : nullptr;
-  // scores
-  float qreg[G][8];
+  const int scld = a.Tmax + 1;
+  float* sc = a.scratch + ((size_t)b * a.H + kvh * G) * scld;
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qreg[g][i] = qs[g * DH + sub * 8 + i];
-  for (int j = grp; j < nk; j += NG) {
+  for (int i = 0; i < CH / NG; ++i) {
+    const int j = j0 + i * NG + grp;
+    if (j > t) continue;   // uniform per key group (LPK lanes)
     float kf[8];
     if (j < t) {
       const uint4 kv = *reinterpret_cast<const uint4*>(kc + (size_t)j * DH + sub * 8);
       kf[0] = lo_bf(kv.x); kf[1] = hi_bf(kv.x); kf[2] = lo_bf(kv.y); kf[3] = hi_bf(kv.y);
       kf[4] = lo_bf(kv.z); kf[5] = hi_bf(kv.z); kf[6] = lo_bf(kv.w); kf[7] = hi_bf(kv.w);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) kf[i] = kn[sub * 8 + i];
+    } else {  // the new token: rope its key, append K and V
+      rope8<DH>(row + (a.H + kvh) * DH, cs, sn, sub * 8, kf);
+      *reinterpret_cast<uint4*>(kc + (size_t)t * DH + sub * 8) =
+          make_uint4(pack_bf(kf[0], kf[1]), pack_bf(kf[2], kf[3]), pack_bf(kf[4], kf[5]), pack_bf(kf[6], kf[7]));
+      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + sub * 8) =
+          *reinterpret_cast<const uint4*>(row + (a.H + a.Hkv + kvh) * DH + sub * 8);
     }
-    const bool kept = keep ? (j < t ? keep[j] != 0 : true) : true;
+    const bool kept = (keep && j < t) ? keep[j] != 0 : true;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float d = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d += qreg[g][i] * kf[i];
+      for (int e = 0; e < 8; ++e) d += q[g][e] * kf[e];
 #pragma unroll
       for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-      if (sub == 0) sc[g * scld + j] = kept ? rbf(rbf(d) * a.scale) : PCY_BF16_MIN;
+      if (sub == 0) sc[(size_t)g * scld + j] = kept ? rbf(rbf(d) * a.scale) : PCY_BF16_MIN;
     }
   }
-  __syncthreads();
-  // softmax stats per head
+}
+
+template <int DH, int G>
+__global__ __launch_bounds__(256) void attn_dec_pv_kernel(PcyDecAttnArgs a) {
+  constexpr int DS = 16;          // output columns per block
+  constexpr int LPR = DS / 2;     // lanes per V row (2 columns = 4 B each)
+  constexpr int NG = 256 / LPR;   // key groups
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* p = reinterpret_cast<float*>(smem);          // [G][nk]
+  const int t = *a.pos_dev;
+  const int nk = t + 1;
+  float* red = p + (size_t)G * (a.Tmax + 1);           // [NG][G][DS]
+  float* wred = red + NG * G * DS;                     // [8]
+  const int c0 = blockIdx.x * DS, kvh = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int scld = a.Tmax + 1;
+  const float* sc = a.scratch + ((size_t)b * a.H + kvh * G) * scld;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     float mx = -INFINITY;
-    for (int j = tid; j < nk; j += 256) mx = fmaxf(mx, sc[g * scld + j]);
+    for (int j = tid; j < nk; j += 256) { const float v = sc[(size_t)g * scld + j]; p[g * scld + j] = v; mx = fmaxf(mx, v); }
     mx = block_max<256>(mx, wred);
     float se = 0.f;
-    for (int j = tid; j < nk; j += 256) se += expf(sc[g * scld + j] - mx);
+    for (int j = tid; j < nk; j += 256) se += expf(p[g * scld + j] - mx);
     se = block_sum<256>(se, wred);
-    for (int j = tid; j < nk; j += 256) sc[g * scld + j] = rbf(expf(sc[g * scld + j] - mx) / se);
+    for (int j = tid; j < nk; j += 256) p[g * scld + j] = rbf(expf(p[g * scld + j] - mx) / se);
   }
   __syncthreads();
-  // P.V : lane owns d in [sub*8, sub*8+8), keys j = grp + NG*i
-  float acc[G][8];
+  const int grp = tid / LPR, sub = tid % LPR;
+  const bf16_t* vc = a.vcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH + c0 + sub * 2;
+  float acc[G][2];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[g][i] = 0.f;
+  for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = 0.f;
   for (int j = grp; j < nk; j += NG) {
-    float vf[8];
-    if (j < t) {
-      const uint4 vv = *reinterpret_cast<const uint4*>(vc + (size_t)j * DH + sub * 8);
-      vf[0] = lo_bf(vv.x); vf[1] = hi_bf(vv.x); vf[2] = lo_bf(vv.y); vf[3] = hi_bf(vv.y);
-      vf[4] = lo_bf(vv.z); vf[5] = hi_bf(vv.z); vf[6] = lo_bf(vv.w); vf[7] = hi_bf(vv.w);
-    } else {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(vc + (size_t)j * DH);
+    const float v0 = lo_bf(w), v1 = hi_bf(w);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vf[i] = vn[sub * 8 + i];
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float p = sc[g * scld + j];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[g][i] += p * vf[i];
-    }
+    for (int g = 0; g < G; ++g) { const float pj = p[g * scld + j]; acc[g][0] += pj * v0; acc[g][1] += pj * v1; }
   }
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) red[(grp * G + g) * DH + sub * 8 + i] = acc[g][i];
+  for (int g = 0; g < G; ++g) { red[(grp * G + g) * DS + sub * 2] = acc[g][0]; red[(grp * G + g) * DS + sub * 2 + 1] = acc[g][1]; }
   __syncthreads();
-  for (int e = tid; e < G * DH; e += 256) {
+  if (tid < G * DS) {
     float s = 0.f;
-#pragma unroll 4
-    for (int gg = 0; gg < NG; ++gg) s += red[gg * G * DH + e];
-    const int g = e / DH, d = e - g * DH;
-    a.o[(size_t)b * a.ldo + (kvh * G + g) * DH + d] = f2bf(s);
+    for (int gg = 0; gg < NG; ++gg) s += red[gg * G * DS + tid];
+    const int g = tid / DS, c = tid % DS;
+    a.o[(size_t)b * a.ldo + (kvh * G + g) * DH + c0 + c] = f2bf(s);
   }
 }
 
 template <int DH, int G>
 void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
-  constexpr int LPK = DH / 8, NG = 256 / LPK;
-  const size_t smem = sizeof(float) * ((size_t)G * DH + 2 * DH + (size_t)NG * G * DH + 2 * G + 8 + (size_t)G * (a.Tmax + 1));
+  constexpr int NGB = 256 / 8;
+  const size_t smem = sizeof(float) * ((size_t)G * (a.Tmax + 1) + (size_t)NGB * G * 16 + 8);
   static size_t configured = 0;
   if (smem > 65536 && smem > configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<DH, G>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_pv_kernel<DH, G>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
-  hipLaunchKernelGGL((attn_decode_kernel<DH, G>), dim3(a.Hkv, a.B), dim3(256), smem, s, a);
+  hipLaunchKernelGGL((attn_dec_scores_kernel<DH, G>), dim3((a.Tmax + 63) / 64, a.Hkv, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((attn_dec_pv_kernel<DH, G>), dim3(DH / 16, a.Hkv, a.B), dim3(256), smem, s, a);
 }
 
 template <int DH>

@@ -220,20 +220,25 @@ __global__ __launch_bounds__(NT) void pool_kernel(const bf16_t* __restrict__ h, 
   out[(size_t)p * d + c] = (mode == 2) ? f2bf(acc) : f2bf(rbf(acc) / (float)cnt);
 }
 
-// ------------------------------------------------------------------ greedy pick (A8): argmax + log-prob + advance
-constexpr int PICK_NT = 1024;
-__global__ __launch_bounds__(PICK_NT) void greedy_pick_kernel(const bf16_t* __restrict__ logits, int V,
-                                                              int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out,
-                                                              int max_steps, float* __restrict__ logprob,
-                                                              const int32_t* __restrict__ step_dev) {
+// ------------------------------------------------------------------ greedy pick (A8): argmax + log-prob
+// two stages so the 128k-entry vocabulary is scanned by 64 workgroups instead of one:
+//   stage 1: block c of row b scans a contiguous chunk -> (max, lowest argmax, sum exp(x - local max))
+//   stage 2: one wave per row merges the 64 partials, picks the token, adds bf16 log_softmax(logits)[tok]
+constexpr int PICK_NT = 256;
+constexpr int PICK_NB = 64;
+struct PickPartial { float mx; int idx; float se; int pad; };
+
+__global__ __launch_bounds__(PICK_NT) void pick_stage1_kernel(const bf16_t* __restrict__ logits, int V, PickPartial* __restrict__ part) {
   __shared__ float redv[PICK_NT / 64];
   __shared__ int redi[PICK_NT / 64];
   __shared__ float red[PICK_NT / 64];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int chunk = (V + PICK_NB - 1) / PICK_NB;
+  const int lo = c * chunk, hi = (lo + chunk) < V ? (lo + chunk) : V;
   const bf16_t* lg = logits + (size_t)b * V;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += PICK_NT) {
+  for (int i = lo + threadIdx.x; i < hi; i += PICK_NT) {
     const float v = bf2f(lg[i]);
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
@@ -249,13 +254,31 @@ __global__ __launch_bounds__(PICK_NT) void greedy_pick_kernel(const bf16_t* __re
   best = redv[0]; bi = redi[0];
   for (int i = 1; i < PICK_NT / 64; ++i)
     if (redv[i] > best || (redv[i] == best && redi[i] < bi)) { best = redv[i]; bi = redi[i]; }
-  // log_softmax in bf16 (model dtype): bf16( x - max - log(sum exp(x - max)) )
   float se = 0.f;
-  for (int i = threadIdx.x; i < V; i += PICK_NT) se += expf(bf2f(lg[i]) - best);
+  for (int i = lo + threadIdx.x; i < hi; i += PICK_NT) se += expf(bf2f(lg[i]) - best);
   se = block_sum<PICK_NT>(se, red);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) part[b * PICK_NB + c] = PickPartial{best, bi, (lo < hi) ? se : 0.f, 0};
+}
+
+__global__ __launch_bounds__(64) void pick_stage2_kernel(const bf16_t* __restrict__ logits, int V, const PickPartial* __restrict__ part,
+                                                         int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, int max_steps,
+                                                         float* __restrict__ logprob, const int32_t* __restrict__ step_dev) {
+  const int b = blockIdx.x, l = threadIdx.x;
+  const PickPartial pp = part[b * PICK_NB + l];
+  float best = pp.mx;
+  int bi = pp.idx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  float se = pp.se * expf(pp.mx - best);   // empty chunks: mx = -inf -> exp(-inf) = 0
+  se = wave_sum(se);
+  if (l == 0) {
     const int step = *step_dev;
-    const float lsm = rbf((bf2f(lg[bi]) - best) - logf(se));
+    // log_softmax in model dtype: bf16( x - max - log(sum exp(x - max)) ), x[tok] == max
+    const float lsm = rbf((bf2f(logits[(size_t)b * V + bi]) - best) - logf(se));
     logprob[b] += lsm;
     next_tok[b] = bi;
     tokens_out[(size_t)b * max_steps + step] = bi;
@@ -313,8 +336,10 @@ void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, 
   if (nprot > 0) hipLaunchKernelGGL(pool_kernel, dim3(nprot, (d + NT - 1) / NT), dim3(NT), 0, s, h, d, seg, rng, mode, out);
 }
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
-                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
-  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(PICK_NT), 0, s, logits, V, next_tok, tokens_out, max_steps, logprob, step_dev);
+                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials) {
+  hipLaunchKernelGGL(pick_stage1_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, reinterpret_cast<PickPartial*>(partials));
+  hipLaunchKernelGGL(pick_stage2_kernel, dim3(B), dim3(64), 0, s, logits, V, reinterpret_cast<const PickPartial*>(partials), next_tok,
+                     tokens_out, max_steps, logprob, step_dev);
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev, advance_pos);
 }
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {

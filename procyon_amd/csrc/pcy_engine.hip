@@ -97,10 +97,11 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
 // ------------------------------------------------------------------ decode step (enqueue only)
 struct DecodeWs { bf16_t *x, *qkv, *ao, *act; };
 
-size_t decode_ws_bytes(const pcy_llama_desc* m, int B) {
+size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
   const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
   return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
-         align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) + 4096;
+         align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) +
+         align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) + 4096;
 }
 
 void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
@@ -112,6 +113,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   bf16_t* qkv = cv.take<bf16_t>((size_t)B * qkvw);
   bf16_t* ao = cv.take<bf16_t>((size_t)B * H * dh);
   bf16_t* act = cv.take<bf16_t>((size_t)B * F);
+  float* scores = cv.take<float>((size_t)B * H * (kv->Tmax + 1));
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l) {
@@ -123,7 +125,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
-    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = nullptr; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
+    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
     pcy_launch_attn_decode(s, t);
     PcyGemvArgs o{};
@@ -147,13 +149,19 @@ __global__ void store_logits_kernel(const bf16_t* __restrict__ logits, bf16_t* _
   const size_t base = (size_t)(*step_dev) * n;
   for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) all[base + i] = logits[i];
 }
-void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos) {
+void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos, int Tmax) {
   hipStream_t s = c->stream;
   if (st->logits_all)
     hipLaunchKernelGGL(store_logits_kernel, dim3(64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)st->logits_all,
                        st->step, (size_t)B * m->vocab);
+  // partials live at the tail of the decode workspace carve (same offsets as enqueue_decode)
+  Carver cv(c->ws);
+  const int qkvw = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  cv.take<bf16_t>((size_t)B * m->d); cv.take<bf16_t>((size_t)B * qkvw); cv.take<bf16_t>((size_t)B * m->n_heads * m->head_dim);
+  cv.take<bf16_t>((size_t)B * m->ffn); cv.take<float>((size_t)B * m->n_heads * (Tmax + 1));
+  void* partials = cv.take<char>((size_t)B * 64 * 16);
   pcy_launch_greedy_pick(s, (const bf16_t*)st->logits, B, m->vocab, st->next_tok, st->tokens_out, st->max_steps,
-                         st->logprob, st->pos, st->step, advance_pos);
+                         st->logprob, st->pos, st->step, advance_pos, partials);
 }
 
 __global__ void kv_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ rows,
@@ -411,24 +419,25 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
 
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
-  if (int r = c->reserve(decode_ws_bytes(m, B))) return r;
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
 
-int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos) {
-  enqueue_pick(c, m, st, B, advance_pos);
+int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int advance_pos) {
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  enqueue_pick(c, m, st, B, advance_pos, kv->Tmax);
   return check_launch("pcy_greedy_pick");
 }
 
 int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
                      int use_graph) {
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
-  if (int r = c->reserve(decode_ws_bytes(m, B))) return r;
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       enqueue_decode(c, m, kv, st, B);
-      enqueue_pick(c, m, st, B, 1);
+      enqueue_pick(c, m, st, B, 1, kv->Tmax);
     }
     return check_launch("pcy_llama_greedy");
   }
@@ -441,7 +450,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e0 == hipSuccess) {
       enqueue_decode(c, m, kv, st, B);
-      enqueue_pick(c, m, st, B, 1);
+      enqueue_pick(c, m, st, B, 1, kv->Tmax);
       e0 = hipStreamEndCapture(c->cap_stream, &g);
     }
     c->stream = user;
@@ -459,8 +468,8 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
   const int Hkv = m->n_kv_heads, dh = m->head_dim;
   if (t <= 0) return 0;
   const size_t tmp_elems = (size_t)B * Hkv * t * dh;
-  if (int r = c->reserve(decode_ws_bytes(m, B) + align_up(tmp_elems * 2, 256) + 4096)) return r;
-  bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B), 256));
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
+  bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l)
     for (int which = 0; which < 2; ++which) {

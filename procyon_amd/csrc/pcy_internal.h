@@ -74,6 +74,7 @@ void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, 
 // logprob[B] (bf16 log-softmax, fp32 running sum), appends tok to tokens_out[b*max_steps + step], writes
 // next_tok[b], then (one thread) ++*step and, if advance_pos, ++*pos.
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
-                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos);
+                            int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos,
+                            void* partials /* B*64*16 bytes of scratch */);
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);

@@ -304,8 +304,9 @@ class LlamaEngine:
     def decode(self, cache: KVCache, st: GenState, B):
         L.check(self.ctx.lib.pcy_llama_decode(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode")
 
-    def pick(self, st: GenState, B, advance_pos):
-        L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(st.c), B, int(advance_pos)), "pcy_greedy_pick")
+    def pick(self, cache: KVCache, st: GenState, B, advance_pos):
+        L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, int(advance_pos)),
+                "pcy_greedy_pick")
 
     def greedy_steps(self, cache, st, B, n_steps, use_graph=True):
         L.check(self.ctx.lib.pcy_llama_greedy(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, n_steps,
@@ -329,7 +330,7 @@ class LlamaEngine:
         logits, _ = self.prefill(embeds, attn_mask, cache, "last")
         st.logits.copy_(logits)
         st.pos.fill_(T)
-        self.pick(st, B, advance_pos=False)
+        self.pick(cache, st, B, advance_pos=False)
         if max_len > 1:
             self.greedy_steps(cache, st, B, max_len - 1, use_graph)
         la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
