@@ -69,6 +69,11 @@ int pcy_rope(pcy_ctx*, void* buf, int ld, int col0, int nh, int dh, const int32_
 int pcy_attention(pcy_ctx*, const void* q, int ldq, int qcol0, const void* k, int ldk, int kcol0, const void* v, int ldv,
                   int vcol0, void* o, int ldo, const int32_t* cu, const int32_t* vt_cu, const uint8_t* keep, int nseq,
                   int max_len, int vt_total, int H, int Hkv, int dh, int causal, float scale);
+/* Decode attention of ONE new token per row against the [B,Hkv,Tmax,dh] cache: ropes q and the new k at position
+ * *pos (device scalar = cache length), appends K,V at slot *pos, attends slots [0,*pos] (keep: optional [B,Tmax]
+ * key mask, NULL = the reference's unmasked decode, quirk Q1).  qkv [B,(H+2Hkv)*dh] un-roped projections. */
+int pcy_attn_decode(pcy_ctx*, void* qkv, int ld, void* kcache, void* vcache, void* o, int ldo, const int32_t* pos,
+                    const void* cos_t, const void* sin_t, const uint8_t* keep, int B, int H, int Hkv, int dh, int Tmax);
 /* pooled[i] over the token ranges rng[2*r],rng[2*r+1] = (start,len), r in [seg[i], seg[i+1])  (esm.py:131-173) */
 int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pcy_embed_splice": (ci, [vp, vp, vp, vp, vp, vp, ci, ci]),
     "pcy_rope": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, ci, C.c_float]),
     "pcy_attention": (ci, [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, C.c_float]),
+    "pcy_attn_decode": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "pcy_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),

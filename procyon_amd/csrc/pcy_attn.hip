@@ -158,99 +158,210 @@ __device__ __forceinline__ void rope8(const bf16_t* __restrict__ x, const bf16_t
   }
 }
 
+// Fused decode attention: grid (DH/16 column slices, Hkv, B), 512 threads.  Every block ropes q, scores ALL keys of
+// its kv head (the K panel is small; the redundancy across the DH/16 slices buys a launch without any cross-workgroup
+// dependency), normalises exactly, and accumulates P.V for its 16 output columns.
+//   phase A  scores by MFMA: A operand = the G roped query heads (rows >= G are zero), B operand = 16 cached key rows
+//            loaded straight from HBM in fragment layout (16 B per lane) -> no cross-lane reduction at all
+//   phase B  exact softmax statistics (max, sum, p = bf16(exp(s-m)/l)) for all G heads in LDS
+//   phase C  P.V on the VALU: lane pair (2 x 16 B) per V row slice, DPP row-rotate reduction over the key groups
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(r);
+}
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x122>(v);  // row_ror:2
+  v = dpp_add<0x121>(v);  // row_ror:1
+  return v;
+}
+
 template <int DH, int G>
-__global__ __launch_bounds__(256) void attn_dec_scores_kernel(PcyDecAttnArgs a) {
-  constexpr int LPK = DH / 8;    // lanes per key row
-  constexpr int NG = 256 / LPK;  // key groups per block
-  constexpr int CH = 64;         // keys per block
+__global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
+  constexpr int NT = 512, NWV = NT / 64;
+  constexpr int KB = DH / 32;
+  constexpr int DS = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int scld = a.Tmax + 1;
+  bf16_t* qk = reinterpret_cast<bf16_t*>(smem);                        // [(G+1)][DH] roped q heads, then roped k_new
+  float* sc = reinterpret_cast<float*>(smem + (G + 1) * DH * 2);       // [G][scld] scores, then probabilities
+  float* red = sc + (size_t)G * scld;           // [NWV][G][DS]
+  float* wred = red + NWV * G * DS;             // [NWV][G]
+  const int c0 = blockIdx.x * DS, kvh = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
   const int t = *a.pos_dev;
-  const int j0 = blockIdx.x * CH;
-  if (j0 > t) return;
-  const int kvh = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, grp = tid / LPK, sub = tid % LPK;
+  const int nk = t + 1;
+  if (a.dbg == 1) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = (bf16_t)t; return; }
   const bf16_t* row = a.qkv + (size_t)b * a.ld;
   bf16_t* kc = a.kcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH;
   bf16_t* vc = a.vcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH;
   const bf16_t* cs = a.cos_t + (size_t)t * DH;
   const bf16_t* sn = a.sin_t + (size_t)t * DH;
-  float q[G][8];
-#pragma unroll
-  for (int g = 0; g < G; ++g) rope8<DH>(row + (kvh * G + g) * DH, cs, sn, sub * 8, q[g]);
   const uint8_t* keep = a.keep ? a.keep + (size_t)b * a.ld_keep : nullptr;
-  const int scld = a.Tmax + 1;
-  float* sc = a.scratch + ((size_t)b * a.H + kvh * G) * scld;
+
+  // ---- phase A ----
+  {
+    // key fragments of the first two 16-key tiles of this wave, in flight while q / k_new are roped
+    constexpr int PASS = NWV * 32;   // keys per block per iteration (2 tiles of 16 per wave)
+    auto key_of = [&](int j0, int tile) { return j0 + wave * 32 + tile * 16 + fr; };
+    auto load_tile = [&](int j, bf16x8 (&f)[KB]) {
+      const int jc = j < t ? j : (t > 0 ? t - 1 : 0);
+      const bf16_t* p = kc + (size_t)jc * DH + fq * 8;
 #pragma unroll
-  for (int i = 0; i < CH / NG; ++i) {
-    const int j = j0 + i * NG + grp;
-    if (j > t) continue;   // uniform per key group (LPK lanes)
-    float kf[8];
-    if (j < t) {
-      const uint4 kv = *reinterpret_cast<const uint4*>(kc + (size_t)j * DH + sub * 8);
-      kf[0] = lo_bf(kv.x); kf[1] = hi_bf(kv.x); kf[2] = lo_bf(kv.y); kf[3] = hi_bf(kv.y);
-      kf[4] = lo_bf(kv.z); kf[5] = hi_bf(kv.z); kf[6] = lo_bf(kv.w); kf[7] = hi_bf(kv.w);
-    } else {  // the new token: rope its key, append K and V
-      rope8<DH>(row + (a.H + kvh) * DH, cs, sn, sub * 8, kf);
-      *reinterpret_cast<uint4*>(kc + (size_t)t * DH + sub * 8) =
-          make_uint4(pack_bf(kf[0], kf[1]), pack_bf(kf[2], kf[3]), pack_bf(kf[4], kf[5]), pack_bf(kf[6], kf[7]));
-      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + sub * 8) =
-          *reinterpret_cast<const uint4*>(row + (a.H + a.Hkv + kvh) * DH + sub * 8);
+      for (int kb = 0; kb < KB; ++kb) f[kb] = *reinterpret_cast<const bf16x8*>(p + kb * 32);
+    };
+    bf16x8 k0[KB], k1[KB];
+    load_tile(key_of(0, 0), k0);
+    load_tile(key_of(0, 1), k1);
+    // rope q (G heads) and the new key ONCE per block into LDS (bf16), then pick fragments from there
+    for (int e = tid; e < (G + 1) * (DH / 8); e += NT) {
+      const int hh = e / (DH / 8), ch = e % (DH / 8);
+      const bf16_t* src = (hh < G) ? row + (kvh * G + hh) * DH : row + (a.H + kvh) * DH;
+      float tmp[8];
+      rope8<DH>(src, cs, sn, ch * 8, tmp);
+      *reinterpret_cast<uint4*>(qk + hh * DH + ch * 8) =
+          make_uint4(pack_bf(tmp[0], tmp[1]), pack_bf(tmp[2], tmp[3]), pack_bf(tmp[4], tmp[5]), pack_bf(tmp[6], tmp[7]));
+      if (hh == G && blockIdx.x == 0)   // append the new token's K
+        *reinterpret_cast<uint4*>(kc + (size_t)t * DH + ch * 8) = *reinterpret_cast<const uint4*>(qk + hh * DH + ch * 8);
     }
-    const bool kept = (keep && j < t) ? keep[j] != 0 : true;
+    if (blockIdx.x == 0 && tid >= NT - DH / 8) {  // ... and its V
+      const int ch = tid - (NT - DH / 8);
+      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + ch * 8) = *reinterpret_cast<const uint4*>(row + (a.H + a.Hkv + kvh) * DH + ch * 8);
+    }
+    __syncthreads();
+    // A operand: roped q of head `fr` (zero rows for fr >= G); new key in B-fragment layout
+    bf16x8 qf[KB], knf[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      knf[kb] = *reinterpret_cast<const bf16x8*>(qk + G * DH + kb * 32 + fq * 8);
+      if (fr < G) qf[kb] = *reinterpret_cast<const bf16x8*>(qk + fr * DH + kb * 32 + fq * 8);
+      else qf[kb] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+
+    for (int j0 = 0; j0 < nk; j0 += PASS) {
+      bf16x8 n0[KB], n1[KB];
+      const bool more = j0 + PASS < nk;
+      if (more) { load_tile(key_of(j0 + PASS, 0), n0); load_tile(key_of(j0 + PASS, 1), n1); }
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        const int j = key_of(j0, tile);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          bf16x8 kf = tile == 0 ? k0[kb] : k1[kb];
+          if (j == t) kf = knf[kb];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kb], kf, acc, 0, 0, 0);
+        }
+        // D[row = head = fq*4 + r][col = key fr]
+        if (j < nk) {
+          const bool kept = (keep && j < t) ? keep[j] != 0 : true;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int head = fq * 4 + r;
+            if (head < G) sc[head * scld + j] = kept ? rbf(rbf(acc[r]) * a.scale) : PCY_BF16_MIN;
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { k0[kb] = n0[kb]; k1[kb] = n1[kb]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (a.dbg == 2) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = f2bf(sc[0]); return; }
+  // ---- phase B ----
+  {
+    float mx[G], se[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float d = 0.f;
+      mx[g] = -INFINITY;
+      for (int j = tid; j < nk; j += NT) mx[g] = fmaxf(mx[g], sc[g * scld + j]);
+      mx[g] = wave_max(mx[g]);
+      if (lane == 0) wred[wave * G + g] = mx[g];
+    }
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d += q[g][e] * kf[e];
+    for (int g = 0; g < G; ++g) {
+      mx[g] = wred[g];
 #pragma unroll
-      for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-      if (sub == 0) sc[(size_t)g * scld + j] = kept ? rbf(rbf(d) * a.scale) : PCY_BF16_MIN;
+      for (int w = 1; w < NWV; ++w) mx[g] = fmaxf(mx[g], wred[w * G + g]);
+      se[g] = 0.f;
+      for (int j = tid; j < nk; j += NT) se[g] += expf(sc[g * scld + j] - mx[g]);
+      se[g] = wave_sum(se[g]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) if (lane == 0) wred[wave * G + g] = se[g];
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float l = wred[g];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) l += wred[w * G + g];
+      for (int j = tid; j < nk; j += NT) sc[g * scld + j] = rbf(expf(sc[g * scld + j] - mx[g]) / l);
     }
   }
-}
-
-template <int DH, int G>
-__global__ __launch_bounds__(256) void attn_dec_pv_kernel(PcyDecAttnArgs a) {
-  constexpr int DS = 16;          // output columns per block
-  constexpr int LPR = DS / 2;     // lanes per V row (2 columns = 4 B each)
-  constexpr int NG = 256 / LPR;   // key groups
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* p = reinterpret_cast<float*>(smem);          // [G][nk]
-  const int t = *a.pos_dev;
-  const int nk = t + 1;
-  float* red = p + (size_t)G * (a.Tmax + 1);           // [NG][G][DS]
-  float* wred = red + NG * G * DS;                     // [8]
-  const int c0 = blockIdx.x * DS, kvh = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x;
-  const int scld = a.Tmax + 1;
-  const float* sc = a.scratch + ((size_t)b * a.H + kvh * G) * scld;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float mx = -INFINITY;
-    for (int j = tid; j < nk; j += 256) { const float v = sc[(size_t)g * scld + j]; p[g * scld + j] = v; mx = fmaxf(mx, v); }
-    mx = block_max<256>(mx, wred);
-    float se = 0.f;
-    for (int j = tid; j < nk; j += 256) se += expf(p[g * scld + j] - mx);
-    se = block_sum<256>(se, wred);
-    for (int j = tid; j < nk; j += 256) p[g * scld + j] = rbf(expf(p[g * scld + j] - mx) / se);
-  }
   __syncthreads();
-  const int grp = tid / LPR, sub = tid % LPR;
-  const bf16_t* vc = a.vcache + ((size_t)b * a.Hkv + kvh) * a.Tmax * DH + c0 + sub * 2;
-  float acc[G][2];
+  if (a.dbg == 3) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = f2bf(sc[0]); return; }
+  // ---- phase C: lanes 0-31 / 32-63 of a wave = the two 16-byte halves of 32 V row slices ----
+  const int sub = lane >> 5, grp = wave * 32 + (lane & 31);
+  constexpr int NGV = NWV * 32;
+  constexpr int UV = 4;
+  float acc[G][8];
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = 0.f;
-  for (int j = grp; j < nk; j += NG) {
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(vc + (size_t)j * DH);
-    const float v0 = lo_bf(w), v1 = hi_bf(w);
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int g = 0; g < G; ++g) { const float pj = p[g * scld + j]; acc[g][0] += pj * v0; acc[g][1] += pj * v1; }
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  const bf16_t* vnew = row + (a.H + a.Hkv + kvh) * DH + c0 + sub * 8;
+  const bf16_t* vsl = vc + c0 + sub * 8;
+  for (int j0 = 0; j0 < nk; j0 += UV * NGV) {
+    uint4 vv[UV];
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int j = j0 + grp + u * NGV;
+      const bf16_t* src = (j < t) ? vsl + (size_t)j * DH : vnew;   // slot t comes straight from the projection
+      vv[u] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int u = 0; u < UV; ++u) {
+      const int j = j0 + grp + u * NGV;
+      if (j < nk) {
+        const float vf[8] = {lo_bf(vv[u].x), hi_bf(vv[u].x), lo_bf(vv[u].y), hi_bf(vv[u].y),
+                             lo_bf(vv[u].z), hi_bf(vv[u].z), lo_bf(vv[u].w), hi_bf(vv[u].w)};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float pj = sc[g * scld + j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[g][e] += pj * vf[e];
+        }
+      }
+    }
   }
+  // reduce over the 32 key groups of a wave half: 16-lane DPP row sums, then the two rows of the half
 #pragma unroll
-  for (int g = 0; g < G; ++g) { red[(grp * G + g) * DS + sub * 2] = acc[g][0]; red[(grp * G + g) * DS + sub * 2 + 1] = acc[g][1]; }
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = row16_sum(acc[g][e]);
+      v += __shfl_xor(v, 16, 64);
+      acc[g][e] = v;
+    }
+  if ((lane & 31) == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(wave * G + g) * DS + sub * 8 + e] = acc[g][e];
+  }
   __syncthreads();
   if (tid < G * DS) {
-    float s = 0.f;
-    for (int gg = 0; gg < NG; ++gg) s += red[gg * G * DS + tid];
+    float s = red[tid];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) s += red[w * G * DS + tid];
     const int g = tid / DS, c = tid % DS;
     a.o[(size_t)b * a.ldo + (kvh * G + g) * DH + c0 + c] = f2bf(s);
   }
@@ -258,16 +369,14 @@ __global__ __launch_bounds__(256) void attn_dec_pv_kernel(PcyDecAttnArgs a) {
 
 template <int DH, int G>
 void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
-  constexpr int NGB = 256 / 8;
-  const size_t smem = sizeof(float) * ((size_t)G * (a.Tmax + 1) + (size_t)NGB * G * 16 + 8);
+  const size_t smem = sizeof(float) * ((size_t)G * (a.Tmax + 1) + 8 * G * 16 + 8 * G + 8) + (size_t)(G + 1) * DH * 2 + 64;
   static size_t configured = 0;
   if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_pv_kernel<DH, G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_kernel<DH, G>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
-  hipLaunchKernelGGL((attn_dec_scores_kernel<DH, G>), dim3((a.Tmax + 63) / 64, a.Hkv, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL((attn_dec_pv_kernel<DH, G>), dim3(DH / 16, a.Hkv, a.B), dim3(256), smem, s, a);
+  hipLaunchKernelGGL((attn_dec_kernel<DH, G>), dim3(DH / 16, a.Hkv, a.B), dim3(512), smem, s, a);
 }
 
 template <int DH>

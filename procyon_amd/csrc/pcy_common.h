@@ -18,19 +18,19 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// fp32 -> bf16, round to nearest even; NaN stays NaN (c10::BFloat16 semantics)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even; NaN stays NaN (c10::BFloat16 semantics).  gfx950 has the conversion in
+// hardware (v_cvt_pk_bf16_f32): one instruction instead of the 6-op integer emulation.
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 // round-trip: the value a bf16 tensor would hold
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16pair));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -54,6 +54,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   float t = 0.f;
 #pragma unroll
   for (int i = 0; i < NT / 64; ++i) t += red[i];
+  return t;
+}
+// block-wide sum with a run-time wave count (<= 8)
+__device__ __forceinline__ float block_sum_rt(float v, float* red, int nwaves) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nwaves; ++i) t += red[i];
   return t;
 }
 template <int NT>

@@ -1,6 +1,7 @@
 // Host side of libpcy.so: context, workspace, layer loops, hipGraph capture, and the extern "C" ABI
 // declared in include/pcy.h.  No torch types; everything is raw device pointers on one HIP stream.
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 #include <vector>
@@ -289,6 +290,20 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
   t.H = H; t.Hkv = Hkv; t.dh = dh; t.causal = causal; t.scale = scale;
   pcy_launch_attn(c->stream, t);
   return check_launch("pcy_attention");
+}
+
+int pcy_attn_decode(pcy_ctx* c, void* qkv, int ld, void* kcache, void* vcache, void* o, int ldo, const int32_t* pos,
+                    const void* cos_t, const void* sin_t, const uint8_t* keep, int B, int H, int Hkv, int dh, int Tmax) {
+  if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_attn_decode: head_dim %d unsupported (32/64/128)", dh);
+  const int G = H / Hkv;
+  if (H % Hkv || !(G == 1 || G == 2 || G == 4 || G == 8)) return fail(1, "pcy_attn_decode: H/Hkv must be 1, 2, 4 or 8");
+  PcyDecAttnArgs t{};
+  t.qkv = (bf16_t*)qkv; t.ld = ld; t.kcache = (bf16_t*)kcache; t.vcache = (bf16_t*)vcache; t.o = (bf16_t*)o; t.ldo = ldo;
+  t.pos_dev = pos; t.cos_t = (const bf16_t*)cos_t; t.sin_t = (const bf16_t*)sin_t; t.keep = keep; t.ld_keep = Tmax;
+  t.scratch = nullptr; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = Tmax; t.scale = 1.0f / sqrtf((float)dh);
+  { const char* e = getenv("PCY_DBG_ATTN"); t.dbg = e ? atoi(e) : 0; }
+  pcy_launch_attn_decode(c->stream, t);
+  return check_launch("pcy_attn_decode");
 }
 
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {

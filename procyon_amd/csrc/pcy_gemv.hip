@@ -185,8 +185,199 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int K
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Streaming variant (whole x fits LDS): persistent waves, software-pipelined weight loads.
+//   * a "unit" = R output rows (R features = 2R weight rows for SwiGLU); wave w of the launch handles units
+//     w, w + n_waves, ...; the host sizes the grid so that every wave gets the same number of units
+//   * the first batch of weight loads is issued BEFORE the x-staging / RMSNorm prologue, and each later batch
+//     (16 x 16 B per lane) is issued before the previous one is consumed (two register sets, static indexing)
+template <int NB, int EPI, bool RMS, int R>
+__global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int units) {
+  constexpr int RW = (EPI == EPI_SWIGLU) ? 2 * R : R;
+  constexpr int UN = 16 / RW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                          // [NB][K]
+  float* red = reinterpret_cast<float*>(smem + (size_t)NB * a.K * 2);    // [waves per block]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.K;
+  const int nit = (K + 511) >> 9;
+  const int wpb = blockDim.x >> 6;
+  const int nw = gridDim.x * wpb;
+  const int nthr = blockDim.x;
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+
+  // element offset of weight row i of unit u (clamped into the matrix)
+  auto row_off = [&](int u, int i) -> size_t {
+    int r;
+    if (EPI == EPI_SWIGLU) {
+      const int f = u * R + (i % R);
+      const int fc = f < a.N ? f : a.N - 1;
+      r = (fc >> 4) * 32 + (fc & 15) + (i >= R ? 16 : 0);
+    } else {
+      r = u * R + i;
+      r = r < nrows ? r : nrows - 1;
+    }
+    return (size_t)r * K;
+  };
+  auto issue = [&](int u, int it0, uint4 (&wv)[UN][RW]) {
+#pragma unroll
+    for (int un = 0; un < UN; ++un) {
+      const int k = ((it0 + un) * 64 + lane) * 8;
+      const bool ok = k < K;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) wv[un][i] = ok ? ldg_nt(a.W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  float acc[RW][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
+  };
+  auto compute = [&](int it0, const uint4 (&wv)[UN][RW]) {
+#pragma unroll
+    for (int un = 0; un < UN; ++un) {
+      const int k = ((it0 + un) * 64 + lane) * 8;
+      if (k < K) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(xs + (size_t)b * K + k);
+#pragma unroll
+          for (int i = 0; i < RW; ++i) acc[i][b] = dot8(wv[un][i], xv, acc[i][b]);
+        }
+      }
+    }
+  };
+  auto finish = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[i][b] = wave_sum(acc[i][b]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int n = u * R + i;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float v;
+          if (EPI == EPI_SWIGLU) {
+            const float g = rbf(acc[i][b]), up = rbf(acc[i + R][b]);
+            v = rbf(silu_f(g)) * up;
+          } else {
+            v = rbf(acc[i][b] + (a.bias ? bf2f(a.bias[n]) : 0.f));
+            if (EPI == EPI_RESID) v = rbf(v + bf2f(a.resid[(size_t)b * a.ldy + n]));
+            if (EPI == EPI_GELU_ERF) v = rbf(gelu_erf_f(v));
+            if (EPI == EPI_GELU_ESM) v = gelu_esm_chain(v);
+          }
+          a.y[(size_t)b * a.ldy + n] = f2bf(v);
+        }
+      }
+    }
+    zero_acc();
+  };
+
+  uint4 wa[UN][RW], wb[UN][RW];
+  int u = blockIdx.x * wpb + wave;
+  int it0 = 0;
+  bool have = u < units;
+  if (have) issue(u, 0, wa);
+
+  // ---- prologue: x (optionally RMS-normalised) -> LDS, overlapping the first weight batch ----
+  float rstd[NB];
+  if (RMS) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float ss = 0.f;
+      for (int k = threadIdx.x * 8; k < K; k += nthr * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
+      }
+      ss = block_sum_rt(ss, red, wpb);
+      rstd[b] = rsqrtf(ss / (float)K + a.rms_eps);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    for (int k = threadIdx.x * 8; k < K; k += nthr * 8) {
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k);
+      if (RMS) {
+        const uint4 g = *reinterpret_cast<const uint4*>(a.rms_w + k);
+        const uint32_t xin[4] = {v.x, v.y, v.z, v.w}, gin[4] = {g.x, g.y, g.z, g.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x0 = lo_bf(xin[j]) * rstd[b], x1 = hi_bf(xin[j]) * rstd[b];
+          if (a.rms_cast == 0) { x0 = rbf(x0); x1 = rbf(x1); }
+          o[j] = pack_bf(lo_bf(gin[j]) * x0, hi_bf(gin[j]) * x1);
+        }
+        v = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      *reinterpret_cast<uint4*>(xs + (size_t)b * K + k) = v;
+    }
+  }
+  __syncthreads();
+  zero_acc();
+
+  // ---- steady state: issue batch i+1, consume batch i (roles of wa/wb alternate) ----
+#define PCY_GEMV_STEP(CUR, NXT)                                  \
+  {                                                              \
+    int nit0 = it0 + UN, nu = u;                                 \
+    if (nit0 >= nit) { nit0 = 0; nu = u + nw; }                  \
+    const bool nhave = nu < units;                               \
+    if (nhave) issue(nu, nit0, NXT);                             \
+    compute(it0, CUR);                                           \
+    if (nit0 == 0) finish(u);                                    \
+    u = nu; it0 = nit0; have = nhave;                            \
+  }
+  while (have) {
+    PCY_GEMV_STEP(wa, wb)
+    if (!have) break;
+    PCY_GEMV_STEP(wb, wa)
+  }
+#undef PCY_GEMV_STEP
+}
+
+constexpr int GEMV_MAX_WAVES = 2048;  // 256 CUs x 2 waves/SIMD x 4 SIMDs
+constexpr int GEMV_CUS = 256;
+
+// Grid shape: a multiple of the CU count with 4..8 waves per workgroup, chosen so that every CU streams the same
+// number of rows (a 448-block launch on 256 CUs leaves 3/4 of the chip idle for its second half).
+inline void pick_grid(int units, int& blocks, int& wpb) {
+  double best = 1e30;
+  blocks = GEMV_CUS; wpb = 4;
+  for (int bl = GEMV_CUS; bl <= 2 * GEMV_CUS; bl += GEMV_CUS)
+    for (int w = 4; w <= 8; ++w) {
+      const int waves = bl * w;
+      if (waves > GEMV_MAX_WAVES) continue;
+      const int per = (units + waves - 1) / waves;
+      const double cost = (double)per * waves / units + 1e-3 * (GEMV_MAX_WAVES - waves) / GEMV_MAX_WAVES;
+      if (cost < best) { best = cost; blocks = bl; wpb = w; }
+    }
+  if (units < GEMV_CUS * 4) { blocks = (units + 3) / 4; wpb = 4; }
+}
+
+template <int NB, int EPI, bool RMS, int R>
+void launch_stream(hipStream_t s, const PcyGemvArgs& a) {
+  const int units = (a.N + R - 1) / R;
+  int blocks, wpb;
+  pick_grid(units, blocks, wpb);
+  const size_t smem = (size_t)NB * a.K * 2 + 64;
+  hipLaunchKernelGGL((gemv_stream_kernel<NB, EPI, RMS, R>), dim3(blocks), dim3(wpb * 64), smem, s, a, units);
+}
+
 template <int NB, int EPI, bool RMS>
 void launch_nb(hipStream_t s, const PcyGemvArgs& a) {
+  if ((size_t)NB * a.K * 2 <= XS_BYTES_MAX) {
+    // few rows -> 2-row units so that the launch still spreads over ~2k waves
+    if ((a.N + 3) / 4 < GEMV_MAX_WAVES) launch_stream<NB, EPI, RMS, 2>(s, a);
+    else launch_stream<NB, EPI, RMS, 4>(s, a);
+    return;
+  }
   int KC = a.K;
   if ((size_t)NB * KC * 2 > XS_BYTES_MAX) KC = (XS_BYTES_MAX / (NB * 2)) & ~511;
   const size_t smem = (size_t)NB * KC * 2 + 64;

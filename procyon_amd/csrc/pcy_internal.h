@@ -63,7 +63,7 @@ struct PcyDecAttnArgs {
   const bf16_t* cos_t; const bf16_t* sin_t;  // [max_pos, dh]
   const uint8_t* keep; int ld_keep;  // optional [B,Tmax] key-keep mask ("clean" mode) or null (reference quirk Q1)
   float* scratch;                 // [B*H*Tmax] fp32 probabilities workspace
-  int B, H, Hkv, dh, Tmax; float scale;
+  int B, H, Hkv, dh, Tmax; float scale; int dbg;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 

@@ -125,6 +125,14 @@ class Context:
                                        int(causal), scale), "pcy_attention")
         return o
 
+    def attn_decode(self, qkv, kcache, vcache, pos, cos_t, sin_t, H, Hkv, dh, keep=None, out=None):
+        """qkv [B,(H+2Hkv)*dh]; kcache/vcache [B,Hkv,Tmax,dh]; pos int32 device scalar."""
+        B, Tmax = kcache.shape[0], kcache.shape[2]
+        o = torch.empty(B, H * dh, dtype=BF16, device=qkv.device) if out is None else out
+        L.check(self.lib.pcy_attn_decode(self.h, _p(qkv), qkv.shape[1], _p(kcache), _p(vcache), _p(o), H * dh, _p(pos), _p(cos_t),
+                                         _p(sin_t), _p(keep), B, H, Hkv, dh, Tmax), "pcy_attn_decode")
+        return o
+
     def pool(self, hidden, seg, rng, nprot, mode):
         _chk_bf16(hidden)
         d = hidden.shape[-1]

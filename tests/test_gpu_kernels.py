@@ -227,3 +227,29 @@ def test_rope(ctx, mode):
     ref = ref[0].transpose(0, 1).reshape(n, nh * dh)
     out = ctx.rope_(x.cuda().clone(), 0, nh, dh, pos.cuda(), cos.cuda(), sin.cuda(), mode, 0.0 if mode == 0 else dh ** -0.5).cpu()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("H,Hkv,dh,t", [(32, 8, 128, 600), (8, 2, 64, 37), (4, 4, 32, 5), (8, 1, 128, 0)])
+def test_attn_decode(ctx, H, Hkv, dh, t):
+    """decode attention (rope + append + exact softmax) vs the oracle's eager formulas (llama_ref.layer_forward)."""
+    from oracle import llama_ref as LR
+    from procyon_amd.engine import rope_tables
+    B, Tmax = 2, t + 3
+    qkv = rnd(B, (H + 2 * Hkv) * dh, seed=1)
+    kc, vc = rnd(B, Hkv, Tmax, dh, seed=2), rnd(B, Hkv, Tmax, dh, seed=3)
+    cos, sin = rope_tables(dh, 10000.0, Tmax + 1, "cpu")
+    q = qkv[:, :H * dh].view(B, 1, H, dh).transpose(1, 2)
+    k = qkv[:, H * dh:(H + Hkv) * dh].view(B, 1, Hkv, dh).transpose(1, 2)
+    v = qkv[:, (H + Hkv) * dh:].view(B, 1, Hkv, dh).transpose(1, 2)
+    qr, kr = LR.apply_rope(q, k, cos[t][None, None].expand(B, 1, dh), sin[t][None, None].expand(B, 1, dh))
+    K = torch.cat([kc[:, :, :t], kr], 2).repeat_interleave(H // Hkv, 1)
+    V = torch.cat([vc[:, :, :t], v], 2).repeat_interleave(H // Hkv, 1)
+    s = torch.matmul(qr, K.transpose(2, 3)) * dh ** -0.5
+    p = F.softmax(s, dim=-1, dtype=torch.float32).to(BF)
+    ref = torch.matmul(p, V).transpose(1, 2).reshape(B, H * dh)
+    kcd, vcd = kc.cuda(), vc.cuda()
+    out = ctx.attn_decode(qkv.cuda(), kcd, vcd, torch.tensor([t], dtype=torch.int32).cuda(), cos.cuda(), sin.cuda(), H, Hkv, dh).cpu()
+    assert rel_err(out, ref) < 1e-3
+    assert_bf16_close(out, ref, "attn decode", max_frac=0.03, inter=torch.full_like(ref, 0.05))
+    assert torch.equal(kcd.cpu()[:, :, t], kr[:, :, 0]) and torch.equal(vcd.cpu()[:, :, t], v[:, :, 0])
+    assert torch.equal(kcd.cpu()[:, :, :t], kc[:, :, :t])
