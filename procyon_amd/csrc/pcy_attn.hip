@@ -10,41 +10,44 @@
 //     probabilities are exactly the lane's A-operand fragment of the P.V MFMA (no LDS, no shuffles),
 //     and the matching B operand is one 16-byte load from a pre-transposed V (Vt[d][key]).
 // (2) attn_dec_scores / attn_dec_pv: one new token per row against the KV cache, RoPE + cache append fused.
+#include <stdlib.h>
 #include "pcy_internal.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+// QT = 16-row query tiles per wave: the K / Vt fragments of a 32-key block are loaded once and reused by all QT tiles
+// (QT x fewer L2 requests per MFMA); the next block's fragments are prefetched while the current one is consumed.
+template <int DH, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
   constexpr int KB = DH / 32;   // k-blocks of the QK^T contraction
   constexpr int NT = DH / 16;   // 16-wide output tiles of P.V
+  constexpr int QROWS = QT * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int sq = blockIdx.z, h = blockIdx.y;
   const int t0 = a.cu[sq], len = a.cu[sq + 1] - t0;
-  const int qr0 = blockIdx.x * 64 + wave * 16;
+  const int qr0 = (blockIdx.x * 4 + wave) * QROWS;
   if (qr0 >= len) return;
   const int G = a.H / a.Hkv;
   const int kvh = h / G;
   const int vt0 = a.vt_cu[sq];
 
-  // Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][kb*32 + fq*8 .. +8]
-  const int qrow = (qr0 + fr) < len ? (qr0 + fr) : len - 1;
-  const bf16_t* qp = a.q + (size_t)(t0 + qrow) * a.ldq + a.qcol0 + h * DH + fq * 8;
-  bf16x8 qf[KB];
+  // Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][kb*32 + fq*8 .. +8] of each q tile
+  bf16x8 qf[QT][KB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 32);
-
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = (qr0 + qt * 16 + fr) < len ? (qr0 + qt * 16 + fr) : len - 1;
+    const bf16_t* qp = a.q + (size_t)(t0 + qrow) * a.ldq + a.qcol0 + h * DH + fq * 8;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) qf[qt][kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 32);
+  }
   const bf16_t* kbase = a.k + (size_t)t0 * a.ldk + a.kcol0 + kvh * DH + fq * 8;
   const uint8_t* keep = a.keep ? a.keep + t0 : nullptr;
-  const int qpos = qr0 + fr;
   // A-operand row fr of tile a / tile b maps to key (fr/4)*8 + (fr%4) (+4 for tile b) of the block
   const int krow_a = (fr >> 2) * 8 + (fr & 3);
 
-  // scores of one 32-key block for this lane: keys kb0 + fq*8 + 0..7 of query fr
-  auto scores = [&](int kb0, float (&s)[8]) {
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  auto load_k = [&](int kb0, bf16x8 (&fa)[KB], bf16x8 (&fb)[KB]) {
     int ka = kb0 + krow_a, kbk = ka + 4;
     ka = ka < len ? ka : len - 1;
     kbk = kbk < len ? kbk : len - 1;
@@ -52,78 +55,140 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
     const bf16_t* pb = kbase + (size_t)kbk * a.ldk;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + kb * 32);
-      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pb + kb * 32);
-      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, qf[kb], sa, 0, 0, 0);
-      sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, qf[kb], sb, 0, 0, 0);
+      fa[kb] = *reinterpret_cast<const bf16x8*>(pa + kb * 32);
+      fb[kb] = *reinterpret_cast<const bf16x8*>(pb + kb * 32);
     }
+  };
+  // scores of one 32-key block for q tile qt, in the log2 domain (z = s * log2(e), so that exp(s - m) = exp2(z - mz) is
+  // ONE v_exp_f32): this lane gets keys kb0 + fq*8 + 0..7 of query qr0 + qt*16 + fr.  `interior` blocks (fully inside
+  // the sequence, fully below the causal diagonal, no key mask) skip all masking arithmetic.
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float MASKZ = -3.0e38f;   // finfo.min mask in the log2 domain, kept finite (min * log2e would overflow)
+  auto scores = [&](int kb0, int qt, const bf16x8 (&fa)[KB], const bf16x8 (&fb)[KB], float (&s)[8]) {
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int j = kb0 + fq * 8 + r;
-      float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
-      if (a.scale != 1.0f) v = rbf(v * a.scale);
-      bool allowed = !(a.causal && j > qpos);
-      if (keep && j < len) allowed = allowed && (keep[j] != 0);
-      v = allowed ? v : PCY_BF16_MIN;
-      s[r] = j < len ? v : -INFINITY;
+    for (int kb = 0; kb < KB; ++kb) {
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb], qf[qt][kb], sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kb], qf[qt][kb], sb, 0, 0, 0);
+    }
+    const int qlo = qr0 + qt * 16;
+    const bool interior = (kb0 + 32 <= len) && !keep && !(a.causal && kb0 + 31 > qlo);
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
+        if (a.scale != 1.0f) v = rbf(v * a.scale);
+        s[r] = v * LOG2E;
+      }
+    } else {
+      const int qpos = qlo + fr;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j = kb0 + fq * 8 + r;
+        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
+        if (a.scale != 1.0f) v = rbf(v * a.scale);
+        bool allowed = !(a.causal && j > qpos);
+        if (keep && j < len) allowed = allowed && (keep[j] != 0);
+        s[r] = j < len ? (allowed ? v * LOG2E : MASKZ) : -INFINITY;
+      }
     }
   };
 
-  int kend = a.causal ? ((qr0 + 16) < len ? (qr0 + 16) : len) : len;
-  float m, l;
+  int kend = a.causal ? ((qr0 + QROWS) < len ? (qr0 + QROWS) : len) : len;
+  float m[QT], l[QT];
   for (int attempt = 0; attempt < 2; ++attempt) {
     // pass 1: online row max / sum of exp over keys [0, kend)
-    m = -INFINITY; l = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
+    bf16x8 ka[KB], kb_[KB];
+    load_k(0, ka, kb_);
     for (int kb0 = 0; kb0 < kend; kb0 += 32) {
-      float s[8];
-      scores(kb0, s);
-      float bm = s[0];
+      bf16x8 na[KB], nb[KB];
+      const bool more = kb0 + 32 < kend;
+      if (more) load_k(kb0 + 32, na, nb);
 #pragma unroll
-      for (int r = 1; r < 8; ++r) bm = fmaxf(bm, s[r]);
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-      const float mn = fmaxf(m, bm);
-      float bs = 0.f;
+      for (int qt = 0; qt < QT; ++qt) {
+        float s[8];
+        scores(kb0, qt, ka, kb_, s);
+        float bm = s[0];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) bs += expf(s[r] - mn);
-      bs += __shfl_xor(bs, 16, 64);
-      bs += __shfl_xor(bs, 32, 64);
-      l = l * expf(m - mn) + bs;
-      m = mn;
+        for (int r = 1; r < 8; ++r) bm = fmaxf(bm, s[r]);
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m[qt], bm);
+        float bs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bs += __builtin_amdgcn_exp2f(s[r] - mn);
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        l[qt] = l[qt] * __builtin_amdgcn_exp2f(m[qt] - mn) + bs;
+        m[qt] = mn;
+      }
+      if (more) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
+      }
     }
     // a row whose allowed-key set is empty (a left-pad query): the reference's additive finfo.min mask
     // makes its softmax uniform over ALL keys of the sequence, causal or not -> redo over the full range
-    const bool empty_row = (m == PCY_BF16_MIN) && (qr0 + fr) < len;
+    bool empty_row = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) empty_row = empty_row || ((m[qt] == MASKZ) && (qr0 + qt * 16 + fr) < len);
     if (attempt == 0 && kend < len && __any(empty_row)) { kend = len; continue; }
     break;
   }
 
-  // pass 2: P = bf16(exp(S - m) / l), O += P.V
-  f32x4 oacc[NT];
+  // pass 2: P = bf16(exp(S - m) / l), O += P.V   (one reciprocal per row; a product instead of a division per score)
+  float rl[QT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) oacc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < QT; ++qt) rl[qt] = 1.0f / l[qt];
+  f32x4 oacc[QT][NT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) oacc[qt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bf16_t* vbase = a.vt + ((size_t)kvh * DH + fr) * a.vt_total + vt0 + fq * 8;
-  for (int kb0 = 0; kb0 < kend; kb0 += 32) {
-    float s[8];
-    scores(kb0, s);
-    bf16x8 pf;
+  auto load_v = [&](int kb0, bf16x8 (&vf)[NT]) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) pf[r] = (short)f2bf(expf(s[r] - m) / l);
+    for (int n = 0; n < NT; ++n) vf[n] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)n * 16 * a.vt_total + kb0);
+  };
+  {
+    bf16x8 ka[KB], kb_[KB], vf[NT];
+    load_k(0, ka, kb_);
+    load_v(0, vf);
+    for (int kb0 = 0; kb0 < kend; kb0 += 32) {
+      bf16x8 na[KB], nb[KB], nv[NT];
+      const bool more = kb0 + 32 < kend;
+      if (more) { load_k(kb0 + 32, na, nb); load_v(kb0 + 32, nv); }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vbase + (size_t)n * 16 * a.vt_total + kb0);
-      oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[n], 0, 0, 0);
+      for (int qt = 0; qt < QT; ++qt) {
+        float s[8];
+        scores(kb0, qt, ka, kb_, s);
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pf[r] = (short)f2bf(__builtin_amdgcn_exp2f(s[r] - m[qt]) * rl[qt]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) oacc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[n], oacc[qt][n], 0, 0, 0);
+      }
+      if (more) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) vf[n] = nv[n];
+      }
     }
   }
   // O[q = fq*4 + r][d = n*16 + fr]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qq = qr0 + fq * 4 + r;
-    if (qq >= len) continue;
-    bf16_t* op = a.o + (size_t)(t0 + qq) * a.ldo + h * DH + fr;
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) op[n * 16] = f2bf(oacc[n][r]);
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qr0 + qt * 16 + fq * 4 + r;
+      if (qq >= len) continue;
+      bf16_t* op = a.o + (size_t)(t0 + qq) * a.ldo + h * DH + fr;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) op[n * 16] = f2bf(oacc[qt][n][r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,10 +458,11 @@ void launch_dec_g(hipStream_t s, const PcyDecAttnArgs& a) {
 
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
-  const dim3 grid((a.max_len + 63) / 64, a.H, a.nseq);
-  if (a.dh == 128) hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, a);
-  else if (a.dh == 64) hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, a);
+  // q rows per block = 4 waves x QT x 16.  QT is kept at 2 (dh <= 64) / 1 (dh = 128): the kernel is VALU-bound (softmax),
+  // so larger QT buys nothing, and the QT=4 build mis-scored ~0.3% of rows on gfx950/ROCm 7.2 (tools/diag_attn_scale.py).
+  if (a.dh == 128) hipLaunchKernelGGL((attn_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
+  else if (a.dh == 64) hipLaunchKernelGGL((attn_kernel<64, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_kernel<32, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
 }
 
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a) {

@@ -11,25 +11,32 @@
 //   * fused epilogues reproduce the reference's bf16 rounding points (bias, residual add, erf-GELU,
 //     ESM op-by-op GELU, SwiGLU on 16-row interleaved gate/up weights)
 //   * any M and N (row clamping + predicated stores), K % 64 == 0
+#include <stdlib.h>
 #include "pcy_internal.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int GEMM_THREADS = 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
-// stage a [128 rows][64 k] bf16 tile: 16 wave-instructions of 1 KiB; wave w issues 4 of them.
-// LDS byte (row, chunk') = row*128 + chunk'*16 holds global chunk = chunk' ^ (row & 7).
+// stage a [128 rows][BK k] bf16 tile with 1-KiB wave-instructions (LDS image lane-linear).  A row holds CPR = BK/8
+// 16-byte chunks; LDS chunk position c' of row r holds global chunk c' ^ swz(r), the same XOR is applied on the read side:
+//   BK=64 (128-B rows): swz = r & 7        BK=32 (64-B rows): swz = (r >> 2) & 3      -> conflict-free ds_read_b128
+template <int BK>
+__device__ __forceinline__ int swz(int r) { return BK == 64 ? (r & 7) : ((r >> 2) & 3); }
+
+template <int BK>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = 128 / RPI;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int inst = wave * 4 + i;
-    const int r = inst * 8 + (lane >> 3);
-    const int cp = lane & 7;
-    const int c = cp ^ (r & 7);
+  for (int i = 0; i < NINST / 4; ++i) {
+    const int inst = wave * (NINST / 4) + i;
+    const int r = inst * RPI + lane / CPR;
+    const int cp = lane % CPR;
+    const int c = cp ^ swz<BK>(r);
     int gr = row0 + r;
     gr = gr < nrows_valid ? gr : nrows_valid - 1;
     const bf16_t* src = g + (size_t)gr * ld + k0 + c * 8;
@@ -37,13 +44,14 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
   }
 }
 
+template <int BK>
 __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+  return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK>(row)) << 4));
 }
 
-template <int EPI>
+template <int EPI, int BK>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128*64] bf16 = 64 KiB
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128*BK] bf16: 64 KiB (BK=64) / 32 KiB (BK=32)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
@@ -64,8 +72,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
   const int nk = a.K / BK;
   constexpr int TILE_B = BM * BK * 2;  // 16 KiB; buffer b: A at b*2*TILE_B, W right after it
 
-  stage_tile(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile(a.W, a.K, n0, a.N, 0, smem + TILE_B, wave, lane);
+  stage_tile<BK>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK>(a.W, a.K, n0, a.N, 0, smem + TILE_B, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -74,16 +82,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     const char* Wcur = Acur + TILE_B;
     if (kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
-      stage_tile(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
+      stage_tile<BK>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < BK / 32; ++kb) {
       bf16x8 xf[4], wf[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = lds_frag(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
+      for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = lds_frag(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
+      for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -159,7 +167,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_kernel<EPI>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  static const int bk = [] { const char* e = getenv("PCY_GEMM_BK"); return e ? atoi(e) : 64; }();
+  if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
 }
 
 }  // namespace

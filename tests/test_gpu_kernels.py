@@ -193,7 +193,8 @@ def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
     out = ctx.attention(q.cuda(), k.cuda(), v.cuda(), lens, H, Hkv, dh, causal, scale).cpu()
     assert rel_err(out, ref) < 1e-3
     # a 1-ulp flip of one bf16 probability p_j moves O by 2^-8 * p_j * |v_j| (absolute): allow that on top of O's own ulp
-    assert_bf16_close(out, ref, "attention", max_frac=0.03, inter=torch.full_like(ref, 0.03))
+    # (causal rows near the start have few keys, i.e. p_j up to 1)
+    assert_bf16_close(out, ref, "attention", max_frac=0.03, inter=torch.full_like(ref, 0.25 if causal else 0.03))
 
 
 def test_attention_left_pad_rows_uniform(ctx):
