@@ -380,7 +380,33 @@ def g9(ns):
     save("g9_e2e_tiny", **out)
 
 
+# --------------------------------------------------------------------------- g10 host text preparation
+def g10(ns):
+    """Reference `_prepare_text_inputs_and_tokenize` (model_unified.py:1177-1293) driven by the build's synthetic
+    tokenizer: [EXT] splicing, per-description truncation budget, drug tail, EOS/pad, left padding."""
+    import random
+    from procyon_amd.tokenizer import SyntheticTokenizer
+    extract("procyon/model/model_unified.py", {"UnifiedProCyon._prepare_text_inputs_and_tokenize"}, ns)
+    ns["random"] = random
+    tok = SyntheticTokenizer()
+    out = {}
+    instr = ["Definition: w1 w2 [EXT] then <|protein|> and [EXT] finally [ANSWER]",
+             "Short one <|protein|> [ANSWER] [EXT]",
+             "No description here <|protein|> [ANSWER]"]
+    texts = [["alpha beta gamma delta " * 30, "Drug: <|drug|> tail words " + "filler " * 10], ["only one description " * 5], []]
+    for max_text_len, tag in ((64, "short"), (2048, "long")):
+        for no_pad, left_pad, nm in ((False, False, "pad"), (True, True, "leftpad")):
+            self = types.SimpleNamespace(tokenizer=tok, config=types.SimpleNamespace(max_text_len=max_text_len),
+                                         drug_idx=tok.convert_tokens_to_ids("<|drug|>"), ext_idx=tok.convert_tokens_to_ids("[EXT]"),
+                                         training=False, context_crop_sampling=False)
+            ids, mask = ns["_prepare_text_inputs_and_tokenize"](self, list(instr), [list(t) for t in texts], crop_off=True,
+                                                                retrieval=False, no_pad=no_pad, left_pad=left_pad)
+            out[f"ids_{tag}_{nm}"] = ids
+            out[f"mask_{tag}_{nm}"] = mask
+    save("g10_text_prep", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     ns = ref_ns()
-    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns)
+    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns)

@@ -1,0 +1,71 @@
+"""CPU: host-side logic of the mirror (no GPU): text preparation vs the reference's own function (golden g10),
+multi_replace_tokens / mask_before / left_pad_tensors vs goldens, the splitter mirror vs golden g1, packing."""
+import torch
+
+from procyon_amd.engine import EsmEngine, batched_split_long_seq
+from procyon_amd.model.model_unified import ProCyonConfig, UnifiedProCyon, mask_before, multi_replace_tokens
+from procyon_amd.model.model_utils import left_pad_tensors
+from procyon_amd.tokenizer import SyntheticTokenizer
+
+
+def _host_only_model(max_text_len):
+    m = object.__new__(UnifiedProCyon)
+    m.tokenizer = SyntheticTokenizer()
+    m.config = ProCyonConfig(max_text_len=max_text_len)
+    m.drug_idx = m.tokenizer.convert_tokens_to_ids("<|drug|>")
+    m.ext_idx = m.tokenizer.convert_tokens_to_ids("[EXT]")
+    return m
+
+
+def test_text_prep_matches_reference(golden):
+    g = golden("g10_text_prep")
+    instr = ["Definition: w1 w2 [EXT] then <|protein|> and [EXT] finally [ANSWER]",
+             "Short one <|protein|> [ANSWER] [EXT]",
+             "No description here <|protein|> [ANSWER]"]
+    texts = [["alpha beta gamma delta " * 30, "Drug: <|drug|> tail words " + "filler " * 10], ["only one description " * 5], []]
+    for max_text_len, tag in ((64, "short"), (2048, "long")):
+        m = _host_only_model(max_text_len)
+        for no_pad, left_pad, nm in ((False, False, "pad"), (True, True, "leftpad")):
+            ids, mask = m._prepare_text_inputs_and_tokenize(list(instr), [list(t) for t in texts], crop_off=True,
+                                                            no_pad=no_pad, left_pad=left_pad)
+            assert torch.equal(ids.long(), g[f"ids_{tag}_{nm}"].long()), (tag, nm)
+            assert torch.equal(mask.float(), g[f"mask_{tag}_{nm}"].float()), (tag, nm)
+
+
+def test_special_token_ids_llama3():
+    t = SyntheticTokenizer()
+    assert [t.convert_tokens_to_ids(x) for x in ("[CLS]", "[PAD]", "<|protein|>", "[PROT]", "[ANSWER]", "<|struct|>", "<|drug|>", "[EXT]")] == \
+        list(range(128256, 128264))
+    assert len(t) - 1 == 128263
+
+
+def test_small_helpers(golden):
+    g4, g8 = golden("g4_pad_splice"), golden("g8_qa")
+    bt, am = left_pad_tensors([torch.arange(5), torch.arange(2) + 10, torch.arange(7) + 20], pad_value=99)
+    assert torch.equal(bt, g4["lp_tok"]) and torch.equal(am, g4["lp_mask"])
+    a, b = [5, 9, 1, 9, 2, 9, 3], [[70, 71], [80], [90, 91, 92]]
+    assert multi_replace_tokens(list(a), b, 9, eval=False) == g4["mr_train"].tolist()
+    assert multi_replace_tokens(list(a), b, 9, eval=True) == g4["mr_eval"].tolist()
+    assert torch.equal(mask_before(g8["toks"].clone(), 50, before_last_answer=True), g8["mask_before_last"])
+    try:
+        multi_replace_tokens([1, 9], [], 9)
+        assert False
+    except ValueError:
+        pass
+
+
+def test_splitter_mirror_matches_reference(golden):
+    g = golden("g1_split")
+    for n in range(6):
+        rows, keys = batched_split_long_seq(g[f"in{n}"])
+        assert torch.equal(rows, g[f"rows{n}"]) and torch.equal(keys, g[f"keys{n}"])
+
+
+def test_pack_varlen():
+    rows = torch.tensor([[0, 5, 6, 2, 1, 1], [0, 7, 2, 1, 1, 1], [0, 4, 5, 6, 7, 2]])
+    pk = EsmEngine.pack(rows, mask_pads=True)
+    assert pk["tokens"].tolist() == [0, 5, 6, 2, 0, 7, 2, 0, 4, 5, 6, 7, 2]
+    assert pk["cu"].tolist() == [0, 4, 7, 13] and pk["vt_cu"].tolist() == [0, 32, 64, 96]
+    assert pk["pos"].tolist() == [0, 1, 2, 3, 0, 1, 2, 0, 1, 2, 3, 4, 5]
+    pk = EsmEngine.pack(rows, mask_pads=False)   # HF-"official" call: pads stay as tokens (Q12)
+    assert pk["ntok"] == 18 and pk["real"].tolist() == [4, 3, 6]
