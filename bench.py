@@ -177,9 +177,15 @@ def main():
             ctx.gemv(wl[i], x, epi=4, rms_w=ln[i], out=outb)
     k_ms = ctx.timer_stop() / (reps * len(wl))
     k_bytes = 2 * cfg.ffn * cfg.d * 2
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<1,EPI_SWIGLU,RMS> (Llama gate/up, 32 launches/token)",
+    traffic = None
+    try:  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with tools/bench_gemv.py)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")))["kernels"]
+        traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "<1, 4, true" in k][0] if a.geometry == "full" else None
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "gemv_stream_kernel<1,EPI_SWIGLU,RMS,4> (Llama gate/up, 32 launches/token)",
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": None,
+                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic,
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
 
     # ---- retrieval leg (config 3 shape): DP-sharded forward_sequences + ONE all-gather --------------
