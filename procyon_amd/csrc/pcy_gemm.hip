@@ -49,6 +49,120 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int ch
   return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK>(row)) << 4));
 }
 
+// Tile rasterisation for L2 reuse.  Each XCD (private 4 MiB L2) receives a contiguous run of the logical tile order
+// (see the remap in the kernels); that order walks the N dimension in GROUPS of `gn` column tiles: for each group,
+// all row tiles, inner loop over the group's columns.  The group's W panels (gn x 128 x K x 2 B <= ~2.5 MiB) stay
+// L2-resident for the whole sweep over M, and every A panel is reused gn times back to back, instead of re-streaming
+// all of W from the fabric once per row tile (PMC: 2.3 GB fetched for the 94 MB ESM qkv GEMM before this).
+__device__ __forceinline__ void tile_origin(const PcyGemmArgs& a, int tile, int& m0, int& n0) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const int gn = a.gn;
+  const int per_group = tiles_m * gn;
+  const int g = tile / per_group;
+  const int gw = (g + 1) * gn <= tiles_n ? gn : tiles_n - g * gn;   // width of this (possibly last, narrower) group
+  const int r = tile - g * per_group;
+  m0 = (r / gw) * BM;
+  n0 = (g * gn + r % gw) * BN;
+}
+
+// epilogue shared by the GEMM variants: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile.
+// All global reads of the epilogue (bias: 16 values per lane, residual: 16 x 8 B per lane) are issued up front as
+// independent vector loads -- element-wise loads inside the rounding chain serialised ~64 L2 round trips per tile
+// (20 us of the 37 us a K=1280 tile took).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fr, int fq) {
+  const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
+  if (EPI == EPI_SWIGLU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {  // tile i = gate, i+1 = up of the same 16 features
+        const int nrow = n0 + wn * 64 + i * 16;         // packed row of the gate tile
+        const int f = (nrow >> 5) * 16 + fq * 4;        // output feature
+        if (nrow + 16 + fq * 4 >= a.N) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = rbf(acc[i][j][r]), u = rbf(acc[i + 1][j][r]);
+          o[r] = rbf(silu_f(g)) * u;
+        }
+        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+      }
+    }
+    return;
+  }
+  // bias of this lane's 4 x 4 output features
+  float bias[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    if (a.bias && vec_ok && n < a.N) {
+      const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
+      bias[i][0] = lo_bf(bb.x); bias[i][1] = hi_bf(bb.x); bias[i][2] = lo_bf(bb.y); bias[i][3] = hi_bf(bb.y);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = (n + r) < a.N ? (n + r) : a.N - 1;
+        bias[i][r] = a.bias ? bf2f(a.bias[nn]) : 0.f;
+      }
+    }
+  }
+  uint2 res[4][4];
+  if (EPI == EPI_RESID && vec_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      const int mc = m < a.M ? m : a.M - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        const int nc = n < a.N ? n : 0;
+        res[j][i] = *reinterpret_cast<const uint2*>(a.resid + (size_t)mc * a.ldr + nc);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + fq * 4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][r] + bias[i][r]);
+      if (EPI == EPI_RESID) {
+        if (vec_ok) {
+          v[0] = rbf(v[0] + lo_bf(res[j][i].x)); v[1] = rbf(v[1] + hi_bf(res[j][i].x));
+          v[2] = rbf(v[2] + lo_bf(res[j][i].y)); v[3] = rbf(v[3] + hi_bf(res[j][i].y));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)m * a.ldr + n + r]));
+        }
+      }
+      if (EPI == EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
+      }
+      if (EPI == EPI_GELU_ESM) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_esm_chain(v[r]);
+      }
+      if (vec_ok) {
+        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) a.C[(size_t)m * a.ldc + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
 template <int EPI, int BK>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128*BK] bf16: 64 KiB (BK=64) / 32 KiB (BK=32)
@@ -60,8 +174,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
   const int bid = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  int m0, n0;
+  tile_origin(a, tile, m0, n0);
 
   f32x4 acc[4][4];  // [n-sub][m-sub]
 #pragma unroll
@@ -101,81 +215,85 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     __syncthreads();
   }
 
-  // epilogue: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile
-  const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
+  gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: same 128x128 tile, BK = 32, THREE LDS stages (48 KiB -> 3 workgroups per CU) and counted waits: the loads of
+// stage kt+1 stay in flight across the barrier that publishes stage kt (inline `s_waitcnt vmcnt(4)` + raw `s_barrier`;
+// `__syncthreads()` would drain them).  One barrier per K-step; stage kt+2 is issued right after it, so the buffer
+// it overwrites (read in step kt-1) is provably free.
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_v2(PcyGemmArgs a) {
+  constexpr int BK = 32, NS = 3;
+  constexpr int TILE_B = BM * BK * 2;                      // 8 KiB per operand per stage
+  __shared__ __attribute__((aligned(1024))) char smem[NS * 2 * TILE_B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  int m0, n0;
+  tile_origin(a, tile, m0, n0);
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + fr;
-    if (m >= a.M) continue;
-    if (EPI == EPI_SWIGLU) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; i += 2) {  // tile i = gate, i+1 = up of the same 16 features
-        const int nrow = n0 + wn * 64 + i * 16;         // packed row of the gate tile
-        const int f = (nrow >> 5) * 16 + fq * 4;        // output feature
-        if (nrow + 16 + fq * 4 >= a.N) continue;
-        bf16_t o[4];
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+  const int fr = lane & 15, fq = lane >> 4;
+  auto stage = [&](int kt) {
+    char* buf = smem + (kt % NS) * 2 * TILE_B;
+    stage_tile<BK>(a.A, a.lda, m0, a.M, kt * BK, buf, wave, lane);            // 2 x 1-KiB DMA per wave
+    stage_tile<BK>(a.W, a.K, n0, a.N, kt * BK, buf + TILE_B, wave, lane);     // 2 more
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) stage(kt + 2);
+    const char* Acur = smem + (kt % NS) * 2 * TILE_B;
+    const char* Wcur = Acur + TILE_B;
+    bf16x8 xf[4], wf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = rbf(acc[i][j][r]), u = rbf(acc[i + 1][j][r]);
-          o[r] = f2bf(rbf(silu_f(g)) * u);
-        }
-        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) =
-            make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
-      }
-    } else {
+    for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, fq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fq * 4;
-        if (n >= a.N) continue;
-        float v[4];
+    for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, fq);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nn = (n + r) < a.N ? (n + r) : a.N - 1;
-          v[r] = rbf(acc[i][j][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
-        }
-        if (EPI == EPI_RESID) {
-          if (vec_ok) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
-            v[0] = rbf(v[0] + lo_bf(rr.x)); v[1] = rbf(v[1] + hi_bf(rr.x));
-            v[2] = rbf(v[2] + lo_bf(rr.y)); v[3] = rbf(v[3] + hi_bf(rr.y));
-          } else {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < a.N) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)m * a.ldr + n + r]));
-          }
-        }
-        if (EPI == EPI_GELU_ERF) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
-        }
-        if (EPI == EPI_GELU_ESM) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_esm_chain(v[r]);
-        }
-        if (vec_ok) {
-          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) a.C[(size_t)m * a.ldc + n + r] = f2bf(v[r]);
-        }
-      }
-    }
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   }
+  gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int bk = [] { const char* e = getenv("PCY_GEMM_BK"); return e ? atoi(e) : 64; }();
-  if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  static const int ver = [] { const char* e = getenv("PCY_GEMM_V"); return e ? atoi(e) : 1; }();
+  if (ver == 2) hipLaunchKernelGGL((gemm_kernel_v2<EPI>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  else if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
 }
 
 }  // namespace
 
-void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a) {
-  if (a.M <= 0 || a.N <= 0) return;
+void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
+  if (a0.M <= 0 || a0.N <= 0) return;
+  PcyGemmArgs a = a0;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const long panel = (long)BN * a.K * 2;
+  long gn = (5L << 19) / panel;           // 2.5 MiB of W panels per group
+  if (gn < 4) gn = 4;                      // long-K panels: a narrower group loses more A reuse than it saves (measured)
+  static const int gn_env = [] { const char* e = getenv("PCY_GEMM_GN"); return e ? atoi(e) : 0; }();
+  if (gn_env > 0) gn = gn_env;
+  a.gn = (int)(gn < 1 ? 1 : (gn > tiles_n ? tiles_n : gn));
   switch (a.epi) {
     case EPI_STORE: launch<EPI_STORE>(s, a); break;
     case EPI_RESID: launch<EPI_RESID>(s, a); break;

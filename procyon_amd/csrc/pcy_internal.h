@@ -22,6 +22,7 @@ struct PcyGemmArgs {
   const bf16_t* bias;   // [N] or null
   const bf16_t* resid;  // [M,N] ldr or null; may alias C
   int M, N, K, lda, ldc, ldr, epi;
+  int gn;               // column tiles per rasterisation group (set by pcy_launch_gemm)
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 
