@@ -255,8 +255,32 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   float* sc = reinterpret_cast<float*>(smem + (G + 1) * DH * 2);       // [G][scld] scores, then probabilities
   float* red = sc + (size_t)G * scld;           // [NWV][G][DS]
   float* wred = red + NWV * G * DS;             // [NWV][G]
-  const int c0 = blockIdx.x * DS, kvh = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x >= DH / DS) {
+    // prefetch role: the attention itself occupies (DH/16) x Hkv x B workgroups and almost no HBM bandwidth; the other
+    // CUs stream the next Linear's weights into the memory-side cache meanwhile (results discarded)
+    const int nblk = (gridDim.x - DH / DS) * gridDim.y * gridDim.z;
+    const int bidx = ((blockIdx.x - DH / DS) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+    uint32_t sink = 0;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+      const uint4* p = reinterpret_cast<const uint4*>(seg == 0 ? a.pf0 : a.pf1);
+      const size_t n = (seg == 0 ? a.pf0_bytes : a.pf1_bytes) / 16;
+      for (size_t i = (size_t)bidx * NT + tid; i < n; i += (size_t)nblk * NT * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t j = i + (size_t)u * nblk * NT;
+          v[u] = j < n ? p[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sink ^= v[u].x ^ v[u].w;
+      }
+    }
+    asm volatile("" ::"v"(sink));
+    return;
+  }
+  const int c0 = blockIdx.x * DS, kvh = blockIdx.y, b = blockIdx.z;
   const int fr = lane & 15, fq = lane >> 4;
   const int t = *a.pos_dev;
   const int nk = t + 1;
@@ -267,6 +291,20 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   const bf16_t* cs = a.cos_t + (size_t)t * DH;
   const bf16_t* sn = a.sin_t + (size_t)t * DH;
   const uint8_t* keep = a.keep ? a.keep + (size_t)b * a.ld_keep : nullptr;
+
+  // V row slices of the first P.V pass are requested now: they depend on nothing but t, and their HBM latency is
+  // hidden behind the score and softmax phases
+  const int sub = lane >> 5, grp = wave * 32 + (lane & 31);
+  constexpr int NGV = NWV * 32;
+  constexpr int UV = 4;
+  const bf16_t* vnew = row + (a.H + a.Hkv + kvh) * DH + c0 + sub * 8;
+  const bf16_t* vsl = vc + c0 + sub * 8;
+  uint4 vpre[UV];
+#pragma unroll
+  for (int u = 0; u < UV; ++u) {
+    const int j = grp + u * NGV;
+    vpre[u] = *reinterpret_cast<const uint4*>((j < t) ? vsl + (size_t)j * DH : vnew);
+  }
 
   // ---- phase A ----
   {
@@ -374,20 +412,16 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   __syncthreads();
   if (a.dbg == 3) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = f2bf(sc[0]); return; }
   // ---- phase C: lanes 0-31 / 32-63 of a wave = the two 16-byte halves of 32 V row slices ----
-  const int sub = lane >> 5, grp = wave * 32 + (lane & 31);
-  constexpr int NGV = NWV * 32;
-  constexpr int UV = 4;
   float acc[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-  const bf16_t* vnew = row + (a.H + a.Hkv + kvh) * DH + c0 + sub * 8;
-  const bf16_t* vsl = vc + c0 + sub * 8;
   for (int j0 = 0; j0 < nk; j0 += UV * NGV) {
     uint4 vv[UV];
 #pragma unroll
     for (int u = 0; u < UV; ++u) {
+      if (j0 == 0) { vv[u] = vpre[u]; continue; }   // first pass: rows fetched at kernel start
       const int j = j0 + grp + u * NGV;
       const bf16_t* src = (j < t) ? vsl + (size_t)j * DH : vnew;   // slot t comes straight from the projection
       vv[u] = *reinterpret_cast<const uint4*>(src);
@@ -441,7 +475,8 @@ void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
-  hipLaunchKernelGGL((attn_dec_kernel<DH, G>), dim3(DH / 16, a.Hkv, a.B), dim3(512), smem, s, a);
+  const int pfx = (a.pf0_bytes + a.pf1_bytes) > 0 ? (a.pf_blocks + a.Hkv * a.B - 1) / (a.Hkv * a.B) : 0;
+  hipLaunchKernelGGL((attn_dec_kernel<DH, G>), dim3(DH / 16 + pfx, a.Hkv, a.B), dim3(512), smem, s, a);
 }
 
 template <int DH>

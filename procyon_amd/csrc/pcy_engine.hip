@@ -128,6 +128,16 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
+    {
+      static const long pf_mb = [] { const char* e = getenv("PCY_PREFETCH_MB"); return e ? atol(e) : 0L; }();  // measured null on MI355X (nt weight loads do not benefit), off by default
+      const size_t wo_bytes = (size_t)d * H * dh * 2, wgu_bytes = (size_t)2 * F * d * 2;
+      size_t budget = (size_t)pf_mb << 20;
+      t.pf0 = L.wo; t.pf0_bytes = budget < wo_bytes ? budget : wo_bytes;
+      budget -= t.pf0_bytes;
+      t.pf1 = L.wgu; t.pf1_bytes = budget < wgu_bytes ? budget : wgu_bytes;
+      t.pf_blocks = 192;
+      if (pf_mb <= 0) { t.pf0_bytes = t.pf1_bytes = 0; }
+    }
     pcy_launch_attn_decode(s, t);
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;

@@ -13,10 +13,14 @@
 //   * v_dot2c_f32_bf16 accumulates in fp32; one xor-shuffle tree per output at the end.
 //   * epilogues reproduce the reference's bf16 materialisation points (residual add, SwiGLU,
 //     bias+GELU), see pcy_common.h.
+#include <stdlib.h>
 #include "pcy_internal.h"
 
 namespace {
 
+#ifndef PCY_GEMV_DIRECTX
+#define PCY_GEMV_DIRECTX 0  // reading x straight from L2 in the k-loop measured +2.3 us per o/down launch in situ
+#endif
 constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_WAVES = 4;
 constexpr int XS_BYTES_MAX = 65536;
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int K
 //     (16 x 16 B per lane) is issued before the previous one is consumed (two register sets, static indexing)
 template <int NB, int EPI, bool RMS, int R>
 __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int units) {
+  constexpr bool DIRECTX = PCY_GEMV_DIRECTX && !RMS;
   constexpr int RW = (EPI == EPI_SWIGLU) ? 2 * R : R;
   constexpr int UN = 16 / RW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
       const int k = ((it0 + un) * 64 + lane) * 8;
       const bool ok = k < K;
 #pragma unroll
-      for (int i = 0; i < RW; ++i) wv[un][i] = ok ? ldg_nt(a.W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < RW; ++i)
+        wv[un][i] = ok ? (a.plain_loads ? *reinterpret_cast<const uint4*>(a.W + row_off(u, i) + k) : ldg_nt(a.W + row_off(u, i) + k))
+                       : make_uint4(0, 0, 0, 0);
     }
   };
   float acc[RW][NB];
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
       if (k < K) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const uint4 xv = *reinterpret_cast<const uint4*>(xs + (size_t)b * K + k);
+          const uint4 xv = DIRECTX ? *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k)
+                                   : *reinterpret_cast<const uint4*>(xs + (size_t)b * K + k);
 #pragma unroll
           for (int i = 0; i < RW; ++i) acc[i][b] = dot8(wv[un][i], xv, acc[i][b]);
         }
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
+    if (DIRECTX) break;
     for (int k = threadIdx.x * 8; k < K; k += nthr * 8) {
       uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k);
       if (RMS) {
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
       *reinterpret_cast<uint4*>(xs + (size_t)b * K + k) = v;
     }
   }
-  __syncthreads();
+  if (!DIRECTX) __syncthreads();
   zero_acc();
 
   // ---- steady state: issue batch i+1, consume batch i (roles of wa/wb alternate) ----
@@ -400,7 +409,10 @@ void launch_epi(hipStream_t s, const PcyGemvArgs& a) {
 
 }  // namespace
 
-void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a0) {
+void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
+  static const int plain = [] { const char* e = getenv("PCY_GEMV_PLAIN"); return e ? atoi(e) : 0; }();
+  PcyGemvArgs a0 = a00;
+  a0.plain_loads = plain;
   // batch rows in groups of <= 4 (weights are re-streamed per group; the skinny-MFMA path for
   // larger decode batches is a TODO tracked in DESIGN.md)
   for (int b0 = 0; b0 < a0.B; b0 += 4) {

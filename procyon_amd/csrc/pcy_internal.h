@@ -12,6 +12,7 @@ struct PcyGemvArgs {
   float rms_eps;
   int rms_cast;         // 0: w * bf16(x_hat) (transformers>=4.32) ; 1: bf16(w * x_hat) (4.31)
   int N, K, B, ldx, ldy, epi;
+  int plain_loads;      // debug A/B: 0 = non-temporal weight loads (default), 1 = default cache policy
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
@@ -65,6 +66,9 @@ struct PcyDecAttnArgs {
   const uint8_t* keep; int ld_keep;  // optional [B,Tmax] key-keep mask ("clean" mode) or null (reference quirk Q1)
   float* scratch;                 // [B*H*Tmax] fp32 probabilities workspace
   int B, H, Hkv, dh, Tmax; float scale; int dbg;
+  // optional weight prefetch riding on the idle CUs of this launch: extra workgroups (blockIdx.x >= dh/16) pull
+  // [pf0, pf0+pf0_bytes) and [pf1, pf1+pf1_bytes) through L2 into the 256 MiB Infinity Cache for the next GEMVs
+  const void* pf0; size_t pf0_bytes; const void* pf1; size_t pf1_bytes; int pf_blocks;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 

@@ -1,0 +1,20 @@
+"""Decode-only tokens/s for Llama-3-8B geometry (graph replay), used for A/B of decode-path changes."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from procyon_amd import synth
+from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+kw = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
+eng = LlamaEngine(synth.llama_state_dict(**kw, device="cuda"), LlamaConfig(**kw, max_pos=4096), free_source=True)
+ctx = Context.get()
+T, N = 512, 256
+emb = (torch.randn(1, T, 4096, device="cuda") * 0.02).bfloat16()
+cache = eng.new_cache(1, T + N)
+st = GenState(1, kw["vocab"], N, "cuda")
+logits, _ = eng.prefill(emb, None, cache, "last")
+st.logits.copy_(logits); st.pos.fill_(T)
+eng.pick(cache, st, 1, advance_pos=False)
+eng.greedy_steps(cache, st, 1, 8)
+for rep in range(3):
+    ctx.timer_start(); eng.greedy_steps(cache, st, 1, 60); ms = ctx.timer_stop() / 60
+    print(f"decode {ms:.3f} ms/token  {1e3/ms:.1f} tok/s  {15.09/ms:.2f} TB/s", flush=True)
