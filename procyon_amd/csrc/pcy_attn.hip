@@ -244,6 +244,25 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int r = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __int_as_float(r));
+}
+// wave-wide sum / max: four DPP row rotations + two cross-row exchanges (instead of six ds_bpermute round trips)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = dpp_max<0x128>(v); v = dpp_max<0x124>(v); v = dpp_max<0x122>(v); v = dpp_max<0x121>(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 template <int DH, int G>
 __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   constexpr int NT = 512, NWV = NT / 64;
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
     for (int g = 0; g < G; ++g) {
       mx[g] = -INFINITY;
       for (int j = tid; j < nk; j += NT) mx[g] = fmaxf(mx[g], sc[g * scld + j]);
-      mx[g] = wave_max(mx[g]);
+      mx[g] = wave_max_dpp(mx[g]);
       if (lane == 0) wred[wave * G + g] = mx[g];
     }
     __syncthreads();
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
       for (int w = 1; w < NWV; ++w) mx[g] = fmaxf(mx[g], wred[w * G + g]);
       se[g] = 0.f;
       for (int j = tid; j < nk; j += NT) se[g] += expf(sc[g * scld + j] - mx[g]);
-      se[g] = wave_sum(se[g]);
+      se[g] = wave_sum_dpp(se[g]);
     }
     __syncthreads();
 #pragma unroll
