@@ -181,6 +181,7 @@ def _eager_attention(q, k, v, H, Hkv, dh, lens, causal, scale, keep=None):
 
 
 @pytest.mark.parametrize("H,Hkv,dh,causal,lens", [(4, 4, 64, False, [70, 1, 129, 33]), (20, 20, 64, False, [300]),
+                                                  (4, 4, 64, False, [1026, 191, 192, 193]), (2, 2, 128, True, [515]),
                                                   (8, 2, 128, True, [45, 200]), (4, 1, 64, True, [64, 65]),
                                                   (2, 2, 32, True, [50])])
 def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
@@ -192,9 +193,9 @@ def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
     ref = _eager_attention(q, k, v, H, Hkv, dh, lens, causal, scale)
     out = ctx.attention(q.cuda(), k.cuda(), v.cuda(), lens, H, Hkv, dh, causal, scale).cpu()
     assert rel_err(out, ref) < 1e-3
-    # a 1-ulp flip of one bf16 probability p_j moves O by 2^-8 * p_j * |v_j| (absolute): allow that on top of O's own ulp
-    # (causal rows near the start have few keys, i.e. p_j up to 1)
-    assert_bf16_close(out, ref, "attention", max_frac=0.03, inter=torch.full_like(ref, 0.25 if causal else 0.03))
+    # a 1-ulp flip of one bf16 score S_j moves p_j by up to 0.8 % and O by 2^-7 * p_j * |v_j| (absolute); peaked rows
+    # (or causal rows near the start) have p_j up to O(1): allow that on top of O's own ulp
+    assert_bf16_close(out, ref, "attention", max_frac=0.03, inter=torch.full_like(ref, 0.5))
 
 
 def test_attention_left_pad_rows_uniform(ctx):
