@@ -194,6 +194,218 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-shared variant (the shipped one for dh <= 128): the 4 waves of a workgroup walk the key blocks together; each
+// 32-key block of K ([32][DH]) and Vt ([DH][32]) is fetched from L2 ONCE per workgroup (one or two 16-byte loads per
+// thread), staged in a double-buffered, XOR-swizzled LDS image and read back as MFMA fragments with ds_read_b128.
+// The per-wave global fragment loads of attn_kernel made the kernel L2-bandwidth bound (5.6 GB of fragment traffic per
+// ESM layer at batch 32); this cuts it 4x.  Arithmetic and rounding are identical to attn_kernel.
+template <int DH, int QT>
+__global__ __launch_bounds__(256) void attn_lds_kernel(PcyAttnArgs a) {
+  constexpr int KB = DH / 32, NT = DH / 16, QROWS = QT * 16;
+  constexpr int KCH = DH / 8;                  // 16-B chunks per key row
+  constexpr int KLD = (32 * KCH) / 256;        // K chunks per thread (1 for DH=64, 2 for DH=128)
+  constexpr int VLD = (DH * 4) / 256;          // Vt chunks per thread
+  constexpr int KTILE = 32 * DH * 2, VTILE = DH * 32 * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KTILE + VTILE)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sq = blockIdx.z, h = blockIdx.y;
+  const int t0 = a.cu[sq], len = a.cu[sq + 1] - t0;
+  const int bq0 = blockIdx.x * 4 * QROWS;
+  if (bq0 >= len) return;                      // uniform per workgroup
+  const int qr0 = bq0 + wave * QROWS;
+  const bool active = qr0 < len;
+  const int G = a.H / a.Hkv;
+  const int kvh = h / G;
+  const int vt0 = a.vt_cu[sq];
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float MASKZ = -3.0e38f;
+  const uint8_t* keep = a.keep ? a.keep + t0 : nullptr;
+
+  bf16x8 qf[QT][KB];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int qrow = qr0 + qt * 16 + fr;
+    qrow = qrow < len ? qrow : len - 1;
+    const bf16_t* qp = a.q + (size_t)(t0 + qrow) * a.ldq + a.qcol0 + h * DH + fq * 8;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) qf[qt][kb] = *reinterpret_cast<const bf16x8*>(qp + kb * 32);
+  }
+  const bf16_t* kglob = a.k + (size_t)t0 * a.ldk + a.kcol0 + kvh * DH;
+  const bf16_t* vglob = a.vt + (size_t)kvh * DH * a.vt_total + vt0;
+  auto kswz = [](int row) { return DH == 64 ? (row & 7) : (row & 15); };
+  auto vswz = [](int d) { return (d >> 2) & 3; };
+  // cooperative global -> register fetch of key block kb0 (K part / Vt part)
+  auto fetch_k = [&](int kb0, uint4 (&r)[KLD]) {
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int c = tid + i * 256, key = c / KCH, ch = c % KCH;
+      int kj = kb0 + key;
+      kj = kj < len ? kj : len - 1;
+      r[i] = *reinterpret_cast<const uint4*>(kglob + (size_t)kj * a.ldk + ch * 8);
+    }
+  };
+  auto put_k = [&](char* buf, const uint4 (&r)[KLD]) {
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int c = tid + i * 256, key = c / KCH, ch = c % KCH;
+      *reinterpret_cast<uint4*>(buf + (key * KCH + (ch ^ kswz(key))) * 16) = r[i];
+    }
+  };
+  auto fetch_v = [&](int kb0, uint4 (&r)[VLD]) {
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int c = tid + i * 256, d = c >> 2, ch = c & 3;
+      r[i] = *reinterpret_cast<const uint4*>(vglob + (size_t)d * a.vt_total + kb0 + ch * 8);
+    }
+  };
+  auto put_v = [&](char* buf, const uint4 (&r)[VLD]) {
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int c = tid + i * 256, d = c >> 2, ch = c & 3;
+      *reinterpret_cast<uint4*>(buf + (d * 4 + (ch ^ vswz(d))) * 16) = r[i];
+    }
+  };
+  const int krow_a = (fr >> 2) * 8 + (fr & 3);
+  auto kfrag = [&](const char* buf, int tile, int kb) {
+    const int row = krow_a + tile * 4;
+    return *reinterpret_cast<const bf16x8*>(buf + (row * KCH + ((kb * 4 + fq) ^ kswz(row))) * 16);
+  };
+  auto vfrag = [&](const char* buf, int n) {
+    const int d = n * 16 + fr;
+    return *reinterpret_cast<const bf16x8*>(buf + (d * 4 + (fq ^ vswz(d))) * 16);
+  };
+  auto scores = [&](const char* kbuf, int kb0, int qt, float (&s)[8]) {
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(kbuf, 0, kb), qf[qt][kb], sa, 0, 0, 0);
+      sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(kbuf, 1, kb), qf[qt][kb], sb, 0, 0, 0);
+    }
+    const int qlo = qr0 + qt * 16;
+    const bool interior = (kb0 + 32 <= len) && !keep && !(a.causal && kb0 + 31 > qlo);
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
+        if (a.scale != 1.0f) v = rbf(v * a.scale);
+        s[r] = v * LOG2E;
+      }
+    } else {
+      const int qpos = qlo + fr;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j = kb0 + fq * 8 + r;
+        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
+        if (a.scale != 1.0f) v = rbf(v * a.scale);
+        bool allowed = !(a.causal && j > qpos);
+        if (keep && j < len) allowed = allowed && (keep[j] != 0);
+        s[r] = j < len ? (allowed ? v * LOG2E : MASKZ) : -INFINITY;
+      }
+    }
+  };
+
+  // key range of the WORKGROUP (uniform): causal -> up to its last query row
+  int kend = a.causal ? ((bq0 + 4 * QROWS) < len ? (bq0 + 4 * QROWS) : len) : len;
+  float m[QT], l[QT];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
+    {
+      uint4 kr[KLD];
+      fetch_k(0, kr);
+      __syncthreads();                         // previous readers of buffer 0 are done
+      put_k(smem, kr);
+      __syncthreads();
+    }
+    for (int kb0 = 0, cur = 0; kb0 < kend; kb0 += 32, cur ^= 1) {
+      uint4 kr[KLD];
+      const bool more = kb0 + 32 < kend;
+      if (more) fetch_k(kb0 + 32, kr);
+      const char* kbuf = smem + cur * KTILE;
+      if (active) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          float s[8];
+          scores(kbuf, kb0, qt, s);
+          float bm = s[0];
+#pragma unroll
+          for (int r = 1; r < 8; ++r) bm = fmaxf(bm, s[r]);
+          bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+          bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+          const float mn = fmaxf(m[qt], bm);
+          float bs = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) bs += __builtin_amdgcn_exp2f(s[r] - mn);
+          bs += __shfl_xor(bs, 16, 64);
+          bs += __shfl_xor(bs, 32, 64);
+          l[qt] = l[qt] * __builtin_amdgcn_exp2f(m[qt] - mn) + bs;
+          m[qt] = mn;
+        }
+      }
+      if (more) put_k(smem + (cur ^ 1) * KTILE, kr);
+      __syncthreads();
+    }
+    bool empty_row = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) empty_row = empty_row || (active && (m[qt] == MASKZ) && (qr0 + qt * 16 + fr) < len);
+    // workgroup-uniform decision (every wave must walk the same key blocks)
+    if (attempt == 0 && kend < len && __syncthreads_or(empty_row ? 1 : 0)) { kend = len; continue; }
+    break;
+  }
+
+  float rl[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) rl[qt] = 1.0f / l[qt];
+  f32x4 oacc[QT][NT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) oacc[qt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  char* kb_base = smem;
+  char* vb_base = smem + 2 * KTILE;
+  {
+    uint4 kr[KLD], vr[VLD];
+    fetch_k(0, kr); fetch_v(0, vr);
+    __syncthreads();
+    put_k(kb_base, kr); put_v(vb_base, vr);
+    __syncthreads();
+  }
+  for (int kb0 = 0, cur = 0; kb0 < kend; kb0 += 32, cur ^= 1) {
+    uint4 kr[KLD], vr[VLD];
+    const bool more = kb0 + 32 < kend;
+    if (more) { fetch_k(kb0 + 32, kr); fetch_v(kb0 + 32, vr); }
+    const char* kbuf = kb_base + cur * KTILE;
+    const char* vbuf = vb_base + cur * VTILE;
+    if (active) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float s[8];
+        scores(kbuf, kb0, qt, s);
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pf[r] = (short)f2bf(__builtin_amdgcn_exp2f(s[r] - m[qt]) * rl[qt]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) oacc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vfrag(vbuf, n), oacc[qt][n], 0, 0, 0);
+      }
+    }
+    if (more) { put_k(kb_base + (cur ^ 1) * KTILE, kr); put_v(vb_base + (cur ^ 1) * VTILE, vr); }
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qr0 + qt * 16 + fq * 4 + r;
+      if (qq >= len) continue;
+      bf16_t* op = a.o + (size_t)(t0 + qq) * a.ldo + h * DH + fr;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) op[n * 16] = f2bf(oacc[qt][n][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decode attention (row A7): one new token per row against the KV cache, exact softmax rounding.
 // Two launches so that the work spreads over the chip instead of Hkv*B workgroups:
 //   (A) attn_dec_scores: grid (key chunks of 64, Hkv, B).  Every block ropes the G query heads of its kv head in
@@ -519,6 +731,11 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   // (325 proteins/s vs 321 at QT = 2).  QT = 4 is NOT used: that instantiation mis-normalises ~0.3 % of the rows of
   // its fourth tile (sum p = 1.02-1.03, deterministic, with or without prefetch; tools/diag_attn_scale.py) -- cause not
   // yet found, tracked in DESIGN.md; the strict unit tests (test_attention_exact_rounding) guard the shipped shapes.
+  static const int var = [] { const char* e = getenv("PCY_ATTN_VAR"); return e ? atoi(e) : 0; }();
+  // var 1 = LDS-shared K/Vt tiles (attn_lds_kernel): measured equal to the register-fragment kernel (341 vs 346
+  // proteins/s) -- the kernel is not L2-bound -- so the simpler one stays the default
+  if (var == 1 && a.dh == 64) { hipLaunchKernelGGL((attn_lds_kernel<64, 3>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a); return; }
+  if (var == 1 && a.dh == 128) { hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a); return; }
   if (a.dh == 128) hipLaunchKernelGGL((attn_kernel<128, 1, true>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
   else if (a.dh == 64) hipLaunchKernelGGL((attn_kernel<64, 3, true>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((attn_kernel<32, 2, true>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);

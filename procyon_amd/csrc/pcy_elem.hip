@@ -125,32 +125,50 @@ __global__ __launch_bounds__(NT) void esm_embed_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------ rotary on a token-major buffer
-// one block per token; thread handles (head, i) pairs (i, i+dh/2)
+// one block per token; a thread handles 8 consecutive elements i..i+7 of the low half of a head and their partners
+// i+dh/2.. (16-byte loads/stores)
 __global__ __launch_bounds__(NT) void rope_kernel(bf16_t* __restrict__ buf, int ld, int col0, int nh, int dh,
                                                   const int32_t* __restrict__ pos, const bf16_t* __restrict__ cos_t,
                                                   const bf16_t* __restrict__ sin_t, int mode, float prescale) {
   const int tok = blockIdx.x;
   const int p = pos[tok];
   const int half = dh >> 1;
+  const int cph = half >> 3;  // 8-element chunks per half head
   bf16_t* row = buf + (size_t)tok * ld + col0;
   const bf16_t* c = cos_t + (size_t)p * dh;
   const bf16_t* s = sin_t + (size_t)p * dh;
-  for (int e = threadIdx.x; e < nh * half; e += NT) {
-    const int h = e / half, i = e - h * half;
+  for (int e = threadIdx.x; e < nh * cph; e += NT) {
+    const int h = e / cph, i = (e - h * cph) * 8;
     bf16_t* x = row + h * dh;
-    float x1 = bf2f(x[i]), x2 = bf2f(x[i + half]);
-    if (prescale != 0.f) { x1 = rbf(x1 * prescale); x2 = rbf(x2 * prescale); }
-    const float c1 = bf2f(c[i]), c2 = bf2f(c[i + half]), s1 = bf2f(s[i]), s2 = bf2f(s[i + half]);
-    float o1, o2;
-    if (mode == 0) {  // (x*cos) + (rotate_half(x)*sin), every op a bf16 tensor
-      o1 = rbf(rbf(x1 * c1) + rbf(-x2 * s1));
-      o2 = rbf(rbf(x2 * c2) + rbf(x1 * s2));
-    } else {          // fp32, rounded once
-      o1 = x1 * c1 + (-x2) * s1;
-      o2 = x2 * c2 + x1 * s2;
+    const uint4 a1 = *reinterpret_cast<const uint4*>(x + i), a2 = *reinterpret_cast<const uint4*>(x + i + half);
+    const uint4 c1 = *reinterpret_cast<const uint4*>(c + i), c2 = *reinterpret_cast<const uint4*>(c + i + half);
+    const uint4 s1 = *reinterpret_cast<const uint4*>(s + i), s2 = *reinterpret_cast<const uint4*>(s + i + half);
+    const uint32_t A1[4] = {a1.x, a1.y, a1.z, a1.w}, A2[4] = {a2.x, a2.y, a2.z, a2.w};
+    const uint32_t C1[4] = {c1.x, c1.y, c1.z, c1.w}, C2[4] = {c2.x, c2.y, c2.z, c2.w};
+    const uint32_t S1[4] = {s1.x, s1.y, s1.z, s1.w}, S2[4] = {s2.x, s2.y, s2.z, s2.w};
+    uint32_t O1[4], O2[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float o1[2], o2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float x1 = hh ? hi_bf(A1[w]) : lo_bf(A1[w]), x2 = hh ? hi_bf(A2[w]) : lo_bf(A2[w]);
+        if (prescale != 0.f) { x1 = rbf(x1 * prescale); x2 = rbf(x2 * prescale); }
+        const float cc1 = hh ? hi_bf(C1[w]) : lo_bf(C1[w]), cc2 = hh ? hi_bf(C2[w]) : lo_bf(C2[w]);
+        const float ss1 = hh ? hi_bf(S1[w]) : lo_bf(S1[w]), ss2 = hh ? hi_bf(S2[w]) : lo_bf(S2[w]);
+        if (mode == 0) {  // (x*cos) + (rotate_half(x)*sin), every op a bf16 tensor
+          o1[hh] = rbf(rbf(x1 * cc1) + rbf(-x2 * ss1));
+          o2[hh] = rbf(rbf(x2 * cc2) + rbf(x1 * ss2));
+        } else {          // fp32, rounded once
+          o1[hh] = x1 * cc1 + (-x2) * ss1;
+          o2[hh] = x2 * cc2 + x1 * ss2;
+        }
+      }
+      O1[w] = pack_bf(o1[0], o1[1]);
+      O2[w] = pack_bf(o2[0], o2[1]);
     }
-    x[i] = f2bf(o1);
-    x[i + half] = f2bf(o2);
+    *reinterpret_cast<uint4*>(x + i) = make_uint4(O1[0], O1[1], O1[2], O1[3]);
+    *reinterpret_cast<uint4*>(x + i + half) = make_uint4(O2[0], O2[1], O2[2], O2[3]);
   }
 }
 
