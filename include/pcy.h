@@ -77,6 +77,11 @@ int pcy_attn_decode(pcy_ctx*, void* qkv, int ld, void* kcache, void* vcache, voi
 /* pooled[i] over the token ranges rng[2*r],rng[2*r+1] = (start,len), r in [seg[i], seg[i+1])  (esm.py:131-173) */
 int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out);
 
+/* Retrieval scoring (evaluate/framework/procyon.py:400-406, data/inference_utils.py:955-960):
+ * sims[Q,N] = F.normalize(query) @ F.normalize(targets)^T in bf16 (norm rounded to bf16, then the division, then an
+ * fp32-accumulating matmul rounded once).  D must be a multiple of 64. */
+int pcy_retrieval_scores(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, void* sims_out);
+
 /* ---- create_mlp projector (model_utils.py:13-41) -------------------------------------------- */
 typedef struct {
   int32_t n_layers;          /* 1 (bias-free Linear) or >= 2 (Linear+bias -> GELU ... -> Linear+bias) */

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pcy_attention": (ci, [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, C.c_float]),
     "pcy_attn_decode": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "pcy_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
+    "pcy_retrieval_scores": (ci, [vp, vp, ci, vp, ci, ci, vp]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp]),

@@ -306,6 +306,31 @@ __global__ void advance_kernel(int32_t* pos_dev, int32_t* step_dev, int advance_
   if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev += 1; }
 }
 
+// ------------------------------------------------------------------ F.normalize(x, dim=-1) on a bf16 tensor
+// torch: x / x.norm(2, -1, keepdim).clamp_min(eps): the norm is itself a bf16 tensor (fp32 accumulate, one rounding)
+__global__ __launch_bounds__(NT) void l2norm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int d, float eps) {
+  __shared__ float red[NT / 64];
+  const bf16_t* xr = x + (size_t)blockIdx.x * d;
+  bf16_t* yr = y + (size_t)blockIdx.x * d;
+  float ss = 0.f;
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float a = lo_bf(u[j]), b = hi_bf(u[j]); ss += a * a + b * b; }
+  }
+  ss = block_sum<NT>(ss, red);
+  const float nrm = fmaxf(rbf(sqrtf(ss)), eps);
+  for (int k = threadIdx.x * 8; k < d; k += NT * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf(lo_bf(u[j]) / nrm, hi_bf(u[j]) / nrm);
+    *reinterpret_cast<uint4*>(yr + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 __global__ __launch_bounds__(NT) void copy_rows_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst,
                                                        int ldd, const int32_t* __restrict__ rows, int d) {
   const int r = blockIdx.x;
@@ -362,4 +387,7 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 }
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {
   if (nrows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, dst, ldd, rows, d);
+}
+void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps) {
+  if (rows > 0) hipLaunchKernelGGL(l2norm_rows_kernel, dim3(rows), dim3(NT), 0, s, x, y, d, eps);
 }

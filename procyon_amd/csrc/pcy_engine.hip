@@ -316,6 +316,18 @@ int pcy_attn_decode(pcy_ctx* c, void* qkv, int ld, void* kcache, void* vcache, v
   return check_launch("pcy_attn_decode");
 }
 
+int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, void* sims_out) {
+  if (D % 64) return fail(1, "pcy_retrieval_scores: D=%d must be a multiple of 64", D);
+  const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256);
+  if (int r = c->reserve(qb + tb + 4096)) return r;
+  bf16_t* qn = reinterpret_cast<bf16_t*>(c->ws);
+  bf16_t* tn = reinterpret_cast<bf16_t*>(c->ws + qb);
+  pcy_launch_l2norm_rows(c->stream, (const bf16_t*)query, qn, Q, D, 1e-12f);
+  pcy_launch_l2norm_rows(c->stream, (const bf16_t*)targets, tn, N, D, 1e-12f);
+  linear(c->stream, qn, D, tn, nullptr, nullptr, 0, (bf16_t*)sims_out, N, Q, N, D, EPI_STORE);
+  return check_launch("pcy_retrieval_scores");
+}
+
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
   if (m->n_layers < 1 || m->n_layers > 8) return fail(1, "pcy_mlp_forward: n_layers %d", m->n_layers);
   int maxw = 0;

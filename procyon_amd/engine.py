@@ -133,6 +133,15 @@ class Context:
                                          _p(sin_t), _p(keep), B, H, Hkv, dh, Tmax), "pcy_attn_decode")
         return o
 
+    def retrieval_scores(self, query, targets):
+        """cosine similarities [Q,N] (bf16) as `ProcyonRetrievalEval.get_predictions` forms them (procyon.py:400-406)."""
+        _chk_bf16(query, targets)
+        Q, D = query.shape
+        N = targets.shape[0]
+        out = torch.empty(Q, N, dtype=BF16, device=query.device)
+        L.check(self.lib.pcy_retrieval_scores(self.h, _p(query), Q, _p(targets), N, D, _p(out)), "pcy_retrieval_scores")
+        return out
+
     def pool(self, hidden, seg, rng, nprot, mode):
         _chk_bf16(hidden)
         d = hidden.shape[-1]

@@ -255,3 +255,15 @@ def test_attn_decode(ctx, H, Hkv, dh, t):
     assert_bf16_close(out, ref, "attn decode", max_frac=0.03, inter=torch.full_like(ref, 0.05))
     assert torch.equal(kcd.cpu()[:, :, t], kr[:, :, 0]) and torch.equal(vcd.cpu()[:, :, t], v[:, :, 0])
     assert torch.equal(kcd.cpu()[:, :, :t], kc[:, :, :t])
+
+
+@pytest.mark.parametrize("Q,N,D", [(3, 1000, 1280), (40, 513, 2560)])
+def test_retrieval_scores(ctx, Q, N, D):
+    from oracle.procyon_ref import retrieval_scores
+    q, t = rnd(Q, D, seed=1), rnd(N, D, seed=2)
+    ref = retrieval_scores(q, t)
+    out = ctx.retrieval_scores(q.cuda(), t.cuda()).cpu()
+    assert rel_err(out, ref) < 1e-3
+    assert_bf16_close(out, ref.to(BF), "retrieval sims", inter=torch.full_like(ref, 0.02, dtype=torch.float32))
+    # ranking of the top hits is what the callers consume (data/inference_utils.py:962-969)
+    assert torch.equal(out.float().argmax(-1), ref.float().argmax(-1))
