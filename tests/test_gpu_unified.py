@@ -155,3 +155,29 @@ def test_sampling_probability_vector_and_nucleus_mask(env):
         for s_ in range(4):
             pr = LR.sampling_probs(lg[0, k, s_][None].float(), nucleus_prob=0.9)
             assert pr[0, tokens[0, k, s_]] > 0
+
+
+def test_checkpoint_ingest_builds_identical_model(env):
+    """A state dict in the reference's checkpoint layout (text_encoder.model.*, protein_seq_encoder.model.* with fair-esm
+    names, projector Sequential indices) builds a model whose outputs are bit-identical to the directly built one."""
+    from procyon_amd.checkpoint import build_model
+    from procyon_amd.model import ProCyonConfig
+    m, w = env["model"], env["w"]
+    sd = {"text_encoder.model." + k: v for k, v in w["llama"].items()}
+    for k, v in w["esm"].items():
+        k2 = k[4:].replace("embeddings.word_embeddings", "embed_tokens").replace("encoder.emb_layer_norm_after", "emb_layer_norm_after")
+        k2 = k2.replace("encoder.layer.", "layers.").replace("attention.self.query", "self_attn.q_proj").replace("attention.self.key", "self_attn.k_proj")
+        k2 = k2.replace("attention.self.value", "self_attn.v_proj").replace("attention.output.dense", "self_attn.out_proj")
+        k2 = k2.replace("attention.LayerNorm", "self_attn_layer_norm").replace("intermediate.dense", "fc1").replace("output.dense", "fc2")
+        sd["protein_seq_encoder.model." + k2.replace(".LayerNorm.", ".final_layer_norm.")] = v
+    for name, key in (("token_projectors.aaseq", "aaseq"), ("aaseq_shared_projector", "shared"), ("aaseq_lm_projector", "lm")):
+        for j, (wt, b) in zip((0, 3, 6), w["projs"][key]):
+            sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = wt, b
+    m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, head_dim=64, max_pos=4096)
+    a, b = m.forward_sequences(env["prot"], get_soft_tokens=True), m2.forward_sequences(env["prot"], get_soft_tokens=True)
+    for k in ("original", "shared", "token"):
+        assert torch.equal(a[k], b[k]), k
+    instr = ["w5 w6 <|protein|> w7 [ANSWER]"]
+    t1 = m.generate(_inputs(m, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
+    t2 = m2.generate(_inputs(m2, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
+    assert torch.equal(t1, t2)

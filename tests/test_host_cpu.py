@@ -69,3 +69,41 @@ def test_pack_varlen():
     assert pk["pos"].tolist() == [0, 1, 2, 3, 0, 1, 2, 0, 1, 2, 3, 4, 5]
     pk = EsmEngine.pack(rows, mask_pads=False)   # HF-"official" call: pads stay as tokens (Q12)
     assert pk["ntok"] == 18 and pk["real"].tolist() == [4, 3, 6]
+
+
+def test_checkpoint_key_mapping():
+    """ProCyon state-dict layout -> engine inputs (procyon_amd/checkpoint.py), incl. fair-esm -> HF Esm names."""
+    from procyon_amd import synth
+    from procyon_amd.checkpoint import fair_esm_to_hf, infer_esm_config, infer_llama_config, split_state_dict
+    hf = synth.esm_state_dict(d=64, n_layers=2, n_heads=4, ffn=128, dtype=torch.float32)
+    inv = {"esm.embeddings.word_embeddings.weight": "embed_tokens.weight"}
+    fair = {}
+    for k, v in hf.items():
+        k2 = k[4:]
+        k2 = k2.replace("embeddings.word_embeddings", "embed_tokens").replace("encoder.emb_layer_norm_after", "emb_layer_norm_after")
+        k2 = k2.replace("encoder.layer.", "layers.").replace("attention.self.query", "self_attn.q_proj").replace("attention.self.key", "self_attn.k_proj")
+        k2 = k2.replace("attention.self.value", "self_attn.v_proj").replace("attention.output.dense", "self_attn.out_proj")
+        k2 = k2.replace("attention.LayerNorm", "self_attn_layer_norm").replace("intermediate.dense", "fc1").replace("output.dense", "fc2")
+        k2 = k2.replace(".LayerNorm.", ".final_layer_norm.")
+        fair[k2] = v
+    fair["lm_head.weight"] = torch.zeros(3)                  # dropped
+    fair["layers.0.self_attn.rot_emb.inv_freq"] = torch.zeros(3)
+    back = fair_esm_to_hf(fair)
+    assert set(back) == set(hf) and all(back[k] is hf[k] for k in hf)
+    llama = synth.llama_state_dict(vocab=50, d=256, n_layers=2, n_heads=2, n_kv_heads=1, ffn=512, dtype=torch.float32)
+    sd = {"text_encoder.model." + k: v for k, v in llama.items()}
+    sd.update({"protein_seq_encoder.model." + k: v for k, v in fair.items()})
+    for name, (i, o) in {"token_projectors.aaseq": (64, 256), "aaseq_shared_projector": (64, 64), "aaseq_lm_projector": (256, 64)}.items():
+        for j, (w, b) in zip((0, 3, 6), synth.mlp_layers(3, i, o, 96, 0, dtype=torch.float32)):
+            sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = w, b
+    sd["protein_seq_embeddings.weight"] = torch.zeros(5, 64)
+    sd["contrastive_head.temperature"] = torch.zeros(1)      # training-only, ignored
+    parts = split_state_dict(sd)
+    assert set(parts["llama"]) == set(llama) and set(parts["esm"]) == set(hf)
+    assert [w.shape for w, _ in parts["projectors"]["token_aaseq"]] == [(96, 64), (96, 96), (256, 96)]
+    assert set(parts["projectors"]) == {"token_aaseq", "aaseq_shared_projector", "aaseq_lm_projector"}
+    assert list(parts["tables"]) == ["protein_seq_embeddings"]
+    lc = infer_llama_config(parts["llama"], head_dim=128)
+    assert (lc.vocab, lc.d, lc.n_layers, lc.n_heads, lc.n_kv_heads, lc.ffn) == (50, 256, 2, 2, 1, 512)
+    ec = infer_esm_config(parts["esm"], n_heads=4)
+    assert (ec.d, ec.n_layers, ec.ffn) == (64, 2, 128)
