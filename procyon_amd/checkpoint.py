@@ -91,7 +91,7 @@ def infer_esm_config(esm_sd, n_heads=None, **over):
     return EsmConfig(d=d, n_layers=n_layers, n_heads=n_heads, ffn=ffn, vocab=emb.shape[0], **over)
 
 
-def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, **llama_over):
+def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_heads=None, **llama_over):
     """state dict + `ProCyonConfig` + tokenizer -> engine-backed `UnifiedProCyon` (the tail of `from_pretrained`,
     model_unified.py:1370-1382 `load_state_dict(strict=False)`)."""
     from .engine import BF16, MlpEngine
@@ -101,7 +101,7 @@ def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, **llam
     text_encoder = LlamaPostTokenization(parts["llama"], infer_llama_config(parts["llama"], **llama_over), dev, max_new_tokens)
     plm = None
     if parts["esm"] and not config.use_aaseq_embeddings:
-        plm = ESM_PLM(parts["esm"], infer_esm_config(parts["esm"]), pooling_method=config.protein_pooling_opt,
+        plm = ESM_PLM(parts["esm"], infer_esm_config(parts["esm"], n_heads=esm_heads), pooling_method=config.protein_pooling_opt,
                       protein_pooling_correction_option=config.protein_pooling_correction_option,
                       max_protein_len=config.max_protein_len, device=dev)
     mk = lambda layers: MlpEngine([(w.to(dev, BF16), None if b is None else b.to(dev, BF16)) for w, b in layers])

@@ -173,7 +173,7 @@ def test_checkpoint_ingest_builds_identical_model(env):
     for name, key in (("token_projectors.aaseq", "aaseq"), ("aaseq_shared_projector", "shared"), ("aaseq_lm_projector", "lm")):
         for j, (wt, b) in zip((0, 3, 6), w["projs"][key]):
             sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = wt, b
-    m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, head_dim=64, max_pos=4096)
+    m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, esm_heads=2, head_dim=64, max_pos=4096)
     a, b = m.forward_sequences(env["prot"], get_soft_tokens=True), m2.forward_sequences(env["prot"], get_soft_tokens=True)
     for k in ("original", "shared", "token"):
         assert torch.equal(a[k], b[k]), k
