@@ -102,7 +102,8 @@ size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
   const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
   return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
          align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) +
-         align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) + 4096;
+         align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) +
+         align_up((size_t)B * m->d * 2, 256) + 4096;
 }
 
 void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
@@ -115,6 +116,9 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   bf16_t* ao = cv.take<bf16_t>((size_t)B * H * dh);
   bf16_t* act = cv.take<bf16_t>((size_t)B * F);
   float* scores = cv.take<float>((size_t)B * H * (kv->Tmax + 1));
+  cv.take<char>((size_t)B * 64 * 16);                 // pick partials (same carve as enqueue_pick)
+  bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
+  const bool batched = B > 4 && B <= 32 && d % 512 == 0 && F % 512 == 0;
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l) {
@@ -122,6 +126,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyGemvArgs g{};
     g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
     g.rms_cast = m->rms_cast; g.N = qkvw; g.K = d; g.B = B; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
+    if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, B, d, m->rms_eps, m->rms_cast); g.x = xn; g.rms_w = nullptr; }
     pcy_launch_gemv(s, g);
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
@@ -145,6 +150,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
     u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
+    if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, B, d, m->rms_eps, m->rms_cast); u.x = xn; u.rms_w = nullptr; }
     pcy_launch_gemv(s, u);
     PcyGemvArgs w{};
     w.W = (const bf16_t*)L.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.B = B; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
@@ -153,6 +159,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   PcyGemvArgs h{};
   h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
   h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = B; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
+  if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, xn, B, d, m->rms_eps, m->rms_cast); h.x = xn; h.rms_w = nullptr; }
   pcy_launch_gemv(s, h);
 }
 

@@ -407,12 +407,152 @@ void launch_epi(hipStream_t s, const PcyGemvArgs& a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batched decode (4 < B <= 32, e.g. beam 20): skinny MFMA GEMV.  Weights are still read exactly once; the batch rides
+// on the MFMA N dimension instead of re-streaming W per group of 4 rows.
+//   * workgroup = 16 output rows (32 weight rows for SwiGLU: its gate tile + up tile); the 4 waves split K in quarters
+//   * per 128-k super-step a lane loads 64 contiguous bytes of its weight row (A fragments, k-slots remapped so that the
+//     4 MFMA k-steps of the super-step are the lane's 4 consecutive 16-B pieces) and the matching pieces of x[b] straight
+//     from L2 in B-fragment layout -- no LDS on the operand path
+//   * the four K-quarter partial tiles are summed through LDS in fixed order by wave 0, which runs the fused epilogue
+template <int EPI, int BT>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(PcyGemvArgs a) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  __shared__ float part[3][RT][BT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int K = a.K;
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  const int r0 = blockIdx.x * 16 * RT;
+  const int kq = K >> 2;                    // K % 512 == 0
+  const int kbeg = wave * kq, kend = kbeg + kq;
+  const bf16_t* wp[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int r = r0 + rt * 16 + fr;
+    r = r < nrows ? r : nrows - 1;
+    wp[rt] = a.W + (size_t)r * K + fq * 32;
+  }
+  const bf16_t* xp[BT];
+#pragma unroll
+  for (int bt = 0; bt < BT; ++bt) {
+    int b = bt * 16 + fr;
+    b = b < a.B ? b : a.B - 1;
+    xp[bt] = a.x + (size_t)b * a.ldx + fq * 32;
+  }
+  f32x4 acc[RT][BT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int US = 2;   // super-steps in flight
+  for (int k0 = kbeg; k0 < kend; k0 += 128 * US) {
+    bf16x8 wf[US][RT][4], xf[US][BT][4];
+#pragma unroll
+    for (int u = 0; u < US; ++u) {
+      const int k = k0 + u * 128;
+      const bool ok = k < kend;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ok) { const uint4 v = ldg_nt(wp[rt] + k + j * 8); wf[u][rt][j] = __builtin_bit_cast(bf16x8, v); }
+          else wf[u][rt][j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xf[u][bt][j] = ok ? *reinterpret_cast<const bf16x8*>(xp[bt] + k + j * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < US; ++u)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][rt][j], xf[u][bt][j], acc[rt][bt], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][rt][bt][lane][r] = acc[rt][bt][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[rt][bt][r] = ((acc[rt][bt][r] + part[0][rt][bt][lane][r]) + part[1][rt][bt][lane][r]) + part[2][rt][bt][lane][r];
+  // D[n = fq*4 + r][b = fr]
+#pragma unroll
+  for (int bt = 0; bt < BT; ++bt) {
+    const int b = bt * 16 + fr;
+    if (b >= a.B) continue;
+    if (EPI == EPI_SWIGLU) {
+      const int f = (r0 >> 5) * 16 + fq * 4;
+      if (f >= a.N) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = rbf(silu_f(rbf(acc[0][bt][r]))) * rbf(acc[RT - 1][bt][r]);
+      *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+    } else {
+      const int n = r0 + fq * 4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = (n + r) < a.N ? n + r : a.N - 1;
+        v[r] = rbf(acc[0][bt][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
+        if (EPI == EPI_RESID) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)b * a.ldy + nn]));
+        if (EPI == EPI_GELU_ERF) v[r] = rbf(gelu_erf_f(v[r]));
+        if (EPI == EPI_GELU_ESM) v[r] = gelu_esm_chain(v[r]);
+      }
+      if (n + 3 < a.N && (a.ldy & 3) == 0) {
+        *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) a.y[(size_t)b * a.ldy + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  const int rpb = (EPI == EPI_SWIGLU) ? 32 : 16;
+  const int blocks = (nrows + rpb - 1) / rpb;
+  if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma_kernel<EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemv_mfma_kernel<EPI, 2>), dim3(blocks), dim3(256), 0, s, a);
+}
+
 }  // namespace
 
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   static const int plain = [] { const char* e = getenv("PCY_GEMV_PLAIN"); return e ? atoi(e) : 0; }();
   PcyGemvArgs a0 = a00;
   a0.plain_loads = plain;
+  // 4 < B <= 32 on MFMA (x already normalised by the caller: the fused RMSNorm prologue is a B <= 4 feature)
+  if (a0.B > 4 && a0.B <= 32 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
+    switch (a0.epi) {
+      case EPI_STORE: launch_mfma<EPI_STORE>(s, a0); return;
+      case EPI_RESID: launch_mfma<EPI_RESID>(s, a0); return;
+      case EPI_GELU_ERF: launch_mfma<EPI_GELU_ERF>(s, a0); return;
+      case EPI_GELU_ESM: launch_mfma<EPI_GELU_ESM>(s, a0); return;
+      case EPI_SWIGLU: launch_mfma<EPI_SWIGLU>(s, a0); return;
+    }
+  }
   // batch rows in groups of <= 4 (weights are re-streamed per group; the skinny-MFMA path for
   // larger decode batches is a TODO tracked in DESIGN.md)
   for (int b0 = 0; b0 < a0.B; b0 += 4) {

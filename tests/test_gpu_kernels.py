@@ -74,8 +74,8 @@ def test_gemm_transpose_detecting(ctx):
     assert torch.equal(out, W.t().contiguous())
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 6])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 14336), (1000, 1280), (130, 136)])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 6, 16, 20, 32])   # B > 4 with K % 512 == 0 takes the skinny-MFMA kernel
+@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 14336), (1000, 1280), (130, 136), (1001, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemv(ctx, B, N, K, epi):
     x, W, b, r = rnd(B, K, seed=1), rnd(N, K, seed=2, std=0.05), rnd(N, seed=3, std=0.1), rnd(B, N, seed=4)
@@ -267,3 +267,41 @@ def test_retrieval_scores(ctx, Q, N, D):
     assert_bf16_close(out, ref.to(BF), "retrieval sims", inter=torch.full_like(ref, 0.02, dtype=torch.float32))
     # ranking of the top hits is what the callers consume (data/inference_utils.py:962-969)
     assert torch.equal(out.float().argmax(-1), ref.float().argmax(-1))
+
+
+@pytest.mark.parametrize("B", [5, 20, 32])
+def test_gemv_mfma_swiglu_and_decode_layer(ctx, B):
+    """batched decode path: SwiGLU on the skinny-MFMA kernel, then one full-width Llama-3-8B layer decoding B rows at once
+    against the oracle (beam-20-shaped batch)."""
+    from procyon_amd.engine import interleave_gate_up
+    K, Fh = 4096, 1024 + 16
+    x = rnd(B, K, seed=1)
+    g, u = rnd(Fh, K, seed=2, std=0.03), rnd(Fh, K, seed=3, std=0.03)
+    out = ctx.gemv(interleave_gate_up(g, u).cuda(), x.cuda(), epi=4).cpu()
+    ref = F.silu(F.linear(x, g)) * F.linear(x, u)
+    assert_bf16_close(out, ref, "mfma gemv swiglu", ulps=2)
+
+
+def test_decode_batch20_full_width_layer():
+    from oracle import llama_ref as LR
+    from procyon_amd import synth
+    from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=512, d=4096, n_layers=1, n_heads=32, n_kv_heads=8, ffn=14336)
+    sd = synth.llama_state_dict(**kw)
+    geom = LR.LlamaGeom(**kw)
+    eng = LlamaEngine(sd, LlamaConfig(**kw, max_pos=256))
+    B, T = 20, 9
+    g = torch.Generator().manual_seed(2)
+    emb = (torch.randn(B, T, 4096, generator=g) * 0.02).to(BF)
+    r = LR.llama_forward(sd, geom, inputs_embeds=emb, attn_mask=torch.ones(B, T))
+    cache = eng.new_cache(B, 16)
+    eng.prefill(emb.cuda(), None, cache, "last")
+    tok = r["logits"][:, -1].argmax(-1)
+    st = GenState(B, 512, 2, "cuda")
+    st.pos.fill_(T)
+    st.next_tok.copy_(tok.to(torch.int32))
+    eng.decode(cache, st, B)
+    ro = LR.llama_forward(sd, geom, input_ids=tok[:, None], attn_mask=None, past_kv=r["past_kv"])
+    assert rel_err(st.logits.cpu(), ro["logits"][:, -1]) < 1e-2
+    agree = (st.logits.cpu().float().argmax(-1) == ro["logits"][:, -1].float().argmax(-1)).float().mean()
+    assert agree >= 0.9
