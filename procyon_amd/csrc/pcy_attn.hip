@@ -477,11 +477,15 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return v;
 }
 
-template <int DH, int G>
+// DS = output columns per workgroup.  16 (DH/16 workgroups per (kv head, sequence), each recomputing the scores) fills
+// the chip when B x Hkv is small; at beam / batch sizes where B x Hkv x DH/DS already covers the CUs the redundant score
+// passes are the dominant cost and a wider slice (up to the whole head) is used instead.
+template <int DH, int G, int DS>
 __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   constexpr int NT = 512, NWV = NT / 64;
   constexpr int KB = DH / 32;
-  constexpr int DS = 16;
+  constexpr int LPR = DS / 8;          // lanes that share one V row slice (16 bytes each)
+  constexpr int RPW = 64 / LPR;        // V rows per wave per load
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int scld = a.Tmax + 1;
   bf16_t* qk = reinterpret_cast<bf16_t*>(smem);                        // [(G+1)][DH] roped q heads, then roped k_new
@@ -527,9 +531,12 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
 
   // V row slices of the first P.V pass are requested now: they depend on nothing but t, and their HBM latency is
   // hidden behind the score and softmax phases
-  const int sub = lane >> 5, grp = wave * 32 + (lane & 31);
-  constexpr int NGV = NWV * 32;
-  constexpr int UV = 4;
+  // DS == 16: lanes 0-31 / 32-63 of a wave = the two 16-byte halves of 32 rows; wider slices: LPR consecutive lanes
+  // cover one row slice (coalesced), RPW rows per wave
+  const int sub = DS == 16 ? lane >> 5 : lane % LPR;
+  const int grp = DS == 16 ? wave * 32 + (lane & 31) : wave * RPW + lane / LPR;
+  constexpr int NGV = NWV * RPW;
+  constexpr int UV = DS == 16 ? 4 : 8;
   const bf16_t* vnew = row + (a.H + a.Hkv + kvh) * DH + c0 + sub * 8;
   const bf16_t* vsl = vc + c0 + sub * 8;
   uint4 vpre[UV];
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   }
   __syncthreads();
   if (a.dbg == 3) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = f2bf(sc[0]); return; }
-  // ---- phase C: lanes 0-31 / 32-63 of a wave = the two 16-byte halves of 32 V row slices ----
+  // ---- phase C ----
   float acc[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g)
@@ -679,37 +686,59 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = row16_sum(acc[g][e]);
-      v += __shfl_xor(v, 16, 64);
+      float v = acc[g][e];
+      if constexpr (DS == 16) {
+        v = row16_sum(v);
+        v += __shfl_xor(v, 16, 64);
+      } else {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      }
       acc[g][e] = v;
     }
-  if ((lane & 31) == 0) {
+  if (DS == 16 ? (lane & 31) == 0 : lane < LPR) {
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[(wave * G + g) * DS + sub * 8 + e] = acc[g][e];
   }
   __syncthreads();
-  if (tid < G * DS) {
-    float s = red[tid];
+  for (int i = tid; i < G * DS; i += NT) {
+    float s = red[i];
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) s += red[w * G * DS + tid];
-    const int g = tid / DS, c = tid % DS;
+    for (int w = 1; w < NWV; ++w) s += red[w * G * DS + i];
+    const int g = i / DS, c = i % DS;
     a.o[(size_t)b * a.ldo + (kvh * G + g) * DH + c0 + c] = f2bf(s);
   }
 }
 
-template <int DH, int G>
-void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
-  const size_t smem = sizeof(float) * ((size_t)G * (a.Tmax + 1) + 8 * G * 16 + 8 * G + 8) + (size_t)(G + 1) * DH * 2 + 64;
+template <int DH, int G, int DS>
+void launch_dec_ds(hipStream_t s, const PcyDecAttnArgs& a) {
+  const size_t smem = sizeof(float) * ((size_t)G * (a.Tmax + 1) + 8 * G * DS + 8 * G + 8) + (size_t)(G + 1) * DH * 2 + 64;
   static size_t configured = 0;
   if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_kernel<DH, G>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_kernel<DH, G, DS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
   const int pfx = (a.pf0_bytes + a.pf1_bytes) > 0 ? (a.pf_blocks + a.Hkv * a.B - 1) / (a.Hkv * a.B) : 0;
-  hipLaunchKernelGGL((attn_dec_kernel<DH, G>), dim3(DH / 16 + pfx, a.Hkv, a.B), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((attn_dec_kernel<DH, G, DS>), dim3(DH / DS + pfx, a.Hkv, a.B), dim3(512), smem, s, a);
+}
+
+template <int DH, int G>
+void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
+  // widest slice that still leaves >= ~1 workgroup per CU (PCY_DEC_DS overrides, for measurements)
+  static const int force = [] { const char* e = getenv("PCY_DEC_DS"); return e ? atoi(e) : 0; }();
+  int ds = 16;
+  if constexpr (DH == 128) {
+    const int units = a.Hkv * a.B;
+    if (units >= 128) ds = 128;
+    else if (units >= 64) ds = 64;
+    if (force == 16 || force == 64 || force == 128) ds = force;
+    if (ds == 128) return launch_dec_ds<DH, G, 128>(s, a);
+    if (ds == 64) return launch_dec_ds<DH, G, 64>(s, a);
+  }
+  launch_dec_ds<DH, G, 16>(s, a);
 }
 
 template <int DH>

@@ -231,12 +231,15 @@ def test_rope(ctx, mode):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("H,Hkv,dh,t", [(32, 8, 128, 600), (8, 2, 64, 37), (4, 4, 32, 5), (8, 1, 128, 0)])
-def test_attn_decode(ctx, H, Hkv, dh, t):
-    """decode attention (rope + append + exact softmax) vs the oracle's eager formulas (llama_ref.layer_forward)."""
+@pytest.mark.parametrize("H,Hkv,dh,t,B", [(32, 8, 128, 600, 2), (8, 2, 64, 37, 2), (4, 4, 32, 5, 2), (8, 1, 128, 0, 2),
+                                           (32, 8, 128, 333, 9), (32, 8, 128, 1030, 20), (16, 8, 128, 65, 16),
+                                           (32, 8, 128, 0, 20)])
+def test_attn_decode(ctx, H, Hkv, dh, t, B):
+    """decode attention (rope + append + exact softmax) vs the oracle's eager formulas (llama_ref.layer_forward).
+    B x Hkv >= 64 / >= 128 select the 64- / 128-column workgroup slices."""
     from oracle import llama_ref as LR
     from procyon_amd.engine import rope_tables
-    B, Tmax = 2, t + 3
+    Tmax = t + 3
     qkv = rnd(B, (H + 2 * Hkv) * dh, seed=1)
     kc, vc = rnd(B, Hkv, Tmax, dh, seed=2), rnd(B, Hkv, Tmax, dh, seed=3)
     cos, sin = rope_tables(dh, 10000.0, Tmax + 1, "cpu")
