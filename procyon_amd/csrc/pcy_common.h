@@ -94,6 +94,21 @@ __device__ __forceinline__ float gelu_esm_chain(float x /* already bf16-valued *
   return rbf(t1 * t4);
 }
 
+// 8 bf16 x 8 bf16 -> fp32 (v_dot2c_f32_bf16 x 4) and the 16-byte non-temporal (streaming) weight load
+__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.x), __builtin_bit_cast(bf16pair, x.x), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.y), __builtin_bit_cast(bf16pair, x.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.z), __builtin_bit_cast(bf16pair, x.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.w), __builtin_bit_cast(bf16pair, x.w), acc, false);
+  return acc;
+}
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // Epilogue selectors shared by the GEMM (prefill / encoder) and GEMV (decode) kernels.
 enum PcyEpi : int {
   EPI_STORE = 0,      // y = bf16(acc [+ bias])

@@ -42,6 +42,17 @@ struct pcy_ctx {
   hipGraphExec_t graph = nullptr;
   const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int graph_B = 0;
+  bool graph_fused = false;
+  // persistent decode kernel: device copy of the per-layer weight pointers + progress flags
+  PcyFusedLayer* fused_tab = nullptr;
+  unsigned* fused_xch = nullptr;      // exchange storage: flags + tagged vectors + act (zeroed before every launch)
+  size_t fused_xch_words = 0;
+  unsigned* fused_err = nullptr;      // sticky error word
+  const void* fused_key[2] = {nullptr, nullptr};
+  int fused_L = 0;
+  int n_cu = 0;
+  unsigned long long* fused_trace = nullptr;   // PCY_FUSED_TRACE=<file>: wall-clock stamps of the last decode step
+  int fused_trace_n = 0;
 
   int reserve(size_t bytes) {
     if (bytes <= ws_bytes) return 0;
@@ -98,6 +109,94 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
 // ------------------------------------------------------------------ decode step (enqueue only)
 struct DecodeWs { bf16_t *x, *qkv, *ao, *act; };
 
+// PCY_DECODE_FUSED=1 selects the persistent decode kernel (pcy_decode.hip) for batch 1.  Off by default: on MI355X it
+// measures 3.41 ms/token against 3.38 for the layer-by-layer launches ("persistent decode kernel").
+// Read on every call so that one process can compare both paths.
+bool fused_enabled() {
+  const char* e = getenv("PCY_DECODE_FUSED");
+  return e && atoi(e) != 0;
+}
+
+bool fused_geometry(pcy_ctx* c, const pcy_llama_desc* m, int B, int Tmax, PcyFusedDecArgs& f) {
+  f = PcyFusedDecArgs{};
+  f.L = m->n_layers; f.vocab = m->vocab;
+  f.B = B; f.d = m->d; f.H = m->n_heads; f.Hkv = m->n_kv_heads; f.dh = m->head_dim; f.F = m->ffn; f.Tmax = Tmax;
+  const int units = B * m->n_kv_heads * (m->head_dim / 16);
+  f.n_attn = units < 64 ? units : 64;
+  f.n_stream = (c->n_cu < 256 ? c->n_cu : 256) - f.n_attn;
+  return c->n_cu >= 128 && pcy_fused_decode_supported(f);
+}
+
+bool fused_args(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B,
+                const bf16_t* x, PcyFusedDecArgs& f) {
+  if (!fused_enabled() || B != 1 || !c->fused_tab || !c->fused_xch) return false;
+  if (!fused_geometry(c, m, B, kv->Tmax, f)) return false;
+  if (pcy_fused_decode_words(f) > c->fused_xch_words) return false;
+  f.layers = c->fused_tab;
+  f.lm_head = (const bf16_t*)m->lm_head; f.final_norm = (const bf16_t*)m->final_norm; f.logits = (bf16_t*)st->logits;
+  f.x = x;
+  unsigned* w = c->fused_xch;
+  f.flags = w; w += 2 * PCY_FUSED_NFLAGS;
+  bf16_t* v = reinterpret_cast<bf16_t*>(w);
+  f.xres = v; v += f.d;
+  f.qkv = v; v += (size_t)(f.H + 2 * f.Hkv) * f.dh;
+  f.ao = v; v += f.d;
+  f.act = v;
+  f.err = c->fused_err;
+  f.kcache = (bf16_t*)kv->k; f.vcache = (bf16_t*)kv->v;
+  f.layer_stride = (size_t)kv->B * m->n_kv_heads * kv->Tmax * m->head_dim;
+  f.pos_dev = st->pos; f.cos_t = (const bf16_t*)m->rope_cos; f.sin_t = (const bf16_t*)m->rope_sin;
+  f.keep = st->keep; f.ld_keep = kv->Tmax;
+  f.rms_eps = m->rms_eps; f.rms_cast = m->rms_cast; f.scale = 1.0f / sqrtf((float)m->head_dim);
+  f.trace = c->fused_trace;
+  { static const int nw = [] { const char* e = getenv("PCY_FUSED_NOWAIT"); return e ? atoi(e) : 0; }(); f.nowait = nw; }
+  return true;
+}
+
+// device table of the per-layer weight pointers; must run outside stream capture
+int ensure_fused(pcy_ctx* c, const pcy_llama_desc* m) {
+  if (!fused_enabled()) return 0;
+  if (!c->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
+  if (!c->fused_err) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_err), 64));
+    HIP_TRY(hipMemset(c->fused_err, 0, 64));
+  }
+  {
+    PcyFusedDecArgs f;
+    if (fused_geometry(c, m, 1, 1, f) && pcy_fused_decode_words(f) > c->fused_xch_words) {
+      if (c->fused_xch) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->fused_xch)); c->fused_xch = nullptr; }
+      c->drop_graph();
+      c->fused_xch_words = pcy_fused_decode_words(f);
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_xch), c->fused_xch_words * sizeof(unsigned)));
+    }
+  }
+  const void* key[2] = {m, m->n_layers ? m->layers[0].wqkv : nullptr};
+  if (c->fused_tab && c->fused_L == m->n_layers && memcmp(key, c->fused_key, sizeof(key)) == 0) return 0;
+  if (c->fused_tab) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->fused_tab)); c->fused_tab = nullptr; }
+  c->drop_graph();
+  std::vector<PcyFusedLayer> tab(m->n_layers);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const pcy_llama_layer& L = m->layers[l];
+    tab[l] = PcyFusedLayer{(const bf16_t*)L.wqkv, (const bf16_t*)L.wo, (const bf16_t*)L.wgu, (const bf16_t*)L.wdown,
+                           (const bf16_t*)L.ln1, (const bf16_t*)L.ln2};
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_tab), tab.size() * sizeof(PcyFusedLayer) + 64));
+  HIP_TRY(hipMemcpy(c->fused_tab, tab.data(), tab.size() * sizeof(PcyFusedLayer), hipMemcpyHostToDevice));
+  memcpy(c->fused_key, key, sizeof(key));
+  c->fused_L = m->n_layers;
+  if (getenv("PCY_FUSED_TRACE")) {
+    if (c->fused_trace) HIP_TRY(hipFree(c->fused_trace));
+    c->fused_trace_n = 256 * ((4 * m->n_layers + 1) * 4 + m->n_layers * 2);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_trace), c->fused_trace_n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->fused_trace, 0, c->fused_trace_n * sizeof(unsigned long long)));
+  }
+  return 0;
+}
+
 size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
   const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
   return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
@@ -120,6 +219,13 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
   const bool batched = B > 4 && B <= 32 && d % 512 == 0 && F % 512 == 0;
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
+  PcyFusedDecArgs fa;
+  if (fused_args(c, m, kv, st, B, x, fa)) {
+    // one persistent launch for the whole step (pcy_decode.hip)
+    (void)hipMemsetAsync(c->fused_xch, 0, 2 * PCY_FUSED_NFLAGS * sizeof(unsigned), s);
+    pcy_launch_decode_fused(s, fa);
+    return;
+  }
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
@@ -133,16 +239,6 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
-    {
-      static const long pf_mb = [] { const char* e = getenv("PCY_PREFETCH_MB"); return e ? atol(e) : 0L; }();  // measured null on MI355X (nt weight loads do not benefit), off by default
-      const size_t wo_bytes = (size_t)d * H * dh * 2, wgu_bytes = (size_t)2 * F * d * 2;
-      size_t budget = (size_t)pf_mb << 20;
-      t.pf0 = L.wo; t.pf0_bytes = budget < wo_bytes ? budget : wo_bytes;
-      budget -= t.pf0_bytes;
-      t.pf1 = L.wgu; t.pf1_bytes = budget < wgu_bytes ? budget : wgu_bytes;
-      t.pf_blocks = 192;
-      if (pf_mb <= 0) { t.pf0_bytes = t.pf1_bytes = 0; }
-    }
     pcy_launch_attn_decode(s, t);
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
@@ -226,12 +322,35 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   hipStreamSynchronize(c->stream);
   c->drop_graph();
   if (c->ws) hipFree(c->ws);
+  if (c->fused_tab) hipFree(c->fused_tab);
+  if (c->fused_xch) hipFree(c->fused_xch);
+  if (c->fused_err) hipFree(c->fused_err);
+  if (c->fused_trace) hipFree(c->fused_trace);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
   delete c;
 }
-int pcy_ctx_sync(pcy_ctx* c) { HIP_TRY(hipStreamSynchronize(c->stream)); return 0; }
+int pcy_ctx_sync(pcy_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->fused_trace) {
+    std::vector<unsigned long long> t(c->fused_trace_n);
+    HIP_TRY(hipMemcpy(t.data(), c->fused_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* fp = fopen(getenv("PCY_FUSED_TRACE"), "w")) {
+      for (size_t i = 0; i < t.size(); ++i) fprintf(fp, "%llu\n", t[i]);
+      fclose(fp);
+    }
+  }
+  if (c->fused_err) {
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, c->fused_err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) {
+      HIP_TRY(hipMemset(c->fused_err, 0, sizeof(err)));
+      return fail(4, "persistent decode kernel: a cross-workgroup dependency wait timed out (results invalid)");
+    }
+  }
+  return 0;
+}
 int pcy_timer_start(pcy_ctx* c) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); return 0; }
 int pcy_timer_stop(pcy_ctx* c, float* ms) {
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -464,6 +583,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_fused(c, m)) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
@@ -478,6 +598,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
                      int use_graph) {
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_fused(c, m)) return r;
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       enqueue_decode(c, m, kv, st, B);
@@ -486,7 +607,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     return check_launch("pcy_llama_greedy");
   }
   const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
-  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != B) {
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != B || c->graph_fused != fused_enabled()) {
     c->drop_graph();
     hipGraph_t g = nullptr;
     hipStream_t user = c->stream;
@@ -503,6 +624,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     hipGraphDestroy(g);
     memcpy(c->graph_key, key, sizeof(key));
     c->graph_B = B;
+    c->graph_fused = fused_enabled();
   }
   for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
   return 0;

@@ -25,20 +25,6 @@ constexpr int GEMV_THREADS = 256;
 constexpr int GEMV_WAVES = 4;
 constexpr int XS_BYTES_MAX = 65536;
 
-__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.x), __builtin_bit_cast(bf16pair, x.x), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.y), __builtin_bit_cast(bf16pair, x.y), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.z), __builtin_bit_cast(bf16pair, x.z), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair, w.w), __builtin_bit_cast(bf16pair, x.w), acc, false);
-  return acc;
-}
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
-  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-  return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
 // RW = weight rows per wave (4, or 8 = 4 gate + 4 up for SwiGLU); UN = K-iterations in flight
 template <int NB, int EPI, bool RMS, int UN>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int KC) {

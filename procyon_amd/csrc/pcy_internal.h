@@ -66,9 +66,9 @@ struct PcyDecAttnArgs {
   const uint8_t* keep; int ld_keep;  // optional [B,Tmax] key-keep mask ("clean" mode) or null (reference quirk Q1)
   float* scratch;                 // [B*H*Tmax] fp32 probabilities workspace
   int B, H, Hkv, dh, Tmax; float scale; int dbg;
-  // optional weight prefetch riding on the idle CUs of this launch: extra workgroups (blockIdx.x >= dh/16) pull
-  // [pf0, pf0+pf0_bytes) and [pf1, pf1+pf1_bytes) through L2 into the 256 MiB Infinity Cache for the next GEMVs
-  const void* pf0; size_t pf0_bytes; const void* pf1; size_t pf1_bytes; int pf_blocks;
+  // persistent decode kernel only (zero otherwise): cache length + 1 if already known; `o` written through to memory
+  // with agent-scope stores
+  int t_plus1; int o_sc1;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 
@@ -84,3 +84,26 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps);
+
+// ---- persistent decode-step kernel (pcy_decode.hip), batch 1 ----
+struct PcyFusedLayer { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };   // wgu: gate/up interleaved by 16 rows
+constexpr int PCY_FUSED_NFLAGS = 256;   // progress flags of the streaming workgroups
+struct PcyFusedDecArgs {
+  const PcyFusedLayer* layers; int L;       // device table [L]
+  const bf16_t* lm_head; const bf16_t* final_norm; bf16_t* logits; int vocab;
+  const bf16_t* x;                          // [d] embedded token (written by the previous launch)
+  // vectors exchanged between workgroups inside the launch (agent-scope stores / loads, guarded by `flags`)
+  bf16_t *xres, *qkv, *ao, *act;            // residual stream [d], projections [(H+2Hkv)dh], attention output [H dh], [F]
+  bf16_t *kcache, *vcache; size_t layer_stride;   // layer l at + l*layer_stride, [B,Hkv,Tmax,dh]
+  const int32_t* pos_dev; const bf16_t *cos_t, *sin_t; const uint8_t* keep; int ld_keep;
+  unsigned* flags;                          // [2 * PCY_FUSED_NFLAGS] streaming, then attention workgroups; zero before every launch
+  unsigned* err;                            // sticky: != 0 after a dependency wait timed out (results invalid)
+  int B, d, H, Hkv, dh, F, Tmax; float rms_eps; int rms_cast; float scale;
+  int n_stream, n_attn;                     // workgroup roles; grid = n_stream + n_attn <= CU count
+  int nowait;                               // debug: skip every cross-workgroup wait (timing of the pure stream; results invalid)
+  unsigned long long* trace;                // optional [(4L+1)*4 + L*2] wall-clock stamps of workgroup 0 / attention wg 0
+};
+bool pcy_fused_decode_supported(const PcyFusedDecArgs& a);
+// 32-bit words of exchange storage (flags, then the exchanged vectors); the flags are zeroed before every launch
+size_t pcy_fused_decode_words(const PcyFusedDecArgs& a);
+void pcy_launch_decode_fused(hipStream_t s, const PcyFusedDecArgs& a);
