@@ -137,9 +137,19 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) f[kb] = *reinterpret_cast<const bf16x8*>(p + kb * 32);
     };
-    bf16x8 k0[KB], k1[KB];
-    load_tile(key_of(0, 0), k0);
-    load_tile(key_of(0, 1), k1);
+    // the key tiles of the first NP passes (NP x 256 keys) are all requested up front: each pass that fetched its own
+    // tiles paid a full memory round trip inside the dependent chain rope -> scores -> softmax -> P.V
+    constexpr int NP = DS == 16 ? 4 : 2;
+    bf16x8 kt[NP][2][KB];
+    auto load_group = [&](int j0) {
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+        if (pp == 0 || j0 + pp * PASS < nk) {
+          load_tile(key_of(j0 + pp * PASS, 0), kt[pp][0]);
+          load_tile(key_of(j0 + pp * PASS, 1), kt[pp][1]);
+        }
+    };
+    load_group(0);
     inputs_ready();
     // rope q (G heads) and the new key ONCE per block into LDS (bf16), then pick fragments from there
     for (int e = tid; e < (G + 1) * (DH / 8); e += NT) {
@@ -166,33 +176,33 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
       else qf[kb] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 
-    for (int j0 = 0; j0 < nk; j0 += PASS) {
-      bf16x8 n0[KB], n1[KB];
-      const bool more = j0 + PASS < nk;
-      if (more) { load_tile(key_of(j0 + PASS, 0), n0); load_tile(key_of(j0 + PASS, 1), n1); }
+    for (int j0 = 0; j0 < nk; j0 += NP * PASS) {
+      if (j0 > 0) load_group(j0);
 #pragma unroll
-      for (int tile = 0; tile < 2; ++tile) {
-        const int j = key_of(j0, tile);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int pp = 0; pp < NP; ++pp) {
+        const int jb = j0 + pp * PASS;
+        if (jb < nk) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          bf16x8 kf = tile == 0 ? k0[kb] : k1[kb];
-          if (j == t) kf = knf[kb];
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kb], kf, acc, 0, 0, 0);
-        }
-        // D[row = head = fq*4 + r][col = key fr]
-        if (j < nk) {
-          const bool kept = (keep && j < t) ? keep[j] != 0 : true;
+          for (int tile = 0; tile < 2; ++tile) {
+            const int j = key_of(jb, tile);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int head = fq * 4 + r;
-            if (head < G) sc[head * scld + j] = kept ? rbf(rbf(acc[r]) * a.scale) : PCY_BF16_MIN;
+            for (int kb = 0; kb < KB; ++kb) {
+              bf16x8 kf = kt[pp][tile][kb];
+              if (j == t) kf = knf[kb];
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kb], kf, acc, 0, 0, 0);
+            }
+            // D[row = head = fq*4 + r][col = key fr]
+            if (j < nk) {
+              const bool kept = (keep && j < t) ? keep[j] != 0 : true;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int head = fq * 4 + r;
+                if (head < G) sc[head * scld + j] = kept ? rbf(rbf(acc[r]) * a.scale) : PCY_BF16_MIN;
+              }
+            }
           }
         }
-      }
-      if (more) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) { k0[kb] = n0[kb]; k1[kb] = n1[kb]; }
       }
     }
   }
