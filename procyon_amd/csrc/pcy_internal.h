@@ -24,6 +24,7 @@ struct PcyGemmArgs {
   const bf16_t* resid;  // [M,N] ldr or null; may alias C
   int M, N, K, lda, ldc, ldr, epi;
   int gn;               // column tiles per rasterisation group (set by pcy_launch_gemm)
+  int dbg;              // timing experiments only (PCY_GEMM_DBG): 1 = no global->LDS loads after the prologue, 2 = no LDS fragment reads
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 
