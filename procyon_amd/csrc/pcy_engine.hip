@@ -501,9 +501,19 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_esm_layer& L = m->layers[l];
     pcy_launch_layernorm(s, x, (const bf16_t*)L.ln1_w, (const bf16_t*)L.ln1_b, xn, ntok, d, m->ln_eps);
-    linear(s, xn, d, (const bf16_t*)L.wqkv, (const bf16_t*)L.bqkv, nullptr, 0, qkv, 3 * d, ntok, 3 * d, d, EPI_STORE);
-    pcy_launch_rope(s, qkv, 3 * d, 0, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, qscale);
-    pcy_launch_rope(s, qkv, 3 * d, d, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, 0.f);
+    if (dh == 64 && ntok > 8 && d % 64 == 0) {
+      // rotary (q pre-scaled) fused into the projection's epilogue: saves a read+write pass over q and k
+      PcyGemmArgs g{};
+      g.A = xn; g.W = (const bf16_t*)L.wqkv; g.C = qkv; g.bias = (const bf16_t*)L.bqkv;
+      g.M = ntok; g.N = 3 * d; g.K = d; g.lda = d; g.ldc = 3 * d; g.epi = EPI_STORE;
+      g.rope_pos = pos; g.rope_cos = (const bf16_t*)m->rope_cos; g.rope_sin = (const bf16_t*)m->rope_sin;
+      g.rope_ncols = 2 * d; g.rope_qcols = d; g.rope_mode = m->rope_mode; g.rope_scale = qscale;
+      pcy_launch_gemm(s, g);
+    } else {
+      linear(s, xn, d, (const bf16_t*)L.wqkv, (const bf16_t*)L.bqkv, nullptr, 0, qkv, 3 * d, ntok, 3 * d, d, EPI_STORE);
+      pcy_launch_rope(s, qkv, 3 * d, 0, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, qscale);
+      pcy_launch_rope(s, qkv, 3 * d, d, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, 0.f);
+    }
     pcy_launch_transpose_v(s, qkv, 3 * d, 2 * d, H, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
     PcyAttnArgs t{};
     t.q = qkv; t.ldq = 3 * d; t.qcol0 = 0; t.k = qkv; t.ldk = 3 * d; t.kcol0 = d; t.vt = vt; t.vt_total = vt_total;

@@ -96,6 +96,82 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
     }
     return;
   }
+  if (EPI == EPI_STORE && a.rope_cos != nullptr) {
+    // fused rotary: a head = 4 consecutive 16-feature tiles, this lane holds features e..e+3 (tile t) and their partners
+    // e+32.. (tile t+2) of the same token.  All loads are issued in batches ahead of the arithmetic: bias once, the
+    // positions of the WTM tokens once, then per token its four cos and four sin quads (shared by every head).
+    constexpr int NH = WTN / 4;
+    float b1[NH][2][4], b2[NH][2][4];
+#pragma unroll
+    for (int hg = 0; hg < NH; ++hg)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n1 = n0 + wn * 64 + hg * 64 + t * 16 + fq * 4;
+        const int nc = (a.bias && n1 + 35 < a.N) ? n1 : 0;
+        const uint2 u1 = a.bias ? *reinterpret_cast<const uint2*>(a.bias + nc) : make_uint2(0, 0);
+        const uint2 u2 = a.bias ? *reinterpret_cast<const uint2*>(a.bias + nc + 32) : make_uint2(0, 0);
+        b1[hg][t][0] = lo_bf(u1.x); b1[hg][t][1] = hi_bf(u1.x); b1[hg][t][2] = lo_bf(u1.y); b1[hg][t][3] = hi_bf(u1.y);
+        b2[hg][t][0] = lo_bf(u2.x); b2[hg][t][1] = hi_bf(u2.x); b2[hg][t][2] = lo_bf(u2.y); b2[hg][t][3] = hi_bf(u2.y);
+      }
+    int pj[WTM];
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      pj[j] = a.rope_pos[m < a.M ? m : a.M - 1];
+    }
+    uint2 cs[WTM][2][4];   // [token][t][cos lo, cos hi, sin lo, sin hi]
+#pragma unroll
+    for (int j = 0; j < WTM; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int e = t * 16 + fq * 4;
+        const bf16_t* crow = a.rope_cos + (size_t)pj[j] * 64 + e;
+        const bf16_t* srow = a.rope_sin + (size_t)pj[j] * 64 + e;
+        cs[j][t][0] = *reinterpret_cast<const uint2*>(crow);
+        cs[j][t][1] = *reinterpret_cast<const uint2*>(crow + 32);
+        cs[j][t][2] = *reinterpret_cast<const uint2*>(srow);
+        cs[j][t][3] = *reinterpret_cast<const uint2*>(srow + 32);
+      }
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int hg = 0; hg < NH; ++hg) {
+        const int nh = n0 + wn * 64 + hg * 64;   // first feature of this head
+        if (nh >= a.N) continue;
+        const bool rot = nh < a.rope_ncols, scl = nh < a.rope_qcols;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int i1 = hg * 4 + t, i2 = i1 + 2;
+          const int n1 = nh + t * 16 + fq * 4, n2 = n1 + 32;
+          const uint2 c1 = cs[j][t][0], c2 = cs[j][t][1], s1 = cs[j][t][2], s2 = cs[j][t][3];
+          const float cc1[4] = {lo_bf(c1.x), hi_bf(c1.x), lo_bf(c1.y), hi_bf(c1.y)}, cc2[4] = {lo_bf(c2.x), hi_bf(c2.x), lo_bf(c2.y), hi_bf(c2.y)};
+          const float ss1[4] = {lo_bf(s1.x), hi_bf(s1.x), lo_bf(s1.y), hi_bf(s1.y)}, ss2[4] = {lo_bf(s2.x), hi_bf(s2.x), lo_bf(s2.y), hi_bf(s2.y)};
+          float o1[4], o2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float y1 = rbf(acc[i1][j][r] + b1[hg][t][r]), y2 = rbf(acc[i2][j][r] + b2[hg][t][r]);
+            if (rot) {
+              if (scl) { y1 = rbf(y1 * a.rope_scale); y2 = rbf(y2 * a.rope_scale); }
+              if (a.rope_mode == 0) {
+                o1[r] = rbf(rbf(y1 * cc1[r]) + rbf(-y2 * ss1[r]));
+                o2[r] = rbf(rbf(y2 * cc2[r]) + rbf(y1 * ss2[r]));
+              } else {
+                o1[r] = y1 * cc1[r] + (-y2) * ss1[r];
+                o2[r] = y2 * cc2[r] + y1 * ss2[r];
+              }
+            } else {
+              o1[r] = y1; o2[r] = y2;
+            }
+          }
+          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n1) = make_uint2(pack_bf(o1[0], o1[1]), pack_bf(o1[2], o1[3]));
+          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n2) = make_uint2(pack_bf(o2[0], o2[1]), pack_bf(o2[2], o2[3]));
+        }
+      }
+    }
+    return;
+  }
   // bias of this lane's 4 x 4 output features
   float bias[WTN][4];
 #pragma unroll

@@ -24,6 +24,10 @@ struct PcyGemmArgs {
   const bf16_t* resid;  // [M,N] ldr or null; may alias C
   int M, N, K, lda, ldc, ldr, epi;
   int gn;               // column tiles per rasterisation group (set by pcy_launch_gemm)
+  // optional rotary embedding fused into the EPI_STORE epilogue (head_dim 64 only): columns [0, rope_ncols) are heads
+  // of 64 features rotated with cos/sin rows of pos[token]; columns < rope_qcols are first multiplied by rope_scale and
+  // rounded (ESM q.dh^-1/2); rope_mode 0 = every product a bf16 tensor (HF Llama), 1 = fp32, rounded once (HF ESM)
+  const int32_t* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin; int rope_ncols, rope_qcols, rope_mode; float rope_scale;
   int dbg;              // timing experiments only (PCY_GEMM_DBG): 1 = no global->LDS loads after the prologue, 2 = no LDS fragment reads
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
