@@ -143,10 +143,13 @@ typedef struct {
 /* Prefill: embeds [B,T,d]; keep [B*T] uint8 attention_mask or NULL; pos[B*T] rotary positions
  * (reference: arange(T) per row, Q2); cu/vt_cu [B+1] = b*T / b*roundup(T,32).
  * logit_rows[n_logit_rows] = token rows (b*T+t) whose logits are wanted -> logits_out [n_logit_rows, vocab];
- * hidden_out (optional) [B*T,d] = hidden_states[-1] (final-normed). K/V of slots [0,T) are written. */
+ * hidden_out (optional) [B*T,d] = hidden_states[-1] (final-normed). K/V of slots [0,T) are written.
+ * sum_rows[n_sum_rows] (optional) -> hidden_sum_out [n_sum_rows, d] = sum over ALL L+1 hidden states of those token rows
+ * (ret_token_access='all', model_unified.py:560-563: fp32 accumulation, rounded once). */
 int pcy_llama_prefill(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const void* embeds, const uint8_t* keep,
                       const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T,
-                      const int32_t* logit_rows, int n_logit_rows, void* logits_out, void* hidden_out);
+                      const int32_t* logit_rows, int n_logit_rows, void* logits_out, void* hidden_out,
+                      const int32_t* sum_rows, int n_sum_rows, void* hidden_sum_out);
 typedef struct {
   int32_t* pos;              /* device scalar: cache length == rotary position of the next token (Q2) */
   int32_t* step;             /* device scalar: index of the next generated token */

@@ -70,7 +70,7 @@ SIGNATURES = {
     "pcy_retrieval_scores": (ci, [vp, vp, ci, vp, ci, ci, vp]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
-    "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp]),
+    "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp]),
     "pcy_llama_decode": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci]),
     "pcy_greedy_pick": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci]),
     "pcy_llama_greedy": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, ci]),

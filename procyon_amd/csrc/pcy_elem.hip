@@ -339,7 +339,29 @@ __global__ __launch_bounds__(NT) void copy_rows_kernel(const bf16_t* __restrict_
     *reinterpret_cast<uint4*>(dst + (size_t)r * ldd + k) = *reinterpret_cast<const uint4*>(src + (size_t)sr * lds_ + k);
 }
 
+// fp32 running sum of selected rows (ret_token_access='all': torch.stack(hidden_states, -1).sum(-1) accumulates the
+// L+1 bf16 states in fp32 and rounds once)
+__global__ __launch_bounds__(NT) void acc_rows_kernel(const bf16_t* __restrict__ src, int lds_, const int32_t* __restrict__ rows,
+                                                      float* __restrict__ acc, int d, int first) {
+  const int r = blockIdx.x;
+  const bf16_t* sp = src + (size_t)(rows ? rows[r] : r) * lds_;
+  for (int k = threadIdx.x; k < d; k += NT) {
+    const float v = bf2f(sp[k]);
+    acc[(size_t)r * d + k] = first ? v : acc[(size_t)r * d + k] + v;
+  }
+}
+__global__ __launch_bounds__(NT) void acc_finish_kernel(const float* __restrict__ acc, bf16_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) out[i] = f2bf(acc[i]);
+}
+
 }  // namespace
+
+void pcy_launch_acc_rows(hipStream_t s, const bf16_t* src, int lds_, const int32_t* rows, float* acc, int nrows, int d, int first) {
+  if (nrows > 0) hipLaunchKernelGGL(acc_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, rows, acc, d, first);
+}
+void pcy_launch_acc_finish(hipStream_t s, const float* acc, bf16_t* out, size_t n) {
+  if (n > 0) hipLaunchKernelGGL(acc_finish_kernel, dim3((unsigned)((n + NT - 1) / NT > 1024 ? 1024 : (n + NT - 1) / NT)), dim3(NT), 0, s, acc, out, n);
+}
 
 void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int d, float eps, int cast) {
   if (rows > 0) hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, y, d, eps, cast);

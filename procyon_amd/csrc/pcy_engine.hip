@@ -531,7 +531,8 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
 
 int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
                       const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
-                      int n_logit_rows, void* logits_out, void* hidden_out) {
+                      int n_logit_rows, void* logits_out, void* hidden_out, const int32_t* sum_rows, int n_sum_rows,
+                      void* hidden_sum_out) {
   const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
   if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_llama_prefill: head_dim %d unsupported (32/64/128)", dh);
   if (d % 64 || F % 64 || (H * dh) % 64 || (Hkv * dh) % 64) return fail(1, "pcy_llama_prefill: d, ffn, H*dh, Hkv*dh must be multiples of 64");
@@ -542,7 +543,8 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   const int vt_total = B * Tp;
   const size_t need = align_up((size_t)M * d * 2, 256) * 2 + align_up((size_t)M * qkvw * 2, 256) + align_up((size_t)M * H * dh * 2, 256) +
                       align_up((size_t)M * F * 2, 256) + align_up((size_t)Hkv * dh * vt_total * 2, 256) +
-                      align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + 4096;
+                      align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + align_up((size_t)(n_sum_rows + 1) * d * 6, 256) + 4096;
+  if (n_sum_rows > 0 && (!sum_rows || !hidden_sum_out)) return fail(1, "pcy_llama_prefill: sum_rows / hidden_sum_out missing");
   if (int r = c->reserve(need)) return r;
   Carver cv(c->ws);
   bf16_t* x = cv.take<bf16_t>((size_t)M * d);
@@ -552,8 +554,12 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   bf16_t* act = cv.take<bf16_t>((size_t)M * F);
   bf16_t* vt = cv.take<bf16_t>((size_t)Hkv * dh * vt_total);
   bf16_t* lastx = cv.take<bf16_t>((size_t)(n_logit_rows + 1) * d);
+  float* hsum = cv.take<float>((size_t)(n_sum_rows + 1) * d);      // ret_token_access='all': fp32 sum of the L+1 hidden states
+  bf16_t* hsum_tmp = cv.take<bf16_t>((size_t)(n_sum_rows + 1) * d);
   hipStream_t s = c->stream;
   HIP_TRY(hipMemcpyAsync(x, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  // hidden_states = (embeddings, output of layers 0..L-2, final-normed output of layer L-1)  [HF LlamaModel.forward]
+  pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 1);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
@@ -578,8 +584,15 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
       linear(s, xn, d, (const bf16_t*)L.wgu, nullptr, nullptr, 0, act, F, M, 2 * F, d, EPI_SWIGLU);
     }
     linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID);
+    if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
   }
   if (hidden_out) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, (bf16_t*)hidden_out, M, d, m->rms_eps, m->rms_cast);
+  if (n_sum_rows > 0) {
+    pcy_launch_copy_rows(s, x, d, hsum_tmp, d, sum_rows, n_sum_rows, d);
+    pcy_launch_rmsnorm(s, hsum_tmp, (const bf16_t*)m->final_norm, hsum_tmp, n_sum_rows, d, m->rms_eps, m->rms_cast);
+    pcy_launch_acc_rows(s, hsum_tmp, d, nullptr, hsum, n_sum_rows, d, 0);
+    pcy_launch_acc_finish(s, hsum, (bf16_t*)hidden_sum_out, (size_t)n_sum_rows * d);
+  }
   if (n_logit_rows > 0 && logits_out) {
     pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
     PcyGemvArgs h{};

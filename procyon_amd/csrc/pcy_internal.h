@@ -89,6 +89,9 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps);
+// acc[r][:] (fp32) = / += src[rows[r]][:]; out = bf16(acc)
+void pcy_launch_acc_rows(hipStream_t s, const bf16_t* src, int lds, const int32_t* rows, float* acc, int nrows, int d, int first);
+void pcy_launch_acc_finish(hipStream_t s, const float* acc, bf16_t* out, size_t n);
 
 // ---- persistent decode-step kernel (pcy_decode.hip), batch 1 ----
 struct PcyFusedLayer { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };   // wgu: gate/up interleaved by 16 rows

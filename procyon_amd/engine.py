@@ -292,8 +292,10 @@ class LlamaEngine:
         sm = None if soft_map is None else soft_map.to(self.device, torch.int32).contiguous().view(-1)
         return self.ctx.embed_splice(self.embed, i32, soft, sm).view(B, T, self.cfg.d)
 
-    def prefill(self, embeds, attn_mask, cache: KVCache, logit_rows="last", want_hidden=False):
-        """embeds [B,T,d] bf16; attn_mask [B,T] (0/1) or None.  Returns (logits [n,V], hidden [B,T,d]|None)."""
+    def prefill(self, embeds, attn_mask, cache: KVCache, logit_rows="last", want_hidden=False, sum_rows=None):
+        """embeds [B,T,d] bf16; attn_mask [B,T] (0/1) or None.  Returns (logits [n,V], hidden [B,T,d]|None), and with
+        `sum_rows` (flat token rows b*T+t) additionally the sum over all L+1 hidden states of those rows [n,d]
+        (ret_token_access='all')."""
         B, T, d = embeds.shape
         embeds = embeds.contiguous()
         _chk_bf16(embeds)
@@ -314,8 +316,14 @@ class LlamaEngine:
         n = rows.numel()
         logits = torch.empty(n, self.cfg.vocab, dtype=BF16, device=dev)
         hidden = torch.empty(B, T, d, dtype=BF16, device=dev) if want_hidden else None
+        srows = None if sum_rows is None else sum_rows.to(dev, torch.int32).contiguous()
+        ns = 0 if srows is None else srows.numel()
+        hsum = torch.empty(ns, d, dtype=BF16, device=dev) if ns else None
         L.check(self.ctx.lib.pcy_llama_prefill(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(embeds), _p(keep), _p(pos),
-                                               _p(cu), _p(vt_cu), B, T, _p(rows), n, _p(logits), _p(hidden)), "pcy_llama_prefill")
+                                               _p(cu), _p(vt_cu), B, T, _p(rows), n, _p(logits), _p(hidden), _p(srows), ns, _p(hsum)),
+                "pcy_llama_prefill")
+        if sum_rows is not None:
+            return logits, hidden, hsum
         return logits, hidden
 
     def decode(self, cache: KVCache, st: GenState, B):

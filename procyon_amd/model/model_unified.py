@@ -286,17 +286,21 @@ class UnifiedProCyon:
                 all_masks |= mask_before(full_labels, self.answer_idx, before_last_answer=True)
             full_labels = torch.where(all_masks, -100, full_labels)
             answer_pos = torch.tensor([int((input_ids[i] == self.answer_idx).nonzero()[:, 0].max()) for i in range(B)])
+        if retrieval and self.config.ret_token_access not in ('last', 'all'):
+            raise NotImplementedError("Invalid option {} for ret_token_access".format(self.config.ret_token_access))
+        sum_all = retrieval and self.config.ret_token_access == 'all'
+        ret_rows = ret_idx[:, :real].reshape(-1).nonzero()[:, 0] if sum_all else None   # flat b*T + t, row-major like boolean indexing
         outputs = self.text_encoder(input_embeds=emb, attn_masks=attn_masks[:, :real], full_labels=full_labels,
                                     logit_positions=answer_pos if not retrieval else torch.zeros(B, dtype=torch.long),
-                                    want_hidden=retrieval)
+                                    want_hidden=retrieval and not sum_all, hidden_sum_positions=ret_rows)
         out = {'outputs': outputs, 'text_toks': input_ids, 'full_labels': full_labels if get_full_labels else None,
                'contrastive_out': None, 'contrastive_loss': None, 'answer_positions': answer_pos}
         if retrieval:
-            if self.config.ret_token_access != 'last':
-                raise NotImplementedError("ret_token_access='all' (sum of all hidden states) is not built; shipped "
-                                          "ProCyon-Full uses 'last' (configs/llama3-full.yml:53)")
-            hidden = outputs.hidden_states[-1]
-            extracted = hidden[ret_idx[:, :real].to(hidden.device)]
+            if sum_all:   # torch.stack(hidden_states, -1).sum(-1)[ret] (model_unified.py:560-563), computed at the [PROT] rows only
+                extracted = outputs.hidden_state_sum_rows
+            else:
+                hidden = outputs.hidden_states[-1]
+                extracted = hidden[ret_idx[:, :real].to(hidden.device)]
             shared_lm = self.aaseq_lm_projector(extracted)
             c = {"positive": {}, "negative": {}}
             if inputs["target"]["text"] is None:

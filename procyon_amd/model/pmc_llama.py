@@ -44,7 +44,7 @@ class LlamaPostTokenization:
         return self.engine.embed
 
     def forward(self, input_embeds=None, input_ids=None, attn_masks=None, full_labels=None, past_key_values=None,
-                use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True):
+                use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None):
         assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
         eng = self.engine
         if past_key_values is None:
@@ -56,10 +56,16 @@ class LlamaPostTokenization:
                 rows = torch.arange(B * T, dtype=torch.int32)
             else:
                 rows = (torch.arange(B) * T + logit_positions.cpu().long()).to(torch.int32)
-            logits, hidden = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden)
+            hsum = None
+            if hidden_sum_positions is not None:
+                # ret_token_access='all': sum of all L+1 hidden states, only at the requested flat token rows
+                logits, hidden, hsum = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden,
+                                                   sum_rows=hidden_sum_positions)
+            else:
+                logits, hidden = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden)
             logits = logits.view(B, -1, self.cfg.vocab)
             past = _Past(cache, T) if use_cache else None
-            return SimpleNamespace(logits=logits, past_key_values=past, hidden_states=(hidden,), loss=None)
+            return SimpleNamespace(logits=logits, past_key_values=past, hidden_states=(hidden,), hidden_state_sum_rows=hsum, loss=None)
         # cached decode: one new token per row, no mask, position = cache length (quirks Q1/Q2)
         assert input_ids is not None and input_ids.shape[1] == 1, "cached decode takes input_ids [B,1]"
         cache, t = past_key_values.cache, past_key_values.t

@@ -123,6 +123,15 @@ def test_forward_retrieval_and_qa(env):
     out = m.forward(inp, retrieval=True)
     got = out["contrastive_out"]["positive"]["text"]
     assert got.shape == ref.shape and rel_err(got.cpu(), ref) < 1e-2
+    # ret_token_access='all' (the ModelArgs default, training_args_IT.py:173): sum of all L+1 hidden states at [PROT]
+    ref_all = PR.retrieval_text_embedding(r["hidden_states"], ret[:, :real], w["projs"]["lm"], "all")
+    m.config.ret_token_access = "all"
+    try:
+        got_all = m.forward(inp, retrieval=True)["contrastive_out"]["positive"]["text"]
+    finally:
+        m.config.ret_token_access = "last"
+    assert got_all.shape == ref_all.shape and rel_err(got_all.cpu(), ref_all) < 1e-2
+    assert rel_err(got_all.cpu(), ref_all) < 0.5 * rel_err(got_all.cpu(), ref)   # ... and not the 'last' embedding
     # QA: yes/no probabilities at the last [ANSWER] position
     instr = ["w1 <|protein|> is w2 ? [ANSWER] yes w3 <|protein|> ? [ANSWER]", "w4 <|protein|> ? [ANSWER]"]
     inp = _inputs(m, env["prot"], instr, [[0, 1], [1]], text_slots=[[], []])
