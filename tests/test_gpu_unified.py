@@ -190,3 +190,73 @@ def test_checkpoint_ingest_builds_identical_model(env):
     t1 = m.generate(_inputs(m, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
     t2 = m2.generate(_inputs(m2, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
     assert torch.equal(t1, t2)
+
+
+def test_config4_shape_mixed_lengths_ragged_batch(env):
+    """BASELINE configs[3] in miniature: a batch of prompts of different lengths (left-padded, reference quirks Q1/Q2),
+    proteins of mixed lengths of which some exceed max_protein_len (chunk splitting + cross-chunk pooling), greedy decode.
+    Per row: step-0 logits at the noise bar, tokens equal up to the first near-tie of the oracle."""
+    from oracle import llama_ref as LR
+    from oracle import procyon_ref as PR
+    from procyon_amd import synth
+    m, w = env["model"], env["w"]
+    mpl = 64
+    prot = synth.protein_tokens([30, 70, 150, 41, 129, 64], seed=11)     # 70, 150, 129 > 64 residues -> 2-3 chunks
+    old = m.protein_seq_encoder.max_protein_len
+    m.protein_seq_encoder.max_protein_len = mpl
+    try:
+        instr = ["w1 <|protein|> w2 w3 w4 w5 w6 describe [ANSWER]", "<|protein|> [ANSWER]",
+                 "w7 w8 <|protein|> and <|protein|> w9 [ANSWER]", "w2 w2 w2 w3 w3 w3 w4 w4 w4 <|protein|> [ANSWER]",
+                 "w5 <|protein|> [ANSWER]"]
+        slots = [[0], [1], [2, 3], [4], [5]]
+        inputs = _inputs(m, prot, instr, slots, text_slots=[[] for _ in instr])
+        z = PR.esm_plm_forward(w["esm"], env["egeom"], prot, pooling="mean", max_protein_len=mpl)
+        soft = PR.mlp_forward(z[[i for r in slots for i in r]], w["projs"]["aaseq"])
+        ids, mask = m._prepare_text_inputs_and_tokenize(list(instr), [[] for _ in instr], crop_off=True, no_pad=True, left_pad=True)
+        assert len(set(mask.sum(1).tolist())) > 2, "prompts must be ragged"
+        emb, _ = PR.prepare_input_embeddings(w["llama"]["model.embed_tokens.weight"], ids.long(), m.prot_replacement_idx, soft,
+                                             ret_idx=m.prot_retrieval_idx)
+        N = 8
+        tok_ref, lg_ref, _ = LR.greedy_generate(w["llama"], env["lgeom"], emb, mask, N)
+        tokens, _, logits, _ = m.generate(_inputs(m, prot, instr, slots, text_slots=[[] for _ in instr]), max_len=N, method="greedy")
+    finally:
+        m.protein_seq_encoder.max_protein_len = old
+    assert tokens.shape == (5, 1, N)
+    for b in range(5):
+        assert rel_err(logits[b, 0, 0], lg_ref[b, 0]) < 1e-2, b
+        for s_ in range(N):
+            if tokens[b, 0, s_] != tok_ref[b, s_]:
+                top2 = lg_ref[b, s_].float().topk(2).values
+                noise = float((logits[b, 0, s_].float() - lg_ref[b, s_].float()).abs().max())
+                assert float(top2[0] - top2[1]) <= 4 * noise, (b, s_)
+                break
+
+
+def test_config5_shape_pair_scoring_with_in_context_examples(env):
+    """BASELINE configs[4] in miniature (bf16; there is no reference counterpart for fp8): QA prompts with SIX protein
+    slots each -- a positive and a negative in-context pair plus the query pair (instruct_constructor.py:124-145,
+    protpep_qa_scores.py:129-193) -- scored as P(yes), P(no) at the last [ANSWER]."""
+    from oracle import llama_ref as LR
+    from oracle import procyon_ref as PR
+    from procyon_amd import synth
+    m, w = env["model"], env["w"]
+    prot = synth.protein_tokens([80, 12, 80, 9, 80, 15, 11], seed=5)     # receptor-like + short peptides
+    tmpl = ("w1 <|protein|> binds <|protein|> ? [ANSWER] yes w2 <|protein|> binds <|protein|> ? [ANSWER] no "
+            "w3 <|protein|> binds <|protein|> ? [ANSWER]")
+    instr = [tmpl, tmpl, tmpl]
+    slots = [[0, 1, 2, 3, 4, 5], [0, 1, 2, 3, 4, 6], [0, 1, 2, 3, 0, 3]]      # the query pair changes, the examples do not
+    inp = _inputs(m, prot, instr, slots, text_slots=[[], [], []])
+    z = PR.esm_plm_forward(w["esm"], env["egeom"], prot, pooling="mean")
+    soft = PR.mlp_forward(z[[i for r in slots for i in r]], w["projs"]["aaseq"])
+    ids, mask = m._prepare_text_inputs_and_tokenize(list(instr), [[], [], []], crop_off=False, no_pad=False, left_pad=False)
+    emb, _ = PR.prepare_input_embeddings(w["llama"]["model.embed_tokens.weight"], ids.long(), m.prot_replacement_idx, soft,
+                                         ret_idx=m.prot_retrieval_idx)
+    real = int(mask.sum(1).max())
+    r = LR.llama_forward(w["llama"], env["lgeom"], inputs_embeds=emb[:, :real], attn_mask=mask[:, :real])
+    yes_ref, no_ref, _ = PR.qa_yes_no_probs(r["logits"], ids[:, :real], m.answer_idx, m.yes_token, m.no_token)
+    out = m.forward(inp, retrieval=False)
+    probs = out["outputs"].logits[:, 0].softmax(-1).cpu()
+    assert torch.allclose(probs[:, m.yes_token].float(), yes_ref.float(), rtol=0.05, atol=1e-6)
+    assert torch.allclose(probs[:, m.no_token].float(), no_ref.float(), rtol=0.05, atol=1e-6)
+    # rows 0 and 1 differ only in the last slot -> different scores; the engine must not have mixed up the slot order
+    assert not torch.allclose(probs[0], probs[1])
