@@ -114,3 +114,137 @@ def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_he
                           protein_seq_embeddings=tabs.get("protein_seq_embeddings"), domain_embeddings=tabs.get("domain_embeddings"),
                           peptide_embeddings=tabs.get("peptide_embeddings"), protein_struct_embeddings=tabs.get("protein_struct_embeddings"),
                           drug_structure_embeddings=tabs.get("drug_structure_embeddings"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `UnifiedProCyon.from_pretrained` / `get_checkpoint_configs` (model_unified.py:1296-1406)
+
+class ArgsShell:
+    """Stand-in for the reference's pickled dataclasses (`procyon.training.training_args_IT.ModelArgs` / `DataArgs` /
+    `TrainArgs`): `model_args.pt` & co. are `torch.save`d dataclass INSTANCES, so unpickling them needs those classes
+    importable.  The shell receives the instance dictionary; attribute access works as on the original."""
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(f'{k}={v!r}' for k, v in sorted(vars(self).items()))})"
+
+
+class _ShellPickle:
+    """`pickle_module` for torch.load: any class under `procyon.*` (or otherwise not importable) becomes an ArgsShell
+    subclass named after it."""
+    import pickle as _pickle
+    __name__ = "procyon_amd.checkpoint._ShellPickle"
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] != "procyon":
+                try:
+                    return super().find_class(module, name)
+                except (ImportError, AttributeError):
+                    pass
+            return type(name, (ArgsShell,), {"__module__": module})
+
+    @staticmethod
+    def load(f, **kw):
+        return _ShellPickle.Unpickler(f, **kw).load()
+
+    Pickler = _pickle.Pickler
+    dump, dumps, loads = _pickle.dump, _pickle.dumps, _pickle.loads
+
+
+def load_args(path):
+    """one of model_args.pt / data_args.pt / training_args.pt"""
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
+
+
+def get_checkpoint_configs(resume_from_checkpoint):
+    """`UnifiedProCyon.get_checkpoint_configs` (model_unified.py:1396-1406): (data_args, model_args, train_args)."""
+    import os
+    return tuple(load_args(os.path.join(resume_from_checkpoint, n)) for n in ("data_args.pt", "model_args.pt", "training_args.pt"))
+
+
+def config_from_model_args(args):
+    """ModelArgs (training_args_IT.py:27-651) -> the fields of it the inference path reads."""
+    from dataclasses import fields
+    from .model import ProCyonConfig
+    kw = {f.name: getattr(args, f.name) for f in fields(ProCyonConfig) if hasattr(args, f.name)}
+    return ProCyonConfig(**kw)
+
+
+def hf_tokenizer(path):
+    """`_init_tokenizer` (model_unified.py:1088-1133): Llama tokenizer files + the eight added tokens IN THIS ORDER
+    ([EXT] last: the embedding table has len(tokenizer) - 1 rows, :166)."""
+    import transformers
+    tok = transformers.AutoTokenizer.from_pretrained(path)
+    tok.padding_side = "right"
+    if tok.sep_token is None:
+        tok.add_tokens("[CLS]")
+        tok.sep_token = "[CLS]"
+    if tok.pad_token is None:
+        tok.add_tokens("[PAD]")
+        tok.pad_token = "[PAD]"
+    for t in ("<|protein|>", "[PROT]", "[ANSWER]", "<|struct|>", "<|drug|>", "[EXT]"):
+        tok.add_tokens(t)
+    return tok
+
+
+def from_pretrained(*, pretrained_weights_dir=None, checkpoint_dir=None, model=None, config_only=False, config=None,
+                    state_dict_relative_path="txllm_model_ckpt.pt", strict_load=False, load_plm_directly=False,
+                    protein_pooling_correction_option=False, tokenizer=None, device="cuda", max_new_tokens=256, **engine_kw):
+    """`UnifiedProCyon.from_pretrained` (model_unified.py:1296-1394) -> (model, config).
+
+    Same keyword contract for what inference uses.  Differences: `model=` (update an existing module in place) is not
+    supported -- the engine packs weights at construction; a checkpoint that only holds DeepSpeed ZeRO shards must be
+    consolidated first (`zero_to_fp32.py`, shipped inside every DeepSpeed checkpoint directory); `tokenizer=` may supply
+    the tokenizer object when the Llama tokenizer files are not at $LLAMA3_PATH / pretrained_weights_dir."""
+    import os
+    if model is not None:
+        raise NotImplementedError("from_pretrained(model=...): in-place reload is not supported by the engine-backed model")
+    config_checkpoint = load_args(os.path.join(checkpoint_dir, "model_args.pt"))
+    data_args = load_args(os.path.join(checkpoint_dir, "data_args.pt"))   # noqa: F841 (read like the reference; paths are re-rooted there)
+    if config is None:
+        config = config_checkpoint
+    if config_only:
+        return None, config
+    config.n_model_pieces = 1
+    config.model_splitting = False
+    if load_plm_directly and getattr(config, "use_aaseq_embeddings", False):
+        # the checkpoint was trained on cached ESM embeddings: run the encoder they came from instead (:1343-1366)
+        assert config.protein_seq_embeddings_path is not None
+        aaseq_type, nparams_name, pooling_method = os.path.basename(config.protein_seq_embeddings_path).split(".")[0].split("_")
+        assert pooling_method in ("max", "mean")
+        if nparams_name == "esm2-3b":
+            nparams = "3b"
+        elif nparams_name == "esm-650m":
+            nparams = "650m"
+        else:
+            raise NotImplementedError("Invalid number of parameters")
+        config.use_aaseq_embeddings = False
+        config.freeze_protein_encoder = "all"
+        config.protein_encoder_num_params = nparams
+        config.protein_pooling_opt = pooling_method
+        config.long_protein_strategy = "split"
+        config.max_protein_len = 1024
+        config.protein_enc_batch_limit = None
+        config.protein_pooling_correction_option = protein_pooling_correction_option
+    sd_path = os.path.join(checkpoint_dir, state_dict_relative_path)
+    if not os.path.exists(sd_path):
+        raise NotImplementedError(f"{sd_path} not found: consolidate the DeepSpeed ZeRO shards with the checkpoint's zero_to_fp32.py first")
+    sd = torch.load(sd_path, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
+    if not any(k.startswith("protein_seq_encoder.model.") for k in sd) and not getattr(config, "use_aaseq_embeddings", False):
+        # frozen encoder loaded from the fair-esm release file next to the other pretrained weights (esm.py:378-398)
+        name = {"650m": "esm2_t33_650M_UR50D.pt", "3b": "esm2_t36_3B_UR50D.pt", "35m": "esm2_t12_35M_UR50D.pt",
+                "8m": "esm2_t6_8M_UR50D.pt"}.get(str(getattr(config, "protein_encoder_num_params", "650m")).lower())
+        path = None if name is None or pretrained_weights_dir is None else os.path.join(pretrained_weights_dir, name)
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError(f"protein encoder weights are neither in the checkpoint nor at {path}")
+        esm_sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+        esm_sd = {re.sub(r"^(encoder\.)?(sentence_encoder\.)?", "", k): v for k, v in esm_sd.items()}
+        sd = dict(sd, **{"protein_seq_encoder.model." + k: v for k, v in esm_sd.items()})
+    if tokenizer is None:
+        fname = str(getattr(config, "text_encoder_fname", ""))
+        path = os.getenv("LLAMA3_PATH") if "llama-3" in fname.lower() else os.path.join(pretrained_weights_dir or "", fname)
+        if not path or not os.path.exists(path):
+            raise FileNotFoundError(f"Llama tokenizer files not found at {path!r}; pass tokenizer=")
+        tokenizer = hf_tokenizer(path)
+    m = build_model(sd, config_from_model_args(config), tokenizer, device=device, max_new_tokens=max_new_tokens, **engine_kw)
+    return m, config

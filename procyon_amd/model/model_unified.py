@@ -319,6 +319,18 @@ class UnifiedProCyon:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
+    @staticmethod
+    def from_pretrained(**kw):
+        """`UnifiedProCyon.from_pretrained` (model_unified.py:1296-1394); see procyon_amd.checkpoint.from_pretrained."""
+        from ..checkpoint import from_pretrained
+        return from_pretrained(**kw)
+
+    @staticmethod
+    def get_checkpoint_configs(resume_from_checkpoint):
+        """(data_args, model_args, train_args) (model_unified.py:1396-1406)"""
+        from ..checkpoint import get_checkpoint_configs
+        return get_checkpoint_configs(resume_from_checkpoint)
+
     def forward_sequences(self, seq_input, get_soft_tokens=False, aaseq_type="protein"):
         """`forward_sequences` (model_unified.py:1029-1086)."""
         if isinstance(seq_input, dict):

@@ -190,6 +190,23 @@ def test_checkpoint_ingest_builds_identical_model(env):
     t1 = m.generate(_inputs(m, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
     t2 = m2.generate(_inputs(m2, env["prot"], instr, [[0]], text_slots=[[]]), max_len=6, method="greedy")[0]
     assert torch.equal(t1, t2)
+    # ... and through the reference's entry point: a checkpoint directory with model_args.pt / data_args.pt /
+    # txllm_model_ckpt.pt -> UnifiedProCyon.from_pretrained(...) -> (model, config)
+    import os
+    import tempfile
+    from types import SimpleNamespace
+    from procyon_amd.model import UnifiedProCyon
+    with tempfile.TemporaryDirectory() as d:
+        torch.save(SimpleNamespace(protein_pooling_opt="mean", max_protein_len=1024, ret_token_access="last", use_aaseq_embeddings=False,
+                                   text_encoder_fname="llama-3-8b"), os.path.join(d, "model_args.pt"))
+        torch.save(SimpleNamespace(data_dir="/x"), os.path.join(d, "data_args.pt"))
+        torch.save(sd, os.path.join(d, "txllm_model_ckpt.pt"))
+        m3, cfg = UnifiedProCyon.from_pretrained(pretrained_weights_dir=d, checkpoint_dir=d, tokenizer=m.tokenizer, max_new_tokens=16,
+                                                 esm_heads=2, head_dim=64, max_pos=4096)
+    assert cfg.protein_pooling_opt == "mean" and cfg.n_model_pieces == 1
+    c = m3.forward_sequences(env["prot"], get_soft_tokens=True)
+    for k in ("original", "shared", "token"):
+        assert torch.equal(a[k], c[k]), k
 
 
 def test_config4_shape_mixed_lengths_ragged_batch(env):

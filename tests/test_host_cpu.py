@@ -107,3 +107,57 @@ def test_checkpoint_key_mapping():
     assert (lc.vocab, lc.d, lc.n_layers, lc.n_heads, lc.n_kv_heads, lc.ffn) == (50, 256, 2, 2, 1, 512)
     ec = infer_esm_config(parts["esm"], n_heads=4)
     assert (ec.d, ec.n_layers, ec.ffn) == (64, 2, 128)
+
+
+def test_checkpoint_args_load_without_reference_package(tmp_path):
+    """model_args.pt / data_args.pt / training_args.pt are pickled instances of the reference's dataclasses
+    (`procyon.training.training_args_IT.*`); they must load here, where that package does not exist, and
+    `from_pretrained(config_only=True)` / `get_checkpoint_configs` must return them with their attributes."""
+    import dataclasses
+    import sys
+    import types
+    import torch
+    from procyon_amd.checkpoint import config_from_model_args, from_pretrained, get_checkpoint_configs
+    mod = types.ModuleType("procyon.training.training_args_IT")
+
+    @dataclasses.dataclass
+    class ModelArgs:
+        text_encoder_fname: str = "llama-3-8b"
+        protein_pooling_opt: str = "mean"
+        max_protein_len: int = 1024
+        ret_token_access: str = "last"
+        use_aaseq_embeddings: bool = False
+        protein_encoder_num_params: str = "650m"
+
+    @dataclasses.dataclass
+    class DataArgs:
+        data_dir: str = "/somewhere/else"
+
+    @dataclasses.dataclass
+    class TrainArgs:
+        learning_rate: float = 1e-4
+
+    for cls in (ModelArgs, DataArgs, TrainArgs):
+        cls.__module__ = mod.__name__
+        cls.__qualname__ = cls.__name__
+        setattr(mod, cls.__name__, cls)
+    pkgs = ["procyon", "procyon.training", "procyon.training.training_args_IT"]
+    try:
+        for i, name in enumerate(pkgs):
+            sys.modules[name] = mod if i == 2 else types.ModuleType(name)
+        torch.save(ModelArgs(protein_pooling_opt="max", ret_token_access="all"), tmp_path / "model_args.pt")
+        torch.save(DataArgs(), tmp_path / "data_args.pt")
+        torch.save(TrainArgs(), tmp_path / "training_args.pt")
+    finally:
+        for name in pkgs:
+            sys.modules.pop(name, None)
+    data_args, model_args, train_args = get_checkpoint_configs(str(tmp_path))
+    assert type(model_args).__name__ == "ModelArgs" and model_args.protein_pooling_opt == "max" and model_args.ret_token_access == "all"
+    assert data_args.data_dir == "/somewhere/else" and train_args.learning_rate == 1e-4
+    none, cfg = from_pretrained(checkpoint_dir=str(tmp_path), config_only=True)
+    assert none is None and cfg.max_protein_len == 1024
+    pc = config_from_model_args(cfg)
+    assert pc.protein_pooling_opt == "max" and pc.ret_token_access == "all" and pc.use_aaseq_embeddings is False
+    import pytest
+    with pytest.raises(NotImplementedError, match="zero_to_fp32"):
+        from_pretrained(checkpoint_dir=str(tmp_path))
