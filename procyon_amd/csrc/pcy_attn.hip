@@ -18,7 +18,16 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // QT = 16-row query tiles per wave: the K / Vt fragments of a 32-key block are loaded once and reused by all QT tiles
 // (QT x fewer L2 requests per MFMA); the next block's fragments are prefetched while the current one is consumed.
-template <int DH, int QT, bool PF>
+// SCALED = false when the score scale is 1 (ESM: q arrives pre-scaled): the scale-and-round step disappears at compile time.
+//
+// Loop structure: the key blocks that need no masking for ANY query row of the wave (inside the sequence, below the causal
+// diagonal, no key mask) run in a loop whose body is straight-line code -- no branch between the QT independent
+// softmax chains, so the scheduler can interleave their MFMA / VALU / cross-lane steps; the remaining (boundary or
+// masked) blocks run in the general loop.  Measured: a handful of uniform branches inside the block body cost 18 %.
+// VALU budget per score and pass: half a v_cvt_pk_bf16_f32 + one unpack for the bf16 rounding, one raw v_max (pass 1),
+// one v_fma (log2e fold: exp(s - m) = exp2(s.log2e - m.log2e)), one v_exp_f32, one add (pass 1) or one multiply by 1/l
+// and half a cvt_pk (pass 2).
+template <int DH, int QT, bool PF, bool SCALED>
 __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
   constexpr int KB = DH / 32;   // k-blocks of the QK^T contraction
   constexpr int NT = DH / 16;   // 16-wide output tiles of P.V
@@ -59,73 +68,97 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
       fb[kb] = *reinterpret_cast<const bf16x8*>(pb + kb * 32);
     }
   };
-  // scores of one 32-key block for q tile qt, in the log2 domain (z = s * log2(e), so that exp(s - m) = exp2(z - mz) is
-  // ONE v_exp_f32): this lane gets keys kb0 + fq*8 + 0..7 of query qr0 + qt*16 + fr.  `interior` blocks (fully inside
-  // the sequence, fully below the causal diagonal, no key mask) skip all masking arithmetic.
   constexpr float LOG2E = 1.4426950408889634f;
-  constexpr float MASKZ = -3.0e38f;   // finfo.min mask in the log2 domain, kept finite (min * log2e would overflow)
-  auto scores = [&](int kb0, int qt, const bf16x8 (&fa)[KB], const bf16x8 (&fb)[KB], float (&s)[8]) {
+  // masked keys: the reference's finfo.min additive mask.  A power of two, so MASKV * log2e is exact and a fully masked
+  // row gets exp2(0) = 1 for every key (uniform softmax); keys beyond the sequence get -inf (weight exactly 0)
+  constexpr float MASKV = -0x1p126f;
+  auto round2 = [&](float x0, float x1, float& y0, float& y1) {   // two bf16 roundings: one cvt_pk + two unpacks
+    const uint32_t w = pack_bf(x0, x1);
+    y0 = lo_bf(w); y1 = hi_bf(w);
+  };
+  // bf16-rounded (and scaled-and-rounded) scores of one 32-key block for q tile qt: this lane gets keys kb0 + fq*8 + 0..7
+  // of query qr0 + qt*16 + fr
+  auto scores_raw = [&](int qt, const bf16x8 (&fa)[KB], const bf16x8 (&fb)[KB], float (&s)[8]) {
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb], qf[qt][kb], sa, 0, 0, 0);
       sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kb], qf[qt][kb], sb, 0, 0, 0);
     }
-    const int qlo = qr0 + qt * 16;
-    const bool interior = (kb0 + 32 <= len) && !keep && !(a.causal && kb0 + 31 > qlo);
-    if (interior) {
+    round2(sa[0], sa[1], s[0], s[1]); round2(sa[2], sa[3], s[2], s[3]);
+    round2(sb[0], sb[1], s[4], s[5]); round2(sb[2], sb[3], s[6], s[7]);
+    if (SCALED) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
-        if (a.scale != 1.0f) v = rbf(v * a.scale);
-        s[r] = v * LOG2E;
-      }
-    } else {
-      const int qpos = qlo + fr;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int j = kb0 + fq * 8 + r;
-        float v = rbf(r < 4 ? sa[r & 3] : sb[r & 3]);
-        if (a.scale != 1.0f) v = rbf(v * a.scale);
-        bool allowed = !(a.causal && j > qpos);
-        if (keep && j < len) allowed = allowed && (keep[j] != 0);
-        s[r] = j < len ? (allowed ? v * LOG2E : MASKZ) : -INFINITY;
-      }
+      for (int r = 0; r < 8; r += 2) round2(s[r] * a.scale, s[r + 1] * a.scale, s[r], s[r + 1]);
     }
   };
+  auto mask_block = [&](int kb0, int qt, float (&s)[8]) {
+    const int qpos = qr0 + qt * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int j = kb0 + fq * 8 + r;
+      bool allowed = !(a.causal && j > qpos);
+      if (keep && j < len) allowed = allowed && (keep[j] != 0);
+      s[r] = j < len ? (allowed ? s[r] : MASKV) : -INFINITY;
+    }
+  };
+  auto vmax = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };   // never NaN here
+  auto vmax3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
 
   int kend = a.causal ? ((qr0 + QROWS) < len ? (qr0 + QROWS) : len) : len;
+  // leading key blocks that need no masking for any query row of this wave
+  int kint = keep ? 0 : (len / 32) * 32;
+  if (a.causal) { const int kc = qr0 >= 31 ? ((qr0 + 1) / 32) * 32 : 0; kint = kint < kc ? kint : kc; }
   float m[QT], l[QT];
+  auto p1_update = [&](int qt, const float (&s)[8]) {
+    float bm = vmax3(s[0], s[1], s[2]);
+    bm = vmax3(bm, s[3], s[4]);
+    bm = vmax3(bm, s[5], s[6]);
+    bm = vmax(bm, s[7]);
+    bm = vmax(bm, __shfl_xor(bm, 16, 64));
+    bm = vmax(bm, __shfl_xor(bm, 32, 64));
+    const float mn = vmax(m[qt], bm);
+    const float nmz = -mn * LOG2E;
+    float bs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bs += __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nmz));
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    l[qt] = l[qt] * __builtin_amdgcn_exp2f(fmaf(m[qt], LOG2E, nmz)) + bs;
+    m[qt] = mn;
+  };
   for (int attempt = 0; attempt < 2; ++attempt) {
     // pass 1: online row max / sum of exp over keys [0, kend)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
     bf16x8 ka[KB], kb_[KB];
     load_k(0, ka, kb_);
-    for (int kb0 = 0; kb0 < kend; kb0 += 32) {
+    int kb0 = 0;
+    const int ki = kint < kend ? kint : kend;
+    for (; kb0 < ki; kb0 += 32) {   // straight-line body
       bf16x8 na[KB], nb[KB];
-      const bool more = kb0 + 32 < kend;
-      if (PF) { if (more) load_k(kb0 + 32, na, nb); }
-      else if (kb0 > 0) load_k(kb0, ka, kb_);
+      load_k(kb0 + 32, na, nb);     // row indices are clamped: the (unused) load past the end is harmless
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float s[8];
-        scores(kb0, qt, ka, kb_, s);
-        float bm = s[0];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) bm = fmaxf(bm, s[r]);
-        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-        const float mn = fmaxf(m[qt], bm);
-        float bs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) bs += __builtin_amdgcn_exp2f(s[r] - mn);
-        bs += __shfl_xor(bs, 16, 64);
-        bs += __shfl_xor(bs, 32, 64);
-        l[qt] = l[qt] * __builtin_amdgcn_exp2f(m[qt] - mn) + bs;
-        m[qt] = mn;
+        scores_raw(qt, ka, kb_, s);
+        p1_update(qt, s);
       }
-      if (PF && more) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
+    }
+    for (; kb0 < kend; kb0 += 32) {
+      bf16x8 na[KB], nb[KB];
+      const bool more = kb0 + 32 < kend;
+      if (more) load_k(kb0 + 32, na, nb);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float s[8];
+        scores_raw(qt, ka, kb_, s);
+        mask_block(kb0, qt, s);
+        p1_update(qt, s);
+      }
+      if (more) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
       }
@@ -134,15 +167,15 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
     // makes its softmax uniform over ALL keys of the sequence, causal or not -> redo over the full range
     bool empty_row = false;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) empty_row = empty_row || ((m[qt] == MASKZ) && (qr0 + qt * 16 + fr) < len);
+    for (int qt = 0; qt < QT; ++qt) empty_row = empty_row || ((m[qt] == MASKV) && (qr0 + qt * 16 + fr) < len);
     if (attempt == 0 && kend < len && __any(empty_row)) { kend = len; continue; }
     break;
   }
 
   // pass 2: P = bf16(exp(S - m) / l), O += P.V   (one reciprocal per row; a product instead of a division per score)
-  float rl[QT];
+  float rl[QT], nmz[QT];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) rl[qt] = 1.0f / l[qt];
+  for (int qt = 0; qt < QT; ++qt) { rl[qt] = 1.0f / l[qt]; nmz[qt] = -m[qt] * LOG2E; }
   f32x4 oacc[QT][NT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
@@ -153,26 +186,50 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) vf[n] = *reinterpret_cast<const bf16x8*>(vbase + (size_t)n * 16 * a.vt_total + kb0);
   };
+  auto p2_update = [&](int qt, const float (&s)[8], const bf16x8 (&vf)[NT]) {
+    float p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nmz[qt])) * rl[qt];
+    const uint32_t pw[4] = {pack_bf(p[0], p[1]), pack_bf(p[2], p[3]), pack_bf(p[4], p[5]), pack_bf(p[6], p[7])};
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) oacc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[n], oacc[qt][n], 0, 0, 0);
+  };
   {
     bf16x8 ka[KB], kb_[KB], vf[NT];
     load_k(0, ka, kb_);
     load_v(0, vf);
-    for (int kb0 = 0; kb0 < kend; kb0 += 32) {
+    int kb0 = 0;
+    // the V prefetch of the block after the last one would leave the sequence's (32-padded) column range
+    const int last = ((kend + 31) / 32 - 1) * 32;
+    const int ki = kint < last ? kint : last;
+    for (; kb0 < ki; kb0 += 32) {   // straight-line body
       bf16x8 na[KB], nb[KB], nv[NT];
-      const bool more = kb0 + 32 < kend;
-      if (PF) { if (more) { load_k(kb0 + 32, na, nb); load_v(kb0 + 32, nv); } }
-      else if (kb0 > 0) { load_k(kb0, ka, kb_); load_v(kb0, vf); }
+      load_k(kb0 + 32, na, nb);
+      load_v(kb0 + 32, nv);
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float s[8];
-        scores(kb0, qt, ka, kb_, s);
-        bf16x8 pf;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pf[r] = (short)f2bf(__builtin_amdgcn_exp2f(s[r] - m[qt]) * rl[qt]);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) oacc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf[n], oacc[qt][n], 0, 0, 0);
+        scores_raw(qt, ka, kb_, s);
+        p2_update(qt, s, vf);
       }
-      if (PF && more) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) vf[n] = nv[n];
+    }
+    for (; kb0 < kend; kb0 += 32) {
+      bf16x8 na[KB], nb[KB], nv[NT];
+      const bool more = kb0 + 32 < kend;
+      if (more) { load_k(kb0 + 32, na, nb); load_v(kb0 + 32, nv); }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float s[8];
+        scores_raw(qt, ka, kb_, s);
+        if (!(kb0 < kint)) mask_block(kb0, qt, s);
+        p2_update(qt, s, vf);
+      }
+      if (more) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
 #pragma unroll
@@ -465,9 +522,17 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   // proteins/s) -- the kernel is not L2-bound -- so the simpler one stays the default
   if (var == 1 && a.dh == 64) { hipLaunchKernelGGL((attn_lds_kernel<64, 3>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a); return; }
   if (var == 1 && a.dh == 128) { hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a); return; }
-  if (a.dh == 128) hipLaunchKernelGGL((attn_kernel<128, 1, true>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
-  else if (a.dh == 64) hipLaunchKernelGGL((attn_kernel<64, 3, true>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attn_kernel<32, 2, true>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
+  const bool scaled = a.scale != 1.0f;
+#define PCY_ATTN_LAUNCH(DHV, QTV, ROWS)                                                                                    \
+  do {                                                                                                                      \
+    const dim3 grid((a.max_len + ROWS - 1) / ROWS, a.H, a.nseq);                                                            \
+    if (scaled) hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, true>), grid, dim3(256), 0, s, a);                         \
+    else hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, false>), grid, dim3(256), 0, s, a);                               \
+  } while (0)
+  if (a.dh == 128) PCY_ATTN_LAUNCH(128, 1, 64);
+  else if (a.dh == 64) PCY_ATTN_LAUNCH(64, 3, 192);
+  else PCY_ATTN_LAUNCH(32, 2, 128);
+#undef PCY_ATTN_LAUNCH
 }
 
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a) {
