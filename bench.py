@@ -91,7 +91,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or bool(os.environ.get("PCY_BENCH_FORCE_DIST"))   # the env switch exercises the RCCL path on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:

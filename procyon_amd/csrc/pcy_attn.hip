@@ -530,7 +530,7 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
     else hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, false>), grid, dim3(256), 0, s, a);                               \
   } while (0)
   if (a.dh == 128) PCY_ATTN_LAUNCH(128, 1, 64);
-  else if (a.dh == 64) PCY_ATTN_LAUNCH(64, 3, 192);
+  else if (a.dh == 64) PCY_ATTN_LAUNCH(64, 3, 192);   // QT = 2: 343 vs 396 proteins/s; forcing 4 waves/SIMD (spills): 322
   else PCY_ATTN_LAUNCH(32, 2, 128);
 #undef PCY_ATTN_LAUNCH
 }
