@@ -239,6 +239,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
+    { static const int dbg = [] { const char* e = getenv("PCY_DBG_ATTN"); return e ? atoi(e) : 0; }(); t.dbg = dbg; }   // timing experiments: early exits
     pcy_launch_attn_decode(s, t);
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
