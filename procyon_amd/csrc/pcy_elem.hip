@@ -74,6 +74,57 @@ __global__ __launch_bounds__(NT) void layernorm_kernel(const bf16_t* __restrict_
   }
 }
 
+// one WAVE per row, the row held in registers (VPL x 16 B per lane): one global read, no workgroup barrier
+template <int VPL>
+__global__ __launch_bounds__(NT) void layernorm_wave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int rows,
+                                                            int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (size_t)row * d;
+  uint4 v[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int k = (i * 64 + lane) * 8;
+    v[i] = k < d ? *reinterpret_cast<const uint4*>(xr + k) : make_uint4(0, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += lo_bf(u[j]) + hi_bf(u[j]);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if ((i * 64 + lane) * 8 < d) {
+      const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a = lo_bf(u[j]) - mean, c = hi_bf(u[j]) - mean; q += a * a + c * c; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  bf16_t* yr = y + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int k = (i * 64 + lane) * 8;
+    if (k < d) {
+      const uint4 g = *reinterpret_cast<const uint4*>(w + k);
+      const uint4 h = *reinterpret_cast<const uint4*>(b + k);
+      const uint32_t u[4] = {v[i].x, v[i].y, v[i].z, v[i].w}, gg[4] = {g.x, g.y, g.z, g.w}, hh[4] = {h.x, h.y, h.z, h.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = pack_bf((lo_bf(u[j]) - mean) * rstd * lo_bf(gg[j]) + lo_bf(hh[j]),
+                       (hi_bf(u[j]) - mean) * rstd * hi_bf(gg[j]) + hi_bf(hh[j]));
+      *reinterpret_cast<uint4*>(yr + k) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ embedding lookup + soft-token splice (A5)
 __global__ __launch_bounds__(NT) void embed_gather_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
                                                           const bf16_t* __restrict__ soft, const int32_t* __restrict__ soft_map,
@@ -367,7 +418,12 @@ void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t*
   if (rows > 0) hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, y, d, eps, cast);
 }
 void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps) {
-  if (rows > 0) hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, b, y, d, eps);
+  if (rows <= 0) return;
+  const int vpl = (d + 511) / 512;
+  const dim3 grid((rows + NT / 64 - 1) / (NT / 64));
+  if (rows >= 64 && vpl <= 3) hipLaunchKernelGGL(layernorm_wave_kernel<3>, grid, dim3(NT), 0, s, x, w, b, y, rows, d, eps);
+  else if (rows >= 64 && vpl <= 5) hipLaunchKernelGGL(layernorm_wave_kernel<5>, grid, dim3(NT), 0, s, x, w, b, y, rows, d, eps);
+  else hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(NT), 0, s, x, w, b, y, d, eps);
 }
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
