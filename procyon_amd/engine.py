@@ -219,6 +219,18 @@ def interleave_gate_up(gate, up):
     return torch.stack([gate.view(F_ // 16, 16, d), up.view(F_ // 16, 16, d)], dim=1).reshape(2 * F_, d).contiguous()
 
 
+def _h2d(t, dev):
+    """host -> device without stalling the stream: a pageable source makes the copy wait for the queued GPU work (the
+    retrieval loop then alternates host packing and GPU encoding instead of overlapping them); the pinned staging tensor
+    is kept alive by riding on the result."""
+    if t.device.type != "cpu" or torch.device(dev).type != "cuda":
+        return t.to(dev)
+    src = t.contiguous().pin_memory()
+    out = src.to(dev, non_blocking=True)
+    out._pcy_src = src
+    return out
+
+
 class KVCache:
     """[L,B,Hkv,Tmax,dh] x2; `layer(l)` gives the reference's past_key_values[l] views."""
 
@@ -464,12 +476,13 @@ class EsmEngine:
         dev = self.device
         if pk["max_len"] > self.cfg.max_len:
             raise ValueError(f"sequence of {pk['max_len']} tokens exceeds the rotary table ({self.cfg.max_len})")
-        t = {k: pk[k].to(dev) for k in ("tokens", "pos", "cu", "vt_cu")}
+        t = {k: _h2d(pk[k], dev) for k in ("tokens", "pos", "cu", "vt_cu")}
         hidden = torch.empty(pk["ntok"], self.cfg.d, dtype=BF16, device=dev)
         L.check(self.ctx.lib.pcy_esm_encode(self.ctx.h, C.byref(self.desc), _p(t["tokens"]), _p(t["pos"]), _p(t["cu"]), _p(t["vt_cu"]),
                                             pk["ntok"], pk["nseq"], pk["max_len"], pk["vt_total"], int(mask_pads), _p(hidden)),
                 "pcy_esm_encode")
-        self._last = t  # keep index tensors alive until the stream has consumed them
+        self._last = (t, getattr(self, "_last", None))  # index tensors (and their pinned sources) of the last two calls stay alive
+        self._last = (self._last[0], self._last[1][0] if self._last[1] else None)
         return hidden
 
     def hidden_states(self, rows, mask_pads=True):
@@ -495,6 +508,7 @@ class EsmEngine:
                 rng += [int(pk["cu"][r]), int(pk["real"][r])]          # pads never enter the pool (esm.py:171-173)
             seg.append(len(rng) // 2)
         mode = {"mean": L.POOL_MEAN_CORRECTED if correction else L.POOL_MEAN, "max": L.POOL_MAX}[pooling]
-        seg_t = torch.tensor(seg, dtype=torch.int32, device=self.device)
-        rng_t = torch.tensor(rng, dtype=torch.int32, device=self.device)
+        seg_t = _h2d(torch.tensor(seg, dtype=torch.int32), self.device)
+        rng_t = _h2d(torch.tensor(rng, dtype=torch.int32), self.device)
+        self._last_pool = (seg_t, rng_t)
         return self.ctx.pool(h, seg_t, rng_t, nprot, mode)
