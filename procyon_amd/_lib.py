@@ -92,6 +92,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PcyError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(the ProCyon engine has no CPU/torch fallback)")
+    # torch first: it ships its own libamdhip64; loading libpcy.so before it binds the engine to /opt/rocm's copy and the
+    # process ends up with two HIP runtimes (the second one then reports "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
