@@ -212,7 +212,7 @@ def main():
                                       f"{a.residues}-residue protein, {a.prompt}-token prompt, {a.tokens}-token greedy generation",
                           "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
                "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
-        if not a.no_cpu_baseline and a.geometry == "full":
+        if not a.no_cpu_baseline and a.geometry == "full" and world == 1:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.tokens, a.residues, a.prompt)
         print(json.dumps(out))
     if dist:
