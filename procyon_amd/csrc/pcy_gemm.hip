@@ -355,63 +355,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large-M variant with a deeper pipeline: same 256 x 256 tile and wave layout, BK = 32 and FOUR LDS stages (4 x 32 KiB).
-// With one workgroup per CU nobody fills the bubble while a stage's loads are in flight, and two stages give the
-// loads only one K-step (~0.85 us of MFMA) to arrive from L2.  Here stage kt+3 is issued in step kt (~1.3 us ahead), the
-// wait before each barrier is counted (`s_waitcnt vmcnt(8)`: the two younger stages stay in flight), one barrier per step.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_kernel_big2(PcyGemmArgs a) {
-  constexpr int BK = 32, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8, NS = 4;
-  constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 16 KiB each
-  extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
-  char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  int m0, n0;
-  tile_origin<TBM, TBN>(a, tile, m0, n0);
-  f32x4 acc[WTN][WTM];
-#pragma unroll
-  for (int i = 0; i < WTN; ++i)
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = a.K / BK;
-  const int fr = lane & 15, fq = lane >> 4;
-  auto stage = [&](int kt) {   // 2 + 2 one-KiB DMA instructions per wave
-    char* buf = smem + (kt % NS) * (TILE_A + TILE_W);
-    stage_tile<BK, TBM, NW>(a.A, a.lda, m0, a.M, kt * BK, buf, wave, lane);
-    stage_tile<BK, TBN, NW>(a.W, a.K, n0, a.N, kt * BK, buf + TILE_A, wave, lane);
-  };
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 3 < nk) stage(kt + 3);   // its buffer was read in step kt-1, which every wave has left
-    const char* Acur = smem + (kt % NS) * (TILE_A + TILE_W);
-    const char* Wcur = Acur + TILE_A;
-    bf16x8 xf[WTM], wf[WTN];
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq);
-#pragma unroll
-    for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < WTN; ++i)
-#pragma unroll
-      for (int j = 0; j < WTM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Large-M variant, 8-wave PING-PONG: same 256 x 256 tile / BK = 32 / four LDS stages, but the two waves of every SIMD
 // run half a step out of phase.  Every wave alternates  R: 12 x ds_read_b128 (its fragments of one 32-k step)  and
 // M: 32 x MFMA, with a workgroup barrier after each; waves 4-7 start with one extra barrier, so in every interval one
@@ -486,323 +429,43 @@ __global__ __launch_bounds__(512) void gemm_kernel_pp(PcyGemmArgs a) {
   gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Large-M variant, ONE wave per SIMD: 256 x 256 tile, 4 waves (2 x 2), 128 x 128 per wave = 4 x 4 tiles of
-// v_mfma_f32_32x32x16_bf16 (accumulators: 256 registers, the AGPR half of the 512-register budget of a 256-thread
-// workgroup).  Why: with 16x16x32 tiles and 64x128 per wave every 32-k step issues 32 MFMA + 12 ds_read_b128 + 4 LDS-DMA
-// pieces per wave, two waves per SIMD; timing experiments on gemm_kernel_pp (PCY_GEMM_DBG) put the DMA pieces at 25 %
-// and the fragment reads at 18 % of the run time -- issue slots, not LDS or L2 bandwidth.  Here a 32-k step is
-// 32 MFMA of 32 cycles with 16 ds_read_b128 + 8 DMA pieces to hide in their shadows (half the fragment reads per flop),
-// fragments double-buffered in registers so the reads of step kt+1 sit between the MFMAs of step kt.
-// BK = 32, four LDS stages: stage kt+3 is requested in step kt-1... see the loop.
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue32(const PcyGemmArgs& a, f32x16 (&acc)[4][4], int m_base, int n_base, int lane) {
-  // lane holds D[n = i*32 + (lane>>5)*4 + 8*g + r][m = j*32 + (lane&31)], g < 4, r < 4
-  const int ml = lane & 31, nq = (lane >> 5) * 4;
-  const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
-  if (EPI == EPI_SWIGLU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m_base + j * 32 + ml;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {   // rows 0-15 of a 32-row tile = gate, 16-31 = up of the same 16 features
-          const int nrow = n_base + i * 32;
-          if (nrow + 16 + nq + 8 * g >= a.N) continue;
-          const int f = (nrow >> 5) * 16 + nq + 8 * g;
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float gt = rbf(acc[i][j][g * 4 + r]), up = rbf(acc[i][j][(g + 2) * 4 + r]);
-            o[r] = rbf(silu_f(gt)) * up;
-          }
-          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
-        }
-      }
-    }
-    return;
-  }
-  float bias[4][4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n_base + i * 32 + nq + 8 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = (n + r) < a.N ? (n + r) : a.N - 1;
-        bias[i][g][r] = a.bias ? bf2f(a.bias[nn]) : 0.f;
-      }
-    }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m_base + j * 32 + ml;
-    const int mc = m < a.M ? m : a.M - 1;
-    uint2 res[4][4];
-    if (EPI == EPI_RESID && vec_ok) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n_base + i * 32 + nq + 8 * g;
-          res[i][g] = *reinterpret_cast<const uint2*>(a.resid + (size_t)mc * a.ldr + (n < a.N ? n : 0));
-        }
-    }
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n_base + i * 32 + nq + 8 * g;
-        if (n >= a.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(acc[i][j][g * 4 + r] + bias[i][g][r]);
-        if (EPI == EPI_RESID) {
-          if (vec_ok) {
-            v[0] = rbf(v[0] + lo_bf(res[i][g].x)); v[1] = rbf(v[1] + hi_bf(res[i][g].x));
-            v[2] = rbf(v[2] + lo_bf(res[i][g].y)); v[3] = rbf(v[3] + hi_bf(res[i][g].y));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < a.N) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)m * a.ldr + n + r]));
-          }
-        }
-        if (EPI == EPI_GELU_ERF) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rbf(gelu_erf_f(v[r]));
-        }
-        if (EPI == EPI_GELU_ESM) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_esm_chain(v[r]);
-        }
-        if (vec_ok) {
-          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) a.C[(size_t)m * a.ldc + n + r] = f2bf(v[r]);
-        }
-      }
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel_w4(PcyGemmArgs a) {
-  constexpr int BK = 32, TBM = 256, TBN = 256, NW = 4, NS = 4;
-  constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 16 KiB each
-  extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
-  char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  int m0, n0;
-  tile_origin<TBM, TBN>(a, tile, m0, n0);
-  f32x16 acc[4][4];   // [feature tile][token tile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const int nk = a.K / BK;
-  const int r32 = lane & 31, kh = lane >> 5;
-  auto stage = [&](int kt) {   // 4 + 4 one-KiB DMA pieces per wave
-    char* buf = smem + (kt % NS) * (TILE_A + TILE_W);
-    stage_tile<BK, TBM, NW>(a.A, a.lda, m0, a.M, kt * BK, buf, wave, lane);
-    stage_tile<BK, TBN, NW>(a.W, a.K, n0, a.N, kt * BK, buf + TILE_A, wave, lane);
-  };
-  // fragments of one 32-k step: [k16 half][tile]; 32x32x16 operand: lane -> row (lane & 31), k = (lane >> 5)*8 .. +7
-  auto load_frags = [&](int kt, bf16x8 (&xf)[2][4], bf16x8 (&wf)[2][4]) {
-    const char* Acur = smem + (kt % NS) * (TILE_A + TILE_W);
-    const char* Wcur = Acur + TILE_A;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[h][j] = lds_frag<BK>(Acur, wm * 128 + j * 32 + r32, h * 2 + kh);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[h][i] = lds_frag<BK>(Wcur, wn * 128 + i * 32 + r32, h * 2 + kh);
-    }
-  };
-  auto mfmas = [&](const bf16x8 (&xf)[2][4], const bf16x8 (&wf)[2][4]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[h][i], xf[h][j], acc[i][j], 0, 0, 0);
-  };
-
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  bf16x8 xa[2][4], wa[2][4], xb[2][4], wb[2][4];
-  load_frags(0, xa, wa);
-  // body kt: stage kt+1 has landed for everybody and everybody has read stage kt-1 (barrier); request stage kt+3 into
-  // the buffer of stage kt-1; read the fragments of step kt+1 while the MFMAs of step kt run.  The steady-state body is
-  // branch-free (one scheduling region) and carries an explicit interleave: per 4 MFMAs one DMA piece and two
-  // fragment reads -- left alone the compiler emits 8 DMA, 16 ds_read, a wait, then 32 MFMAs back to back.
-#define PCY_W4_STEP_FULL(KT, XC, WC, XN, WN)                                              \
-  {                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                            \
-    __builtin_amdgcn_s_barrier();                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    stage((KT) + 3);                                                                        \
-    load_frags((KT) + 1, XN, WN);                                                           \
-    mfmas(XC, WC);                                                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-    }                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-  }
-#define PCY_W4_STEP(KT, XC, WC, XN, WN)                                                   \
-  {                                                                                         \
-    if ((KT) + 2 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");         \
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
-    __builtin_amdgcn_s_barrier();                                                           \
-    if ((KT) + 3 < nk) stage((KT) + 3);                                                     \
-    if ((KT) + 1 < nk) load_frags((KT) + 1, XN, WN);                                        \
-    mfmas(XC, WC);                                                                          \
-  }
-  int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
-    PCY_W4_STEP_FULL(kt, xa, wa, xb, wb)
-    PCY_W4_STEP_FULL(kt + 1, xb, wb, xa, wa)
-  }
-  for (; kt + 1 < nk; kt += 2) {
-    PCY_W4_STEP(kt, xa, wa, xb, wb)
-    PCY_W4_STEP(kt + 1, xb, wb, xa, wa)
-  }
-  if (kt < nk) PCY_W4_STEP(kt, xa, wa, xb, wb)
-#undef PCY_W4_STEP
-#undef PCY_W4_STEP_FULL
-  gemm_epilogue32<EPI>(a, acc, m0 + wm * 128, n0 + wn * 128, lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// v2: same 128x128 tile, BK = 32, THREE LDS stages (48 KiB -> 3 workgroups per CU) and counted waits: the loads of
-// stage kt+1 stay in flight across the barrier that publishes stage kt (inline `s_waitcnt vmcnt(4)` + raw `s_barrier`;
-// `__syncthreads()` would drain them).  One barrier per K-step; stage kt+2 is issued right after it, so the buffer
-// it overwrites (read in step kt-1) is provably free.
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_v2(PcyGemmArgs a) {
-  constexpr int BK = 32, NS = 3;
-  constexpr int TILE_B = BM * BK * 2;                      // 8 KiB per operand per stage
-  __shared__ __attribute__((aligned(1024))) char smem[NS * 2 * TILE_B];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  int m0, n0;
-  tile_origin(a, tile, m0, n0);
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = a.K / BK;
-  const int fr = lane & 15, fq = lane >> 4;
-  auto stage = [&](int kt) {
-    char* buf = smem + (kt % NS) * 2 * TILE_B;
-    stage_tile<BK>(a.A, a.lda, m0, a.M, kt * BK, buf, wave, lane);            // 2 x 1-KiB DMA per wave
-    stage_tile<BK>(a.W, a.K, n0, a.N, kt * BK, buf + TILE_B, wave, lane);     // 2 more
-  };
-  stage(0);
-  if (nk > 1) stage(1);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) stage(kt + 2);
-    const char* Acur = smem + (kt % NS) * 2 * TILE_B;
-    const char* Wcur = Acur + TILE_B;
-    bf16x8 xf[4], wf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, fq);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, fq);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq);
-}
-
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int bk = [] { const char* e = getenv("PCY_GEMM_BK"); return e ? atoi(e) : 64; }();
-  static const int ver = [] { const char* e = getenv("PCY_GEMM_V"); return e ? atoi(e) : 1; }();
   static const int big_min_m = [] { const char* e = getenv("PCY_GEMM_BIG_M"); return e ? atoi(e) : 2048; }();
   // 256x256 tiles pay off where the mainloop dominates (measured, M = 32832: qkv 734 -> 804, fc2 827 -> 911 TFLOP/s);
   // with the heavy GELU epilogues (one workgroup per CU: nobody's MFMAs cover it) and for N = K = 1280 they do not
-  const bool big_ok = a.M >= big_min_m && ver != 2 && EPI != EPI_GELU_ESM && EPI != EPI_GELU_ERF &&
+  const bool big_ok = a.M >= big_min_m && EPI != EPI_GELU_ESM && EPI != EPI_GELU_ERF &&
                       (a.N >= 2560 || (a.N >= 256 && a.K >= 2560));
   if (big_ok) {
     constexpr int smem = 2 * (256 + 256) * 64 * 2;
-    static bool configured = false;
-    if (!configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      configured = true;
-    }
     const int tiles_big = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     PcyGemmArgs b = a;
     const int tn = (a.N + 255) / 256;
     long gnb = (5L << 19) / ((long)256 * a.K * 2);
     if (gnb < 2) gnb = 2;
     b.gn = (int)(gnb > tn ? tn : gnb);
+    // PCY_GEMM_BIGV=3: the ping-pong schedule (experiment, 6 % slower at 4096^3)
     static const int bigv = [] { const char* e = getenv("PCY_GEMM_BIGV"); return e ? atoi(e) : 1; }();
-    if (bigv == 4 && a.K % 32 == 0) {
-      static bool configured4 = false;
-      if (!configured4) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_w4<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        configured4 = true;
-      }
-      hipLaunchKernelGGL((gemm_kernel_w4<EPI>), dim3(tiles_big), dim3(256), smem, s, b);
-    } else if (bigv == 3 && a.K % 32 == 0) {
+    if (bigv == 3 && a.K % 32 == 0) {
       static bool configured3 = false;
       if (!configured3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_pp<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured3 = true;
       }
       hipLaunchKernelGGL((gemm_kernel_pp<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
-    } else if (bigv == 2 && a.K % 32 == 0) {
-      static bool configured2 = false;
-      if (!configured2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big2<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        configured2 = true;
-      }
-      hipLaunchKernelGGL((gemm_kernel_big2<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
     } else {
+      static bool configured = false;
+      if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+      }
       hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
     }
     return;
   }
-  if (ver == 2) hipLaunchKernelGGL((gemm_kernel_v2<EPI>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
-  else if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
 }
 
