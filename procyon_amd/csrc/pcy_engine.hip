@@ -217,7 +217,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* scores = cv.take<float>((size_t)B * H * (kv->Tmax + 1));
   cv.take<char>((size_t)B * 64 * 16);                 // pick partials (same carve as enqueue_pick)
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
-  const bool batched = B > 4 && B <= 32 && d % 512 == 0 && F % 512 == 0;
+  const bool batched = B > 4 && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
   PcyFusedDecArgs fa;
   if (fused_args(c, m, kv, st, B, x, fa)) {

@@ -529,18 +529,26 @@ void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   static const int plain = [] { const char* e = getenv("PCY_GEMV_PLAIN"); return e ? atoi(e) : 0; }();
   PcyGemvArgs a0 = a00;
   a0.plain_loads = plain;
-  // 4 < B <= 32 on MFMA (x already normalised by the caller: the fused RMSNorm prologue is a B <= 4 feature)
-  if (a0.B > 4 && a0.B <= 32 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
-    switch (a0.epi) {
-      case EPI_STORE: launch_mfma<EPI_STORE>(s, a0); return;
-      case EPI_RESID: launch_mfma<EPI_RESID>(s, a0); return;
-      case EPI_GELU_ERF: launch_mfma<EPI_GELU_ERF>(s, a0); return;
-      case EPI_GELU_ESM: launch_mfma<EPI_GELU_ESM>(s, a0); return;
-      case EPI_SWIGLU: launch_mfma<EPI_SWIGLU>(s, a0); return;
+  // B > 4 on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused RMSNorm prologue is a
+  // B <= 4 feature)
+  if (a0.B > 4 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
+    for (int b0 = 0; b0 < a0.B; b0 += 32) {
+      PcyGemvArgs a = a0;
+      a.B = (a0.B - b0) < 32 ? (a0.B - b0) : 32;
+      a.x = a0.x + (size_t)b0 * a0.ldx;
+      a.y = a0.y + (size_t)b0 * a0.ldy;
+      if (a0.resid) a.resid = a0.resid + (size_t)b0 * a0.ldy;
+      switch (a.epi) {
+        case EPI_STORE: launch_mfma<EPI_STORE>(s, a); break;
+        case EPI_RESID: launch_mfma<EPI_RESID>(s, a); break;
+        case EPI_GELU_ERF: launch_mfma<EPI_GELU_ERF>(s, a); break;
+        case EPI_GELU_ESM: launch_mfma<EPI_GELU_ESM>(s, a); break;
+        case EPI_SWIGLU: launch_mfma<EPI_SWIGLU>(s, a); break;
+      }
     }
+    return;
   }
-  // batch rows in groups of <= 4 (weights are re-streamed per group; the skinny-MFMA path for
-  // larger decode batches is a TODO tracked in DESIGN.md)
+  // batch rows in groups of <= 4 (fused RMSNorm, or K not a multiple of 512)
   for (int b0 = 0; b0 < a0.B; b0 += 4) {
     PcyGemvArgs a = a0;
     const int nb = (a0.B - b0) < 4 ? (a0.B - b0) : 4;

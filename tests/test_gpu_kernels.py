@@ -74,7 +74,7 @@ def test_gemm_transpose_detecting(ctx):
     assert torch.equal(out, W.t().contiguous())
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 6, 16, 20, 32])   # B > 4 with K % 512 == 0 takes the skinny-MFMA kernel
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 6, 16, 20, 32, 45])   # B > 4 with K % 512 == 0 takes the skinny-MFMA kernel (32 rows per pass)
 @pytest.mark.parametrize("N,K", [(4096, 4096), (512, 14336), (1000, 1280), (130, 136), (1001, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemv(ctx, B, N, K, epi):
@@ -272,7 +272,7 @@ def test_retrieval_scores(ctx, Q, N, D):
     assert torch.equal(out.float().argmax(-1), ref.float().argmax(-1))
 
 
-@pytest.mark.parametrize("B", [5, 20, 32])
+@pytest.mark.parametrize("B", [5, 20, 32, 40])
 def test_gemv_mfma_swiglu_and_decode_layer(ctx, B):
     """batched decode path: SwiGLU on the skinny-MFMA kernel, then one full-width Llama-3-8B layer decoding B rows at once
     against the oracle (beam-20-shaped batch)."""
