@@ -512,11 +512,8 @@ void launch_dec_g(hipStream_t s, const PcyDecAttnArgs& a) {
 
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
-  // q rows per block = 4 waves x QT x 16.  More q tiles per wave amortise the K/Vt fragment loads and loop overhead
-  // (QT 1 -> 2 halves the kernel time); QT = 3 with register prefetch is the measured optimum for dh = 64
-  // (325 proteins/s vs 321 at QT = 2).  QT = 4 is NOT used: that instantiation mis-normalises ~0.3 % of the rows of
-  // its fourth tile (sum p = 1.02-1.03, deterministic, with or without prefetch; tools/diag_attn_scale.py) -- cause not
-  // yet found, tracked in DESIGN.md; the strict unit tests (test_attention_exact_rounding) guard the shipped shapes.
+  // q rows per block = 4 waves x QT x 16.  More q tiles per wave amortise the K / Vt fragment loads and the loop overhead
+  // (QT 2 -> 3: 343 -> 396 proteins/s for dh = 64); QT = 4 (PCY_ATTN_QT=4) needs 174 VGPRs and is slower again (372).
   static const int var = [] { const char* e = getenv("PCY_ATTN_VAR"); return e ? atoi(e) : 0; }();
   // var 1 = LDS-shared K/Vt tiles (attn_lds_kernel): measured equal to the register-fragment kernel (341 vs 346
   // proteins/s) -- the kernel is not L2-bound -- so the simpler one stays the default
@@ -530,7 +527,11 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
     else hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, false>), grid, dim3(256), 0, s, a);                               \
   } while (0)
   if (a.dh == 128) PCY_ATTN_LAUNCH(128, 1, 64);
-  else if (a.dh == 64) PCY_ATTN_LAUNCH(64, 3, 192);   // QT = 2: 343 vs 396 proteins/s; forcing 4 waves/SIMD (spills): 322
+  else if (a.dh == 64) {
+    static const int qt64 = [] { const char* e = getenv("PCY_ATTN_QT"); return e ? atoi(e) : 3; }();
+    if (qt64 == 4) PCY_ATTN_LAUNCH(64, 4, 256);
+    else PCY_ATTN_LAUNCH(64, 3, 192);   // QT = 2: 343 vs 396 proteins/s; forcing 4 waves/SIMD (spills): 322
+  }
   else PCY_ATTN_LAUNCH(32, 2, 128);
 #undef PCY_ATTN_LAUNCH
 }
