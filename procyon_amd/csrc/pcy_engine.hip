@@ -92,7 +92,7 @@ int check_launch(const char* what) {
 
 // GEMM for any M: MFMA tiles when M is large enough to fill them, the streaming GEMV otherwise
 void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* bias, const bf16_t* resid, int ldr,
-            bf16_t* C, int ldc, int M, int N, int K, int epi) {
+            bf16_t* C, int ldc, int M, int N, int K, int epi, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0) {
   if (M <= 8 && epi != EPI_SWIGLU && (resid == nullptr || ldr == ldc)) {
     PcyGemvArgs g{};
     g.W = W; g.x = A; g.y = C; g.bias = bias; g.resid = resid; g.rms_w = nullptr;
@@ -103,6 +103,7 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
   PcyGemmArgs a{};
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
+  a.splitk_ws = splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
   pcy_launch_gemm(s, a);
 }
 
@@ -544,7 +545,8 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   const int vt_total = B * Tp;
   const size_t need = align_up((size_t)M * d * 2, 256) * 2 + align_up((size_t)M * qkvw * 2, 256) + align_up((size_t)M * H * dh * 2, 256) +
                       align_up((size_t)M * F * 2, 256) + align_up((size_t)Hkv * dh * vt_total * 2, 256) +
-                      align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + align_up((size_t)(n_sum_rows + 1) * d * 6, 256) + 4096;
+                      align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + align_up((size_t)(n_sum_rows + 1) * d * 6, 256) +
+                      (M <= 1024 ? align_up((size_t)8 * M * qkvw * 4, 256) : 0) + 4096;
   if (n_sum_rows > 0 && (!sum_rows || !hidden_sum_out)) return fail(1, "pcy_llama_prefill: sum_rows / hidden_sum_out missing");
   if (int r = c->reserve(need)) return r;
   Carver cv(c->ws);
@@ -555,6 +557,8 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   bf16_t* act = cv.take<bf16_t>((size_t)M * F);
   bf16_t* vt = cv.take<bf16_t>((size_t)Hkv * dh * vt_total);
   bf16_t* lastx = cv.take<bf16_t>((size_t)(n_logit_rows + 1) * d);
+  const size_t sk_bytes = M <= 1024 ? (size_t)8 * M * qkvw * 4 : 0;   // split-K partials for the projections that under-fill the chip
+  float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   float* hsum = cv.take<float>((size_t)(n_sum_rows + 1) * d);      // ret_token_access='all': fp32 sum of the L+1 hidden states
   bf16_t* hsum_tmp = cv.take<bf16_t>((size_t)(n_sum_rows + 1) * d);
   hipStream_t s = c->stream;
@@ -565,7 +569,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
     pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
-    linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE);
+    linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
     pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
     pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
                           (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
@@ -575,7 +579,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     t.o = ao; t.ldo = H * dh; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = B; t.max_len = T; t.H = H; t.Hkv = Hkv; t.dh = dh;
     t.causal = 1; t.scale = 1.0f / sqrtf((float)dh);
     pcy_launch_attn(s, t);
-    linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID);
+    linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes);
     pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
     if (M <= 8) {
       PcyGemvArgs u{};
@@ -584,7 +588,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     } else {
       linear(s, xn, d, (const bf16_t*)L.wgu, nullptr, nullptr, 0, act, F, M, 2 * F, d, EPI_SWIGLU);
     }
-    linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID);
+    linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID, sk_ws, sk_bytes);
     if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
   }
   if (hidden_out) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, (bf16_t*)hidden_out, M, d, m->rms_eps, m->rms_cast);

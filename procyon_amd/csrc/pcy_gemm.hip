@@ -298,6 +298,97 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K for small M (Llama prefill of one 512-token prompt: o / down / qkv projections have 128-192 output tiles for 256
+// CUs, `down` with K = 14336): grid = tiles x splits, every workgroup accumulates its K range with the mainloop of
+// gemm_kernel and writes the fp32 partial tile; a second, element-wise kernel adds the partials in split order (fixed ->
+// deterministic) and applies the epilogue.  Measured at M = 512: down 154 -> see DESIGN.md.
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(PcyGemmArgs a, int splits, int k_per_split) {
+  constexpr int BK = 64;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles = gridDim.x / splits;
+  const int split = blockIdx.x / tiles, bid = blockIdx.x % tiles;
+  const int xq = tiles >> 3, xr = tiles & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  int m0, n0;
+  tile_origin(a, tile, m0, n0);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int kbeg = split * k_per_split;
+  const int nk = k_per_split / BK;
+  constexpr int TILE_B = BM * BK * 2;
+  stage_tile<BK>(a.A, a.lda, m0, a.M, kbeg, smem, wave, lane);
+  stage_tile<BK>(a.W, a.K, n0, a.N, kbeg, smem + TILE_B, wave, lane);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* Acur = smem + cur * 2 * TILE_B;
+    const char* Wcur = Acur + TILE_B;
+    if (kt + 1 < nk) {
+      char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
+      stage_tile<BK>(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK>(a.W, a.K, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_B, wave, lane);
+    }
+#pragma unroll
+    for (int kb = 0; kb < BK / 32; ++kb) {
+      bf16x8 xf[4], wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
+  float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + fq * 4;
+      if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * a.N + n) = acc[i][j];
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) ws[(size_t)m * a.N + n + r] = acc[i][j][r];
+    }
+  }
+}
+
+// sum of the partials in split order + bias (+ residual); 4 consecutive features per thread
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue(PcyGemmArgs a, int splits) {
+  const size_t quads = (size_t)a.M * (a.N / 4);
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+    const int m = (int)(q / (a.N / 4)), n = (int)(q % (a.N / 4)) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.splitk_ws + (size_t)m * a.N + n);
+    for (int s_ = 1; s_ < splits; ++s_) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(a.splitk_ws + ((size_t)s_ * a.M + m) * a.N + n);
+      v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r] = rbf(v[r] + (a.bias ? bf2f(a.bias[n + r]) : 0.f));
+      if (EPI == EPI_RESID) o[r] = rbf(o[r] + bf2f(a.resid[(size_t)m * a.ldr + n + r]));
+    }
+    *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Large-M variant: 256 x 256 x 64 tile, 8 waves (4 along tokens x 2 along features), 64 tokens x 128 features per wave
 // = 4 x 8 MFMA tiles.  Per 32-k step a wave reads 12 fragments for 32 MFMAs (the 128x128 kernel: 8 for 16), which takes
 // the LDS read time from 100 % to 75 % of the MFMA time of a CU, and the 256-wide tile halves the L2 traffic per flop.
@@ -482,6 +573,24 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (gn_env > 0) gn = gn_env;
   a.gn = (int)(gn < 1 ? 1 : (gn > tiles_n ? tiles_n : gn));
   { static const int dbg = [] { const char* e = getenv("PCY_GEMM_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+  // split-K: few tiles, long K, plain / residual epilogue, a workspace supplied by the caller
+  if (a.splitk_ws && (a.epi == EPI_STORE || a.epi == EPI_RESID) && a.rope_cos == nullptr && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+      (a.resid == nullptr || a.ldr % 4 == 0)) {
+    const int tiles = ((a.M + BM - 1) / BM) * tiles_n;
+    // the split count depends on (N, K) only -- sized for four row tiles (one 512-token prompt) -- so that a row's result
+    // does not change with the number of rows in the batch (tests: batch invariance); callers pass the workspace only
+    // for M <= 1024
+    const int tiles_ref = 4 * tiles_n;
+    int splits = 1;
+    while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    if (splits > 1 && (size_t)splits * a.M * a.N * 4 <= a.splitk_ws_bytes) {
+      hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
+      const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
+      if (a.epi == EPI_RESID) hipLaunchKernelGGL(gemm_splitk_epilogue<EPI_RESID>, dim3(eb < 2048 ? eb : 2048), dim3(256), 0, s, a, splits);
+      else hipLaunchKernelGGL(gemm_splitk_epilogue<EPI_STORE>, dim3(eb < 2048 ? eb : 2048), dim3(256), 0, s, a, splits);
+      return;
+    }
+  }
   switch (a.epi) {
     case EPI_STORE: launch<EPI_STORE>(s, a); break;
     case EPI_RESID: launch<EPI_RESID>(s, a); break;

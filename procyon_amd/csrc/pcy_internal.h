@@ -28,6 +28,8 @@ struct PcyGemmArgs {
   // of 64 features rotated with cos/sin rows of pos[token]; columns < rope_qcols are first multiplied by rope_scale and
   // rounded (ESM q.dh^-1/2); rope_mode 0 = every product a bf16 tensor (HF Llama), 1 = fp32, rounded once (HF ESM)
   const int32_t* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin; int rope_ncols, rope_qcols, rope_mode; float rope_scale;
+  // optional split-K workspace (fp32 [splits][M][N]); the launcher splits K when the tile count under-fills the chip
+  float* splitk_ws; size_t splitk_ws_bytes;
   int dbg;              // timing experiments only (PCY_GEMM_DBG): 1 = no global->LDS loads after the prologue, 2 = no LDS fragment reads
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
