@@ -240,3 +240,28 @@ def test_decode_persistent_kernel_matches_layered(monkeypatch):
     for s in range(N):
         assert rel_err(a[0][s], ref[0][s]) < 5e-3, s
     assert rel_err(a[2], ref[2]) < 5e-3 and rel_err(a[3], ref[3]) < 5e-3
+
+
+def test_llama2_7b_geometry_layer():
+    """BASELINE configs[0] geometry (ProCyon-Split text side: Llama-2-7B, multi-head attention H = Hkv = 32, F = 11008, odd
+    vocabulary 32007) at full width, one layer: prefill + 3 cached decode steps against the oracle.  Exercises G = 1 in both
+    attention kernels, K = 11008 (not a multiple of 512) in the GEMV / split-K paths and an odd vocabulary in the picks."""
+    from oracle import llama_ref as LR
+    kw = dict(vocab=32007, d=4096, n_layers=1, n_heads=32, n_kv_heads=32, ffn=11008)
+    sd, geom, eng = llama_pair(kw)
+    T, N = 40, 4
+    torch.manual_seed(5)
+    emb = (torch.randn(2, T, 4096) * 0.02).to(BF)
+    mask = torch.ones(2, T)
+    mask[1, :7] = 0      # one left-padded row
+    tok_ref, lg_ref, _ = LR.greedy_generate(sd, geom, emb, mask, N)
+    tok, _, lg, _ = eng.generate_greedy(emb.cuda(), mask, N, keep_logits=True)
+    for s_ in range(N):
+        assert rel_err(lg[:, s_].cpu(), lg_ref[:, s_]) < 8e-3, s_
+    for b in range(2):
+        for s_ in range(N):
+            if tok[b, s_] != tok_ref[b, s_]:
+                top2 = lg_ref[b, s_].float().topk(2).values
+                noise = float((lg[b, s_].cpu().float() - lg_ref[b, s_].float()).abs().max())
+                assert float(top2[0] - top2[1]) <= 4 * noise, (b, s_)
+                break
