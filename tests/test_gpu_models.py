@@ -265,3 +265,23 @@ def test_llama2_7b_geometry_layer():
                 noise = float((lg[b, s_].cpu().float() - lg_ref[b, s_].float()).abs().max())
                 assert float(top2[0] - top2[1]) <= 4 * noise, (b, s_)
                 break
+
+
+@pytest.mark.parametrize("name,kw", [("esm2-3b", dict(d=2560, n_layers=1, n_heads=40, ffn=10240)),
+                                     ("esm2-150m", dict(d=640, n_layers=2, n_heads=20, ffn=2560))])
+def test_esm_other_sizes_layer(name, kw):
+    """The other encoder sizes the reference can be configured with (procyon/model/esm.py:378-421): ESM2-3B (d2560, head_dim 64:
+    the fused-rotary 256x256 GEMM path, D = 2560 embeddings of ProCyon-Full's 3B variant) and ESM2-150M (head_dim 32: the
+    separate rotary kernel and the dh = 32 attention instantiation) at full width against the oracle."""
+    from oracle import esm_ref as ER
+    from procyon_amd import synth
+    sd, geom, eng = esm_pair(kw)
+    toks = synth.protein_tokens([300, 45, 301], seed=8)
+    ref = ER.esm_forward(sd, geom, toks, mask_pads=True)
+    with alt_accumulation():
+        twin = ER.esm_forward(sd, geom, toks, mask_pads=True)
+    out = eng.hidden_states(toks).cpu()
+    keep = toks != 1
+    floor, err = rel_err(twin[keep], ref[keep]), rel_err(out[keep], ref[keep])
+    print(f"{name}: gpu-vs-oracle {err:.2e}, cpu-vs-cpu floor {floor:.2e}")
+    assert err < parity_bar(floor)
