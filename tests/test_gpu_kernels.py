@@ -182,7 +182,7 @@ def _eager_attention(q, k, v, H, Hkv, dh, lens, causal, scale, keep=None):
 
 @pytest.mark.parametrize("H,Hkv,dh,causal,lens", [(4, 4, 64, False, [70, 1, 129, 33]), (20, 20, 64, False, [300]),
                                                   (4, 4, 64, False, [1026, 191, 192, 193]), (2, 2, 128, True, [515]),
-                                                  (8, 2, 128, True, [45, 200]), (4, 1, 64, True, [64, 65]),
+                                                  (8, 2, 128, True, [45, 200]), (4, 1, 64, True, [64, 65]), (8, 2, 128, True, [1200, 700]),
                                                   (2, 2, 32, True, [50])])
 def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
     n = sum(lens)
@@ -198,18 +198,19 @@ def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
     assert_bf16_close(out, ref, "attention", max_frac=0.03, inter=torch.full_like(ref, 0.5))
 
 
-def test_attention_left_pad_rows_uniform(ctx):
+@pytest.mark.parametrize("T,pad_a,pad_b,dh", [(45, 5, 33, 64), (300, 0, 130, 128)])
+def test_attention_left_pad_rows_uniform(ctx, T, pad_a, pad_b, dh):
     """fully masked (left-pad) query rows: the reference's finfo.min additive mask makes their softmax uniform over ALL
     keys (model_unified.py:769 quirk Q1 depends on the K/V these rows produce)."""
-    H, Hkv, dh, T = 4, 2, 64, 45
+    H, Hkv = 4, 2
     q, k, v = rnd(2 * T, H * dh, seed=1), rnd(2 * T, Hkv * dh, seed=2), rnd(2 * T, Hkv * dh, seed=3)
     keep = torch.ones(2 * T, dtype=torch.uint8)
-    keep[T:T + 33] = 0
-    keep[:5] = 0
+    keep[T:T + pad_b] = 0
+    keep[:pad_a] = 0
     ref = _eager_attention(q, k, v, H, Hkv, dh, [T, T], True, dh ** -0.5, keep)
     out = ctx.attention(q.cuda(), k.cuda(), v.cuda(), [T, T], H, Hkv, dh, True, dh ** -0.5, keep.cuda()).cpu()
     assert rel_err(out, ref) < 1e-3
-    assert_bf16_close(out, ref, "attention left-pad", max_frac=0.03, inter=torch.full_like(ref, 0.03))
+    assert_bf16_close(out, ref, "attention left-pad", max_frac=0.03, inter=torch.full_like(ref, 0.03 if T < 100 else 0.1))
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -233,7 +234,7 @@ def test_rope(ctx, mode):
 
 @pytest.mark.parametrize("H,Hkv,dh,t,B", [(32, 8, 128, 600, 2), (8, 2, 64, 37, 2), (4, 4, 32, 5, 2), (8, 1, 128, 0, 2),
                                            (32, 8, 128, 333, 9), (32, 8, 128, 1030, 20), (16, 8, 128, 65, 16),
-                                           (32, 8, 128, 0, 20)])
+                                           (32, 8, 128, 0, 20), (32, 8, 128, 2500, 2)])
 def test_attn_decode(ctx, H, Hkv, dh, t, B):
     """decode attention (rope + append + exact softmax) vs the oracle's eager formulas (llama_ref.layer_forward).
     B x Hkv >= 64 / >= 128 select the 64- / 128-column workgroup slices."""
