@@ -110,22 +110,33 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
   int kint = keep ? 0 : (len / 32) * 32;
   if (a.causal) { const int kc = qr0 >= 31 ? ((qr0 + 1) / 32) * 32 : 0; kint = kint < kc ? kint : kc; }
   float m[QT], l[QT];
-  auto p1_update = [&](int qt, const float (&s)[8]) {
+  // Online max / sum PER LANE: a lane sees keys fq*8 .. fq*8+7 of every block of its query, so the running (m, l) of the
+  // four lanes of a query are merged once after the loop instead of exchanging partial maxima and sums through the LDS
+  // crossbar in every block (12 ds_bpermute per block and their waits inside the dependent chain).
+  auto p1_update = [&](int qt, const float (&s)[8], bool guard) {
     float bm = vmax3(s[0], s[1], s[2]);
     bm = vmax3(bm, s[3], s[4]);
     bm = vmax3(bm, s[5], s[6]);
     bm = vmax(bm, s[7]);
-    bm = vmax(bm, __shfl_xor(bm, 16, 64));
-    bm = vmax(bm, __shfl_xor(bm, 32, 64));
     const float mn = vmax(m[qt], bm);
-    const float nmz = -mn * LOG2E;
+    // guard (boundary blocks only): a lane whose keys are all beyond the sequence keeps m = -inf; 0 * inf must not appear
+    const float nmz = (guard && mn == -INFINITY) ? 0.f : -mn * LOG2E;
     float bs = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) bs += __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nmz));
-    bs += __shfl_xor(bs, 16, 64);
-    bs += __shfl_xor(bs, 32, 64);
     l[qt] = l[qt] * __builtin_amdgcn_exp2f(fmaf(m[qt], LOG2E, nmz)) + bs;
     m[qt] = mn;
+  };
+  auto p1_merge = [&]() {   // (m, l) of the lanes {x, x^16, x^32, x^48} -> the row's max and sum on all four
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mm = vmax(m[qt], __shfl_xor(m[qt], 16, 64));
+      mm = vmax(mm, __shfl_xor(mm, 32, 64));
+      float ll = (m[qt] == -INFINITY) ? 0.f : l[qt] * __builtin_amdgcn_exp2f((m[qt] - mm) * LOG2E);
+      ll += __shfl_xor(ll, 16, 64);
+      ll += __shfl_xor(ll, 32, 64);
+      m[qt] = mm; l[qt] = ll;
+    }
   };
   for (int attempt = 0; attempt < 2; ++attempt) {
     // pass 1: online row max / sum of exp over keys [0, kend)
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
       for (int qt = 0; qt < QT; ++qt) {
         float s[8];
         scores_raw(qt, ka, kb_, s);
-        p1_update(qt, s);
+        p1_update(qt, s, false);
       }
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
@@ -156,13 +167,14 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
         float s[8];
         scores_raw(qt, ka, kb_, s);
         mask_block(kb0, qt, s);
-        p1_update(qt, s);
+        p1_update(qt, s, true);
       }
       if (more) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) { ka[kb] = na[kb]; kb_[kb] = nb[kb]; }
       }
     }
+    p1_merge();
     // a row whose allowed-key set is empty (a left-pad query): the reference's additive finfo.min mask
     // makes its softmax uniform over ALL keys of the sequence, causal or not -> redo over the full range
     bool empty_row = false;
