@@ -245,21 +245,42 @@ __global__ __launch_bounds__(NT) void kv_scatter_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restrict__ buf, int ld, int vcol0, int dh,
                                                          const int32_t* __restrict__ cu, const int32_t* __restrict__ vt_cu,
                                                          bf16_t* __restrict__ vt, int vt_total) {
-  __shared__ bf16_t tile[64][66];
+  // 16-byte global loads (8 features of a token) and 16-byte global stores (8 tokens of a feature); the 64 x 64 tile
+  // turns in LDS (row stride 72 elements = 144 B keeps the 16-byte rows aligned and spreads the column reads over banks)
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
   const int q = blockIdx.z;
   const int t0 = cu[q], len = cu[q + 1] - t0;
   const int j0 = blockIdx.x * 64;
   if (j0 >= len) return;
   const int f0 = blockIdx.y * 64;  // feature (h*dh + e) tile
   const int padlen = vt_cu[q + 1] - vt_cu[q];
-  for (int e = threadIdx.x; e < 64 * 64; e += NT) {
-    const int j = e >> 6, f = e & 63;
-    tile[j][f] = (j0 + j < len) ? buf[(size_t)(t0 + j0 + j) * ld + vcol0 + f0 + f] : (bf16_t)0;
+  const bool vec = ((ld | vcol0) % 8 == 0) && (vt_total % 8 == 0);
+  if (!vec) {
+    for (int e = threadIdx.x; e < 64 * 64; e += NT) {
+      const int j = e >> 6, f = e & 63;
+      tile[j][f] = (j0 + j < len) ? buf[(size_t)(t0 + j0 + j) * ld + vcol0 + f0 + f] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += NT) {
+      const int f = e >> 6, j = e & 63;
+      if (j0 + j < padlen) vt[(size_t)(f0 + f) * vt_total + vt_cu[q] + j0 + j] = tile[j][f];
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < 64 * 8; e += NT) {
+    const int j = e >> 3, fc = (e & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (j0 + j < len) v = *reinterpret_cast<const uint4*>(buf + (size_t)(t0 + j0 + j) * ld + vcol0 + f0 + fc);
+    *reinterpret_cast<uint4*>(&tile[j][fc]) = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 64 * 64; e += NT) {
-    const int f = e >> 6, j = e & 63;
-    if (j0 + j < padlen) vt[(size_t)(f0 + f) * vt_total + vt_cu[q] + j0 + j] = tile[j][f];
+  for (int e = threadIdx.x; e < 64 * 8; e += NT) {
+    const int f = e >> 3, jc = (e & 7) * 8;
+    if (j0 + jc >= padlen) continue;   // padlen is a multiple of 32: whole 8-token groups
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[jc + 2 * k][f] | ((uint32_t)tile[jc + 2 * k + 1][f] << 16);
+    *reinterpret_cast<uint4*>(vt + (size_t)(f0 + f) * vt_total + vt_cu[q] + j0 + jc) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
