@@ -285,29 +285,81 @@ __global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------ ProteinPooler (A3)
-// grid (nprot, ceil(d/NT)); thread = one feature column
-__global__ __launch_bounds__(NT) void pool_kernel(const bf16_t* __restrict__ h, int d, const int32_t* __restrict__ seg,
-                                                  const int32_t* __restrict__ rng, int mode, bf16_t* __restrict__ out) {
-  const int p = blockIdx.x;
-  const int c = blockIdx.y * NT + threadIdx.x;
-  if (c >= d) return;
+// Two stages so that a 32-protein batch fills the chip: stage 1, grid (nprot, ceil(d/512), POOL_CH): a thread owns 8
+// consecutive features (one 16-byte load per token) of the tokens t with t mod (4*POOL_CH) == 4*chunk + threadIdx.x/64;
+// the four token partitions of a workgroup meet in LDS, the chunk results (fp32 sum / max + count) go to a workspace;
+// stage 2 adds the POOL_CH chunks in order and applies torch.nanmean's two roundings.
+constexpr int POOL_CH = 8;
+__global__ __launch_bounds__(NT) void pool_partial_kernel(const bf16_t* __restrict__ h, int d, const int32_t* __restrict__ seg,
+                                                          const int32_t* __restrict__ rng, int mode, float* __restrict__ wsum,
+                                                          int* __restrict__ wcnt) {
+  __shared__ float part[3][64][8];
+  __shared__ int pcnt[3][64][8];
+  const int p = blockIdx.x, ch = blockIdx.z;
+  const int fg = threadIdx.x & 63, tp = threadIdx.x >> 6;
+  const int c = blockIdx.y * 512 + fg * 8;
+  const bool live = c < d;   // d % 8 == 0
   const int r0 = seg[p], r1 = seg[p + 1];
-  float acc = (mode == 2) ? -INFINITY : 0.f;
-  int cnt = 0;
-  for (int r = r0; r < r1; ++r) {
-    int st = rng[2 * r], ln = rng[2 * r + 1];
-    if (mode == 1) {  // x[1:-1] of the concatenation: drop first token of first range, last of last
-      if (r == r0) { st += 1; ln -= 1; }
-      if (r == r1 - 1) ln -= 1;
-    }
-    for (int j = 0; j < ln; ++j) {
-      const float v = bf2f(h[(size_t)(st + j) * d + c]);
-      if (mode == 2) acc = fmaxf(acc, v);
-      else if (v == v) { acc += v; ++cnt; }  // nanmean skips NaNs
+  constexpr int STEP = 4 * POOL_CH;
+  const int mine = 4 * ch + tp;
+  float acc[8];
+  int cnt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[e] = (mode == 2) ? -INFINITY : 0.f; cnt[e] = 0; }
+  if (live) {
+    int tok = 0;   // running token index over the concatenated ranges
+    for (int r = r0; r < r1; ++r) {
+      int st = rng[2 * r], ln = rng[2 * r + 1];
+      if (mode == 1) {  // x[1:-1] of the concatenation: drop first token of first range, last of last
+        if (r == r0) { st += 1; ln -= 1; }
+        if (r == r1 - 1) ln -= 1;
+      }
+      for (int j = ((mine - tok) % STEP + STEP) % STEP; j < ln; j += STEP) {
+        const uint4 u = *reinterpret_cast<const uint4*>(h + (size_t)(st + j) * d + c);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (e & 1) ? hi_bf(w[e >> 1]) : lo_bf(w[e >> 1]);
+          if (mode == 2) acc[e] = fmaxf(acc[e], v);
+          else if (v == v) { acc[e] += v; ++cnt[e]; }  // nanmean skips NaNs
+        }
+      }
+      tok += ln > 0 ? ln : 0;
     }
   }
+  if (tp > 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { part[tp - 1][fg][e] = acc[e]; pcnt[tp - 1][fg][e] = cnt[e]; }
+  }
+  __syncthreads();
+  if (tp == 0 && live) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[e];
+      int n = cnt[e];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (mode == 2) a = fmaxf(a, part[q][fg][e]);
+        else { a += part[q][fg][e]; n += pcnt[q][fg][e]; }
+      }
+      wsum[((size_t)p * POOL_CH + ch) * d + c + e] = a;
+      wcnt[((size_t)p * POOL_CH + ch) * d + c + e] = n;
+    }
+  }
+}
+__global__ __launch_bounds__(NT) void pool_finish_kernel(const float* __restrict__ wsum, const int* __restrict__ wcnt, int d, int mode,
+                                                         bf16_t* __restrict__ out) {
+  const int p = blockIdx.x, c = blockIdx.y * NT + threadIdx.x;
+  if (c >= d) return;
+  float a = wsum[(size_t)p * POOL_CH * d + c];
+  int n = wcnt[(size_t)p * POOL_CH * d + c];
+  for (int ch = 1; ch < POOL_CH; ++ch) {
+    const float v = wsum[((size_t)p * POOL_CH + ch) * d + c];
+    if (mode == 2) a = fmaxf(a, v);
+    else { a += v; n += wcnt[((size_t)p * POOL_CH + ch) * d + c]; }
+  }
   // torch.nanmean on bf16: nansum (fp32 accumulate, rounded to bf16) / count, rounded again
-  out[(size_t)p * d + c] = (mode == 2) ? f2bf(acc) : f2bf(rbf(acc) / (float)cnt);
+  out[(size_t)p * d + c] = (mode == 2) ? f2bf(a) : f2bf(rbf(a) / (float)n);
 }
 
 // ------------------------------------------------------------------ greedy pick (A8): argmax + log-prob
@@ -474,8 +526,14 @@ void pcy_launch_transpose_v(hipStream_t s, const bf16_t* buf, int ld, int vcol0,
   const int maxpad = (max_len + 31) / 32 * 32;
   hipLaunchKernelGGL(transpose_v_kernel, dim3((maxpad + 63) / 64, nh * dh / 64, nseq), dim3(NT), 0, s, buf, ld, vcol0, dh, cu, vt_cu, vt, vt_total);
 }
-void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, bf16_t* out) {
-  if (nprot > 0) hipLaunchKernelGGL(pool_kernel, dim3(nprot, (d + NT - 1) / NT), dim3(NT), 0, s, h, d, seg, rng, mode, out);
+size_t pcy_pool_ws_bytes(int nprot, int d) { return (size_t)nprot * POOL_CH * d * 8; }
+void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, bf16_t* out,
+                     void* ws) {
+  if (nprot <= 0) return;
+  float* wsum = reinterpret_cast<float*>(ws);
+  int* wcnt = reinterpret_cast<int*>(wsum + (size_t)nprot * POOL_CH * d);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(nprot, (d + 511) / 512, POOL_CH), dim3(NT), 0, s, h, d, seg, rng, mode, wsum, wcnt);
+  hipLaunchKernelGGL(pool_finish_kernel, dim3(nprot, (d + NT - 1) / NT), dim3(NT), 0, s, wsum, wcnt, d, mode, out);
 }
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
                             int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials) {

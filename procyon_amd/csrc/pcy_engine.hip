@@ -403,7 +403,9 @@ int pcy_embed_splice(pcy_ctx* c, const void* table, const int32_t* ids, const vo
 }
 int pcy_pool(pcy_ctx* c, const void* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, void* out) {
   if (mode < 0 || mode > 2) return fail(1, "pcy_pool: mode %d", mode);
-  pcy_launch_pool(c->stream, (const bf16_t*)hidden, d, seg, rng, nprot, mode, (bf16_t*)out);
+  if (d % 8) return fail(1, "pcy_pool: d=%d must be a multiple of 8", d);
+  if (int r = c->reserve(pcy_pool_ws_bytes(nprot, d) + 256)) return r;
+  pcy_launch_pool(c->stream, (const bf16_t*)hidden, d, seg, rng, nprot, mode, (bf16_t*)out, c->ws);
   return check_launch("pcy_pool");
 }
 

@@ -80,8 +80,9 @@ struct PcyDecAttnArgs {
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 
 // pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
+size_t pcy_pool_ws_bytes(int nprot, int d);
 void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot,
-                     int mode, bf16_t* out);
+                     int mode, bf16_t* out, void* ws);
 // per-row argmax (lowest index on ties) over bf16 logits [B,V]; accumulates log_softmax(logits)[tok] into
 // logprob[B] (bf16 log-softmax, fp32 running sum), appends tok to tokens_out[b*max_steps + step], writes
 // next_tok[b], then (one thread) ++*step and, if advance_pos, ++*pos.
