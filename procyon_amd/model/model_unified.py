@@ -354,8 +354,8 @@ class UnifiedProCyon:
     def _generate_sampling(self, input_embeds, attn_masks, max_len=64, num_text_per_instance=1, temperature=1.0,
                            greedy=False, nucleus_prob=None):
         """`_generate_sampling` (model_unified.py:861-921).  Greedy runs entirely on the device (hipGraph-replayed
-        decode steps, fused argmax + log-prob); sampling draws `torch.multinomial` on the host from the same
-        pre-sampling probability vector the reference forms."""
+        decode steps, fused argmax + log-prob); sampling forms the reference's pre-sampling probability vector and draws
+        `torch.multinomial` on the model's device, as the reference does."""
         assert nucleus_prob is None or (0 < nucleus_prob < 1)
         eng = self.text_encoder.engine
         B = len(input_embeds)
@@ -367,8 +367,10 @@ class UnifiedProCyon:
                 lp_list.append(lp.cpu().clone())
                 logit_list.append(lg.cpu())
                 continue
+            # like the reference, the per-step arithmetic (softmax, nucleus mask, multinomial) stays on the model's device;
+            # the logits record goes to the host once at the end
             out, past, logits_all = None, None, []
-            total = torch.zeros(B)
+            total = torch.zeros(B, device=self.device)
             enc = self.text_encoder
             keep_new = enc.max_new_tokens
             enc.max_new_tokens = max(keep_new, max_len)
@@ -379,7 +381,7 @@ class UnifiedProCyon:
                 else:
                     o = enc(input_ids=out[:, -1:], use_cache=True, past_key_values=past)
                 past = o.past_key_values
-                logits = o.logits[:, -1, :].cpu()
+                logits = o.logits[:, -1, :]
                 logits_all.append(logits.clone())
                 log_probs = torch.log_softmax(logits, dim=-1)
                 if nucleus_prob is not None:
@@ -388,12 +390,12 @@ class UnifiedProCyon:
                 else:
                     probs = (logits / temperature).softmax(dim=-1)
                 nxt = torch.multinomial(probs.float(), 1)
-                total += log_probs[torch.arange(B), nxt.squeeze(-1)].float()
+                total += log_probs[torch.arange(B, device=logits.device), nxt.squeeze(-1)].float()
                 out = nxt if out is None else torch.cat([out, nxt], dim=-1)
             enc.max_new_tokens = keep_new
-            out_list.append(out)
-            lp_list.append(total)
-            logit_list.append(torch.stack(logits_all, 1))
+            out_list.append(out.cpu())
+            lp_list.append(total.cpu())
+            logit_list.append(torch.stack(logits_all, 1).cpu())
         return torch.stack(out_list, dim=1), torch.stack(lp_list).T, torch.stack(logit_list, dim=1)
 
     @torch.no_grad()
@@ -402,7 +404,7 @@ class UnifiedProCyon:
         """`_generate_beam_search` (model_unified.py:702-842): diverse beam search with the reference's exact
         bookkeeping (step-0 single-beam top-g, in-place Hamming penalty carried in the score, bf16 log-softmax +
         fp32 running score, EOS-anywhere stop).  The transformer steps run on the engine; the per-step
-        O(B x groups) bookkeeping runs on the host like the reference's."""
+        O(B x groups) bookkeeping is the reference's sequence of torch ops on the model's device."""
         B = input_embeds.shape[0]
         BB = B * beam_size
         V = self.text_encoder.model.vocab_size
@@ -412,13 +414,19 @@ class UnifiedProCyon:
         groups = beam_size // beam_group_size
         emb_rep = torch.repeat_interleave(input_embeds, repeats=beam_size, dim=0)
         mask_rep = torch.repeat_interleave(attn_mask, repeats=beam_size, dim=0)
-        cur = torch.zeros((BB,))
-        out = torch.zeros(BB, max_len, dtype=torch.int64)
+        dev = self.device
+        cur = torch.zeros((BB,), device=dev)
+        out = torch.zeros(BB, max_len, dtype=torch.int64, device=dev)
         enc = self.text_encoder
         keep_new = enc.max_new_tokens
         enc.max_new_tokens = max(keep_new, max_len)
-        past, out_logits = None, None
+        past = None
+        # logits record [BB, steps, V]: preallocated on the device and reordered there (the reference keeps it on the host and
+        # pays a host copy of the whole record per group and step, model_unified.py:827-829)
+        out_logits = torch.empty(BB, max_len, V, dtype=emb_rep.dtype, device=dev)
+        steps = 0
         eng = enc.engine
+        ident = torch.arange(BB, device=dev)
         for i in range(max_len):
             if i == 0:
                 o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
@@ -426,11 +434,11 @@ class UnifiedProCyon:
             else:
                 o = enc(input_ids=out[:, i - 1].unsqueeze(-1), use_cache=True, past_key_values=past)
             past = o.past_key_values
-            logits = o.logits[:, -1, :].cpu()
-            it = logits.clone().unsqueeze(1)
-            out_logits = it if out_logits is None else torch.cat([out_logits, it], dim=1)
+            logits = o.logits[:, -1, :]
+            out_logits[:, i] = logits
+            steps = i + 1
             log_probs = torch.log_softmax(logits, dim=-1) + cur[:, None]
-            src = torch.arange(BB)
+            src = ident.clone()
             for b in range(B):
                 bs0 = b * beam_size
                 for k in range(groups):
@@ -443,14 +451,15 @@ class UnifiedProCyon:
                     top_v, top_i = lp.ravel().topk(beam_group_size)
                     orig = (top_i // V) + gs
                     out[gs:ge] = out[orig]
-                    out[torch.arange(gs, ge), i] = top_i % V
+                    out[torch.arange(gs, ge, device=dev), i] = top_i % V
                     cur[gs:ge] = top_v
-                    out_logits[gs:ge] = out_logits[orig]
+                    out_logits[gs:ge, :steps] = out_logits[orig, :steps]
                     src[gs:ge] = orig
-            if not torch.equal(src, torch.arange(BB)):
+            if not torch.equal(src, ident):
                 eng.kv_reorder(past.cache, src, past.t)  # one gather per layer instead of per-group row copies
             if torch.all((out == self.tokenizer.eos_token_id).any(dim=1)).item():
                 break
+        out, cur, out_logits = out.cpu(), cur.cpu(), out_logits[:, :steps].cpu()
         enc.max_new_tokens = keep_new
         return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
 
