@@ -203,7 +203,7 @@ size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
   return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
          align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) +
          align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) +
-         align_up((size_t)B * m->d * 2, 256) + 4096;
+         align_up((size_t)B * m->d * 2, 256) + (B > 4 ? align_up((size_t)8 * B * qkvw * 4, 256) : 0) + 4096;
 }
 
 void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
@@ -218,6 +218,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* scores = cv.take<float>((size_t)B * H * (kv->Tmax + 1));
   cv.take<char>((size_t)B * 64 * 16);                 // pick partials (same carve as enqueue_pick)
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
+  const size_t sk_bytes = B > 4 ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
+  float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   const bool batched = B > 4 && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
   PcyFusedDecArgs fa;
@@ -233,6 +235,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyGemvArgs g{};
     g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
     g.rms_cast = m->rms_cast; g.N = qkvw; g.K = d; g.B = B; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
+    g.splitk_ws = sk_ws; g.splitk_ws_bytes = sk_bytes;
     if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, B, d, m->rms_eps, m->rms_cast); g.x = xn; g.rms_w = nullptr; }
     pcy_launch_gemv(s, g);
     PcyDecAttnArgs t{};
@@ -244,6 +247,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     pcy_launch_attn_decode(s, t);
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
+    o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     pcy_launch_gemv(s, o);
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
@@ -252,6 +256,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     pcy_launch_gemv(s, u);
     PcyGemvArgs w{};
     w.W = (const bf16_t*)L.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.B = B; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
+    w.splitk_ws = sk_ws; w.splitk_ws_bytes = sk_bytes;
     pcy_launch_gemv(s, w);
   }
   PcyGemvArgs h{};

@@ -522,9 +522,194 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(PcyGemvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched decode, second generation (B = 5..32 rows): the activations are the expensive operand of gemv_mfma_kernel --
+// every 16-row workgroup re-reads all of x from L2 (x : W traffic = 2 : 1, half of a wave's loads).  Here a workgroup is
+// 4 waves x 16 output rows (32 weight rows for SwiGLU) over the SAME K range: x travels global -> LDS once per
+// workgroup in 512-k chunks (LDS-DMA, double buffered) and is shared by the four waves (x : W = 1 : 2), the vector
+// loads carry weights only.  K is split over gridDim.y workgroups when N/64 alone cannot fill the chip (o, down, qkv);
+// partial sums then go to an fp32 workspace and a small finishing kernel adds them in split order and applies the
+// epilogue (deterministic).
+typedef __attribute__((address_space(3))) void* gv_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gv_gptr_t;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_splitk_finish_kernel(PcyGemvArgs a, int ksplit) {
+  const size_t quads = (size_t)a.B * (a.N / 4);
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+    const int b = (int)(q / (a.N / 4)), n = (int)(q % (a.N / 4)) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.splitk_ws + (size_t)b * a.N + n);
+    for (int s_ = 1; s_ < ksplit; ++s_) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(a.splitk_ws + ((size_t)s_ * a.B + b) * a.N + n);
+      v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+    }
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r] = rbf(v[r] + (a.bias ? bf2f(a.bias[n + r]) : 0.f));
+      if (EPI == EPI_RESID) o[r] = rbf(o[r] + bf2f(a.resid[(size_t)b * a.ldy + n + r]));
+    }
+    *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+  }
+}
+
+template <int EPI, int BT>
+__global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int KC = 512;                      // k per x chunk
+  constexpr int XROW = KC * 2 + 16;            // LDS bytes per x row: 16 B of padding spreads the 16 rows of a fragment read over the banks
+  constexpr int XBUF = BT * 16 * XROW;
+  __shared__ __attribute__((aligned(16))) char xs[2 * XBUF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int K = a.K;
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  const int r0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  const int ks = K / ksplit;                   // multiple of KC
+  const int kbeg = blockIdx.y * ks;
+  const int nchunk = ks / KC;
+  const bf16_t* wp[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int r = r0 + rt * 16 + fr;
+    r = r < nrows ? r : nrows - 1;
+    wp[rt] = a.W + (size_t)r * K + kbeg + fq * 8;   // natural fragment layout: the 4 lanes of a row read 64 contiguous bytes per load
+  }
+  // x chunk c -> LDS buffer c & 1: one 1-KiB DMA piece per x row (rows beyond B repeat the last row), BT*4 pieces per wave
+  auto stage_x = [&](int c) {
+    char* buf = xs + (c & 1) * XBUF;
+#pragma unroll
+    for (int i = 0; i < BT * 4; ++i) {
+      const int row = wave * BT * 4 + i;
+      const int b = row < a.B ? row : a.B - 1;
+      const bf16_t* src = a.x + (size_t)b * a.ldx + kbeg + c * KC + lane * 8;
+      __builtin_amdgcn_global_load_lds((gv_gptr_t)src, (gv_lds_ptr_t)(buf + row * XROW), 16, 0, 0);
+    }
+  };
+  f32x4 acc[RT][BT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto load_w = [&](int k, bf16x8 (&wf)[RT][4]) {   // one 128-k super-step = 4 MFMA k-steps
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 v = ldg_nt(wp[rt] + k + j * 32);
+        wf[rt][j] = __builtin_bit_cast(bf16x8, v);
+      }
+  };
+  auto mma = [&](int c, int sstep, const bf16x8 (&wf)[RT][4]) {
+    const char* buf = xs + (c & 1) * XBUF;
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+      bf16x8 xf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xf[j] = *reinterpret_cast<const bf16x8*>(buf + (bt * 16 + fr) * XROW + (sstep * 128 + j * 32 + fq * 8) * 2);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[j], acc[rt][bt], 0, 0, 0);
+    }
+  };
+  stage_x(0);
+  bf16x8 wa[RT][4], wb[RT][4];
+  load_w(0, wa);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 4) : "memory");   // the x pieces are older than the weight loads
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    if (more) stage_x(c + 1);
+    // four super-steps of this chunk; the weights of the next super-step are requested before the current MFMAs
+    load_w(c * KC + 128, wb);
+    mma(c, 0, wa);
+    load_w(c * KC + 256, wa);
+    mma(c, 1, wb);
+    load_w(c * KC + 384, wb);
+    mma(c, 2, wa);
+    if (more) load_w((c + 1) * KC, wa);
+    mma(c, 3, wb);
+    if (more) {
+      // chunk c+1's x pieces were issued before this iteration's 4 weight batches: allow those (still needed) to stay in flight
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RT * 4) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  // D[n = fq*4 + r][b = fr]
+  if (r0 >= nrows) return;
+  if (ksplit > 1) {
+    float* ws = a.splitk_ws + (size_t)blockIdx.y * a.B * a.N;
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+      const int b = bt * 16 + fr;
+      if (b >= a.B) continue;
+      const int n = r0 + fq * 4;
+      if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)b * a.N + n) = acc[0][bt];
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) ws[(size_t)b * a.N + n + r] = acc[0][bt][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int bt = 0; bt < BT; ++bt) {
+    const int b = bt * 16 + fr;
+    if (b >= a.B) continue;
+    if (EPI == EPI_SWIGLU) {
+      const int f = (r0 >> 5) * 16 + fq * 4;
+      if (f >= a.N) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = rbf(silu_f(rbf(acc[0][bt][r]))) * rbf(acc[RT - 1][bt][r]);
+      *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+    } else {
+      const int n = r0 + fq * 4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = (n + r) < a.N ? n + r : a.N - 1;
+        v[r] = rbf(acc[0][bt][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
+        if (EPI == EPI_RESID) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)b * a.ldy + nn]));
+        if (EPI == EPI_GELU_ERF) v[r] = rbf(gelu_erf_f(v[r]));
+        if (EPI == EPI_GELU_ESM) v[r] = gelu_esm_chain(v[r]);
+      }
+      if (n + 3 < a.N && (a.ldy & 3) == 0) {
+        *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) a.y[(size_t)b * a.ldy + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
 template <int EPI>
 void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
   const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  static const int gen = [] { const char* e = getenv("PCY_GEMV_MFMA_GEN"); return e ? atoi(e) : 2; }();
+  if (gen == 2 && (a.ldx % 8) == 0) {
+    const int rpw = (EPI == EPI_SWIGLU) ? 32 : 16;          // weight rows per wave
+    const int bx = (nrows + 4 * rpw - 1) / (4 * rpw);
+    // K split: enough workgroups for two per CU; only with a plain / residual epilogue and a workspace
+    int ksplit = 1;
+    if ((EPI == EPI_STORE || EPI == EPI_RESID) && a.splitk_ws && a.N % 4 == 0 && (a.ldy & 3) == 0)
+      while (ksplit < 8 && bx * ksplit < 256 && a.K % (ksplit * 2 * 512) == 0 &&
+             (size_t)(ksplit * 2) * a.B * a.N * 4 <= a.splitk_ws_bytes) ksplit *= 2;
+    if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 1>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
+    else hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 2>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
+    if (ksplit > 1) {
+      const int eb = (int)(((size_t)a.B * (a.N / 4) + 255) / 256);
+      if (EPI == EPI_RESID) hipLaunchKernelGGL(gemv_splitk_finish_kernel<EPI_RESID>, dim3(eb), dim3(256), 0, s, a, ksplit);
+      else hipLaunchKernelGGL(gemv_splitk_finish_kernel<EPI_STORE>, dim3(eb), dim3(256), 0, s, a, ksplit);
+    }
+    return;
+  }
   const int rpb = (EPI == EPI_SWIGLU) ? 32 : 16;
   const int blocks = (nrows + rpb - 1) / rpb;
   if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma_kernel<EPI, 1>), dim3(blocks), dim3(256), 0, s, a);

@@ -13,6 +13,8 @@ struct PcyGemvArgs {
   int rms_cast;         // 0: w * bf16(x_hat) (transformers>=4.32) ; 1: bf16(w * x_hat) (4.31)
   int N, K, B, ldx, ldy, epi;
   int plain_loads;      // debug A/B: 0 = non-temporal weight loads (default), 1 = default cache policy
+  // optional fp32 workspace [ksplit][B][N] for the batched (B > 4) kernel's K-split partial sums
+  float* splitk_ws; size_t splitk_ws_bytes;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
