@@ -447,7 +447,9 @@ class UnifiedProCyon:
                     ge = gs + beam_group_size
                     lp = log_probs[gs:gs + inc]
                     if k != 0:
-                        lp -= diversity_penalty * torch.bincount(out[bs0:gs, i], minlength=V)
+                        # = diversity_penalty * torch.bincount(out[bs0:gs, i], minlength=V) without bincount's device sync
+                        counts = torch.zeros(V, device=dev).scatter_add_(0, out[bs0:gs, i], torch.ones(gs - bs0, device=dev))
+                        lp -= diversity_penalty * counts
                     top_v, top_i = lp.ravel().topk(beam_group_size)
                     orig = (top_i // V) + gs
                     out[gs:ge] = out[orig]

@@ -14,10 +14,14 @@ def timed(name, fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
     print(f"{name}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
     return out
+model.generate(inp, max_len=3, method="beam", beam_size=10, beam_group_size=2)   # warm-up: workspace growth, first launches
 tok, sc, lg, txt = timed("beam 10/2 x 24 tokens", lambda: model.generate(inp, max_len=24, method="beam", beam_size=10, beam_group_size=2))
+timed("beam 10/2 x 24 tokens (again)", lambda: model.generate(inp, max_len=24, method="beam", beam_size=10, beam_group_size=2))
 print("  tokens", tuple(tok.shape), "scores", sc[0, :4].tolist())
 torch.manual_seed(0)
+model.generate(inp, max_len=3, method="nucleus", nucleus_prob=0.9)
 tok, lp, lg, txt = timed("nucleus x 24 tokens", lambda: model.generate(inp, max_len=24, method="nucleus", nucleus_prob=0.9))
+timed("nucleus x 24 tokens (again)", lambda: model.generate(inp, max_len=24, method="nucleus", nucleus_prob=0.9))
 print("  tokens", tuple(tok.shape))
 tok, lp, lg, txt = timed("greedy x 24 tokens", lambda: model.generate(inp, max_len=24, method="greedy"))
 z = timed("forward_sequences", lambda: model.forward_sequences(prot, get_soft_tokens=True))
