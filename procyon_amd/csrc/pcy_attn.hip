@@ -494,6 +494,155 @@ void launch_dec_ds(hipStream_t s, const PcyDecAttnArgs& a) {
   hipLaunchKernelGGL((attn_dec_kernel<DH, G, DS>), dim3(DH / DS, a.Hkv, a.B), dim3(512), smem, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decode attention + output projection in ONE launch (batch 1).  The attention of a decode step is a latency chain
+// (~14 us at t = 512..768) during which the weight stream stands still, and the o projection that follows needs 33.5 MB
+// of weights that do not depend on the attention at all.  Here workgroups [0, n_attn) run the attention body unchanged
+// (output written through to memory, then one flag per workgroup), and the remaining workgroups -- one per CU, 220 VGPRs
+// keep two of these from sharing a CU -- pull their RW x 8 waves rows of Wo into REGISTERS while the attention runs
+// (RW x K x 2 B / 64 lanes = RW x 8 x 16 B per lane for K = 4096), wait for the flags, fetch the attention output with
+// agent-scope loads and finish with the same per-lane accumulation order, reduction tree and rounding points as
+// gemv_stream_kernel<1, EPI_RESID, false, 2> -- bit-identical to the two-launch path.
+// Attention workgroups have the lowest indices (dispatched first) and never wait for anyone, so the launch cannot
+// dead-lock whatever the residency; the wait carries a watchdog that sets *err and lets the kernel finish.
+__device__ __forceinline__ void ld4_asm_nt(const void* p, u32x4_t& r0, u32x4_t& r1, u32x4_t& r2, u32x4_t& r3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off nt\n\t"
+      "global_load_dwordx4 %1, %4, off offset:1024 nt\n\t"
+      "global_load_dwordx4 %2, %4, off offset:2048 nt\n\t"
+      "global_load_dwordx4 %3, %4, off offset:3072 nt"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld4_asm_sc1(const void* p, u32x4_t& r0, u32x4_t& r1, u32x4_t& r2, u32x4_t& r3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:3072 sc1"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p) : "memory");
+}
+
+template <int DH, int G, int RW>
+__global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvArgs o, int n_attn, const unsigned* epoch_p,
+                                                      unsigned* flags, unsigned* err, int dbg, int delay) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x < n_attn) {
+    constexpr int slices = DH / 16;
+    const int unit = blockIdx.x;
+    if (dbg != 3) attn_dec_body<DH, G, 16>(a, smem, unit % slices, (unit / slices) % a.Hkv, unit / (slices * a.Hkv));
+    // every wave: its (agent-scope, written-through) output stores have left; then the workgroup's flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + unit, *epoch_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- output projection: K == 4096 (8 x 16 B per lane and row), rows [r0, r0 + RW) of this wave ----
+  constexpr int KC = 8;
+  const int K = o.K;
+  const int r0 = ((blockIdx.x - n_attn) * 8 + wave) * RW;
+  const bool active = r0 < o.N;
+  u32x4_t wv[RW][KC];
+  float res[RW], bia[RW];
+  if (dbg == 2) return;
+  if (delay > 0) {   // let the latency-critical first loads of the attention workgroups go ahead of the weight stream
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)delay) __builtin_amdgcn_s_sleep(8);
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int r = r0 + i < o.N ? r0 + i : o.N - 1;
+      const bf16_t* p = o.W + (size_t)r * K + lane * 8;
+      ld4_asm_nt(p, wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
+      ld4_asm_nt(p + 2048, wv[i][4], wv[i][5], wv[i][6], wv[i][7]);
+      res[i] = o.resid ? bf2f(o.resid[r]) : 0.f;
+      bia[i] = o.bias ? bf2f(o.bias[r]) : 0.f;
+    }
+  }
+  const unsigned epoch = *epoch_p;
+  if (wave == 0 && dbg != 1) {
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+      for (int i = lane; i < n_attn; i += 64)
+        ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 18)) { if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  u32x4_t xv[KC];
+  ld4_asm_sc1(o.x + lane * 8, xv[0], xv[1], xv[2], xv[3]);
+  ld4_asm_sc1(o.x + 2048 + lane * 8, xv[4], xv[5], xv[6], xv[7]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    asm volatile("" : "+v"(xv[c]));
+#pragma unroll
+    for (int i = 0; i < RW; ++i) asm volatile("" : "+v"(wv[i][c]));
+  }
+  float acc[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const uint4 x4 = make_uint4(xv[c][0], xv[c][1], xv[c][2], xv[c][3]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) acc[i] = dot8(make_uint4(wv[i][c][0], wv[i][c][1], wv[i][c][2], wv[i][c][3]), x4, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < RW; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      if (r0 + i >= o.N) continue;
+      float v = rbf(acc[i] + bia[i]);
+      if (o.resid) v = rbf(v + res[i]);
+      o.y[r0 + i] = f2bf(v);
+    }
+  }
+}
+
+template <int DH, int G>
+bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch, unsigned* flags, unsigned* err) {
+  const int n_attn = (DH / 16) * a.Hkv * a.B;
+  const int n_o = n_cu - n_attn;
+  if (n_o < 64) return false;
+  const int rw = (o.N + n_o * 8 - 1) / (n_o * 8);
+  if (rw > 4) return false;
+  a.o_sc1 = 1;
+  // timing experiments (results invalid): 1 = no wait for the attention, 2 = attention workgroups only, 3 = no attention
+  static const int dbg = [] { const char* e = getenv("PCY_AO_DBG"); return e ? atoi(e) : 0; }();
+  // The attention issues all of its cache reads (<= 1024 keys) in its first microsecond; 33.5 MB of weight reads queued at
+  // the same moment delay them (attention workgroups alone 15.2 us, beside the immediate weight stream 17.9 us).  The o
+  // workgroups therefore start ~5 us late: decode step 3.335 (no delay) -> 3.285 (4 us) -> 3.277 ms (8 us) at t = 512..768;
+  // 5 us still leaves the stream (~6 us) inside the shortest attention.  PCY_AO_DELAY overrides, in 10 ns ticks.
+  static const int delay = [] { const char* e = getenv("PCY_AO_DELAY"); return e ? atoi(e) : 500; }();
+  const size_t smem = attn_dec_smem_bytes(G, 16, DH, a.Tmax);
+  const dim3 grid(n_attn + (o.N + rw * 8 - 1) / (rw * 8)), block(512);
+#define PCY_AO_LAUNCH(RWV)                                                                                          \
+  do {                                                                                                              \
+    static size_t configured = 0;                                                                                   \
+    if (smem > 65536 && smem > configured) {                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_o_kernel<DH, G, RWV>),                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
+      configured = smem;                                                                                            \
+    }                                                                                                               \
+    hipLaunchKernelGGL((attn_o_kernel<DH, G, RWV>), grid, block, smem, s, a, o, n_attn, epoch, flags, err, dbg, delay); \
+  } while (0)
+  switch (rw) {
+    case 1: PCY_AO_LAUNCH(1); break;
+    case 2: PCY_AO_LAUNCH(2); break;
+    case 3: PCY_AO_LAUNCH(3); break;
+    default: PCY_AO_LAUNCH(4); break;
+  }
+#undef PCY_AO_LAUNCH
+  return true;
+}
+
 template <int DH, int G>
 void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
   // widest slice that still leaves >= ~1 workgroup per CU (PCY_DEC_DS overrides, for measurements)
@@ -552,4 +701,19 @@ void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a) {
   if (a.dh == 128) launch_dec_g<128>(s, a);
   else if (a.dh == 64) launch_dec_g<64>(s, a);
   else launch_dec_g<32>(s, a);
+}
+
+// Fused decode attention + o projection (see attn_o_kernel).  Returns false (nothing launched) when the shape is not
+// covered: batch 1, head_dim 128, G in {1,2,4,8}, K = H*dh = 4096 contiguous, residual epilogue without x staging.
+bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
+                       unsigned* flags, int max_flags, unsigned* err) {
+  if (a.B != 1 || o.B != 1 || a.dh != 128 || o.K != 4096 || o.rms_w || o.epi != EPI_RESID || a.dbg) return false;
+  if ((a.dh / 16) * a.Hkv * a.B > max_flags || n_cu > 256) return false;
+  switch (a.H / a.Hkv) {
+    case 1: return launch_attn_o_rw<128, 1>(s, a, o, n_cu, epoch, flags, err);
+    case 2: return launch_attn_o_rw<128, 2>(s, a, o, n_cu, epoch, flags, err);
+    case 4: return launch_attn_o_rw<128, 4>(s, a, o, n_cu, epoch, flags, err);
+    case 8: return launch_attn_o_rw<128, 8>(s, a, o, n_cu, epoch, flags, err);
+  }
+  return false;
 }

@@ -80,6 +80,11 @@ struct PcyDecAttnArgs {
   int t_plus1; int o_sc1;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
+struct PcyGemvArgs;
+// decode attention + o projection (EPI_RESID GEMV over the attention output) in one launch; false = shape not covered,
+// nothing launched.  epoch: device word that differs between consecutive calls on the same `flags` (max_flags words).
+bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
+                       unsigned* flags, int max_flags, unsigned* err);
 
 // pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
 size_t pcy_pool_ws_bytes(int nprot, int d);

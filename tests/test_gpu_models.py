@@ -242,6 +242,40 @@ def test_decode_persistent_kernel_matches_layered(monkeypatch):
     assert rel_err(a[2], ref[2]) < 5e-3 and rel_err(a[3], ref[3]) < 5e-3
 
 
+def test_decode_attn_o_fused_launch_bit_identical(monkeypatch):
+    """PCY_ATTN_O (default on): decode attention and o projection in one launch -- Wo rows wait in registers while the
+    attention workgroups run, hand-over by per-workgroup flags.  Same per-lane accumulation order, reduction tree and
+    rounding points as the two-launch path, so logits, tokens and the appended K/V must be BIT-identical to PCY_ATTN_O=0,
+    eager and under hipGraph replay, over enough steps that a stale flag or a missed hand-over would show; no watchdog."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=4096, d=4096, n_layers=3, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=512))
+    T, N = 300, 24
+    torch.manual_seed(4)
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(ao, use_graph):
+        monkeypatch.setenv("PCY_ATTN_O", "1" if ao else "0")
+        cache = eng.new_cache(1, T + N + 2)
+        st = GenState(1, kw["vocab"], N + 2, "cuda")
+        logits, _ = eng.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng.pick(cache, st, 1, advance_pos=False)
+        out = []
+        for _ in range(N):
+            eng.greedy_steps(cache, st, 1, 1, use_graph=use_graph)
+            out.append(st.logits[0].clone())
+        Context.get().sync()
+        return torch.stack(out).cpu(), st.tokens_out[0, :N + 1].cpu(), cache.k[:, 0, :, T:T + N].cpu(), cache.v[:, 0, :, T:T + N].cpu()
+
+    ref = run(False, False)
+    for use_graph in (False, True, True):    # the second graph run starts at the epoch / flag state the first one left
+        got = run(True, use_graph)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), use_graph
+
+
 def test_llama2_7b_geometry_layer():
     """BASELINE configs[0] geometry (ProCyon-Split text side: Llama-2-7B, multi-head attention H = Hkv = 32, F = 11008, odd
     vocabulary 32007) at full width, one layer: prefill + 3 cached decode steps against the oracle.  Exercises G = 1 in both

@@ -1,0 +1,30 @@
+"""Decode GEMVs at Llama-3-8B shapes: cold (rotating over >1.2 GB of weight copies) vs warm (the same matrix every
+launch, i.e. served by the 256 MiB Infinity Cache / L2) -- sizes what a weight prefetch during the attention could buy."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from procyon_amd.engine import Context
+ctx = Context.get()
+dev = "cuda"
+d, F, QKV = 4096, 14336, 6144
+shapes = [("qkv+rms", QKV, d, 0, True), ("o+res", d, d, 1, False), ("gateup+rms", F, d, 4, True), ("down+res", d, F, 1, False)]
+for name, N, K, epi, rms in shapes:
+    rows = 2 * N if epi == 4 else N
+    nbytes = rows * K * 2
+    ncopy = max(2, int(1.2e9 // nbytes) + 1)
+    Ws = [torch.randn(rows, K, device=dev).bfloat16() for _ in range(ncopy)]
+    x = torch.randn(1, K, device=dev).bfloat16()
+    w = torch.ones(K, device=dev).bfloat16() if rms else None
+    res = torch.randn(1, N, device=dev).bfloat16() if epi == 1 else None
+    out = torch.empty(1, N, device=dev, dtype=torch.bfloat16)
+    for mode in ("cold", "warm"):
+        seq = Ws if mode == "cold" else [Ws[0]] * ncopy
+        for W in seq:
+            ctx.gemv(W, x, resid=res, epi=epi, rms_w=w, out=out)
+        reps = max(8, 64 // ncopy)
+        ctx.timer_start()
+        for _ in range(reps):
+            for W in seq:
+                ctx.gemv(W, x, resid=res, epi=epi, rms_w=w, out=out)
+        ms = ctx.timer_stop() / (reps * ncopy)
+        print(f"{name:12s} {mode} {nbytes/1e6:8.1f} MB  {ms*1e3:7.2f} us  {nbytes/1e9/(ms/1e3):7.1f} GB/s", flush=True)
