@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 1
+#define PCY_ABI_VERSION 2
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -82,6 +82,17 @@ int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int3
  * fp32-accumulating matmul rounded once).  D must be a multiple of 64. */
 int pcy_retrieval_scores(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, void* sims_out);
 
+/* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path"; the reference has no fp8 counterpart) ----
+ * Per-row symmetric OCP e4m3 quantisation of a bf16 matrix x[rows,K] (ldx elements between rows, K % 8 == 0):
+ * scale_out[r] = the smallest power of two >= 2^-126 with amax|x[r,:]| / scale <= 448 (1 for an all-zero row),
+ * q_out[r,k] = e4m3_rne(x / scale) (exact division), q_out [rows,K] bytes.  Used once per weight matrix (per output
+ * channel) and per call on activations (per token). */
+int pcy_quant_rows_fp8(pcy_ctx*, const void* x, int ldx, int rows, int K, void* q_out, float* scale_out);
+/* C[M,N] = epi( ((A8[M,K] . W8[N,K]^T) * sa[m]) * sw[n] ) on the MX-scaled 16x16x128 fp8 MFMA (unit block scales), fp32
+ * accumulation, then the same bf16 rounding points as pcy_gemm.  epi in {STORE, RESID, SWIGLU}; K % 128 == 0. */
+int pcy_gemm_fp8(pcy_ctx*, const void* A8, const float* sa, const void* W8, const float* sw, const void* resid, int ldr,
+                 void* C, int ldc, int M, int N, int K, int epi);
+
 /* ---- create_mlp projector (model_utils.py:13-41) -------------------------------------------- */
 typedef struct {
   int32_t n_layers;          /* 1 (bias-free Linear) or >= 2 (Linear+bias -> GELU ... -> Linear+bias) */
@@ -125,6 +136,14 @@ typedef struct {
   const void* wdown;         /* [d, F] */
   const void *ln1, *ln2;     /* [d] */
 } pcy_llama_layer;
+/* optional e4m3 copies of the four projection matrices (same row order / interleave as the bf16 ones) and their per-row
+ * scales (pcy_quant_rows_fp8).  When pcy_llama_desc.layers_fp8 != NULL, pcy_llama_prefill quantises the input of every
+ * projection per token and runs it through pcy_gemm_fp8; norms, rope, attention, residuals, lm_head and the whole
+ * decode path stay bf16. */
+typedef struct {
+  const void *wqkv, *wo, *wgu, *wdown;
+  const float *sqkv, *so, *sgu, *sdown;
+} pcy_llama_layer_fp8;
 typedef struct {
   int32_t vocab, d, n_layers, n_heads, n_kv_heads, head_dim, ffn, max_pos;
   float rms_eps;
@@ -134,6 +153,7 @@ typedef struct {
   const void* lm_head;       /* [vocab,d] */
   const void *rope_cos, *rope_sin; /* [max_pos, head_dim] bf16 (table precision is the caller's choice, Q9/Q10) */
   const pcy_llama_layer* layers;   /* host array [n_layers] */
+  const pcy_llama_layer_fp8* layers_fp8; /* host array [n_layers] or NULL (bf16 weights everywhere) */
 } pcy_llama_desc;
 typedef struct {
   void* k;                   /* [L,B,Hkv,Tmax,dh] bf16: layer l rows = past_key_values[l][0] */

@@ -36,6 +36,9 @@ class LlamaGeom:
     # rope tables: 'fp32' = cos/sin from fp32 inv_freq rounded once to model dtype
     # (4.31 cached tables); 'bf16_inv_freq' = 5.15 behaviour after model.bfloat16()
     rope_table: str = "fp32"
+    # 'bf16' (the reference) or 'fp8': the q/k/v/o/gate/up/down projections of the PREFILL run through
+    # oracle.fp8_ref.linear_fp8 (BASELINE configs[4]; no reference counterpart), cached decode steps stay bf16
+    weights: str = "bf16"
 
     @property
     def dh(self) -> int:
@@ -100,11 +103,14 @@ def layer_forward(h, lw, geom: LlamaGeom, cos, sin, add_mask, past_kv):
     """One decoder layer.  h [B,T,d]; past_kv = (K,V) [B,Hkv,t,dh] or None."""
     B, T, _ = h.shape
     H, Hkv, dh = geom.n_heads, geom.n_kv_heads, geom.dh
+    lin = F.linear
+    if geom.weights == "fp8" and past_kv is None:
+        from .fp8_ref import linear_fp8 as lin
     res = h
     x = rms_norm(h, lw["input_layernorm.weight"], geom.rms_eps, geom.rms_cast)
-    q = F.linear(x, lw["self_attn.q_proj.weight"]).view(B, T, H, dh).transpose(1, 2)
-    k = F.linear(x, lw["self_attn.k_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
-    v = F.linear(x, lw["self_attn.v_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
+    q = lin(x, lw["self_attn.q_proj.weight"]).view(B, T, H, dh).transpose(1, 2)
+    k = lin(x, lw["self_attn.k_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
+    v = lin(x, lw["self_attn.v_proj.weight"]).view(B, T, Hkv, dh).transpose(1, 2)
     q, k = apply_rope(q, k, cos, sin)
     if past_kv is not None:
         k = torch.cat([past_kv[0], k], dim=2)
@@ -118,13 +124,13 @@ def layer_forward(h, lw, geom: LlamaGeom, cos, sin, add_mask, past_kv):
         s = s + add_mask
     p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
     o = torch.matmul(p, vv).transpose(1, 2).contiguous().reshape(B, T, H * dh)
-    o = F.linear(o, lw["self_attn.o_proj.weight"])
+    o = lin(o, lw["self_attn.o_proj.weight"])
     h = res + o
     res = h
     x = rms_norm(h, lw["post_attention_layernorm.weight"], geom.rms_eps, geom.rms_cast)
-    gate = F.linear(x, lw["mlp.gate_proj.weight"])
-    up = F.linear(x, lw["mlp.up_proj.weight"])
-    m = F.linear(F.silu(gate) * up, lw["mlp.down_proj.weight"])
+    gate = lin(x, lw["mlp.gate_proj.weight"])
+    up = lin(x, lw["mlp.up_proj.weight"])
+    m = lin(F.silu(gate) * up, lw["mlp.down_proj.weight"])
     return res + m, new_kv
 
 

@@ -34,10 +34,15 @@ class LlamaLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2")]
 
 
+class LlamaLayerFp8(C.Structure):
+    _fields_ = [(n, vp) for n in ("wqkv", "wo", "wgu", "wdown", "sqkv", "so", "sgu", "sdown")]
+
+
 class LlamaDesc(C.Structure):
     _fields_ = [("vocab", i32), ("d", i32), ("n_layers", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("max_pos", i32), ("rms_eps", C.c_float), ("rms_cast", i32), ("embed", vp),
-                ("final_norm", vp), ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("layers", C.POINTER(LlamaLayer))]
+                ("final_norm", vp), ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("layers", C.POINTER(LlamaLayer)),
+                ("layers_fp8", C.POINTER(LlamaLayerFp8))]
 
 
 class KvCache(C.Structure):
@@ -68,6 +73,8 @@ SIGNATURES = {
     "pcy_attn_decode": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "pcy_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
     "pcy_retrieval_scores": (ci, [vp, vp, ci, vp, ci, ci, vp]),
+    "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
+    "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp]),
@@ -100,7 +107,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pcy_abi_version() != 1:
+    if lib.pcy_abi_version() != 2:
         raise PcyError("libpcy.so ABI version mismatch")
     _lib = lib
     return lib

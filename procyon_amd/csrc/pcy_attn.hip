@@ -679,7 +679,16 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   // var 1 = LDS-shared K/Vt tiles (attn_lds_kernel): measured equal to the register-fragment kernel (341 vs 346
   // proteins/s) -- the kernel is not L2-bound -- so the simpler one stays the default
   if (var == 1 && a.dh == 64) { hipLaunchKernelGGL((attn_lds_kernel<64, 3>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a); return; }
-  if (var == 1 && a.dh == 128) { hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a); return; }
+  // head_dim 128 (Llama prefill): one q tile per wave leaves 16 K/Vt fragment loads of 1 KiB per 16 MFMAs to every wave of
+  // the register-fragment kernel -- L1/L2 bound (44 TFLOP/s at B = 64, T = 450).  The LDS-shared variant fetches each key
+  // block once per workgroup: Llama-3-8B pair-scoring prefill 870 -> 932 TFLOP/s (bf16), 1350 -> 1490 (fp8 weights).
+  // PCY_ATTN_VAR=2 selects the register-fragment kernel again; PCY_ATTN_LDS_QT = q tiles per wave (1 or 2).
+  if (var != 2 && a.dh == 128) {
+    static const int qt = [] { const char* e = getenv("PCY_ATTN_LDS_QT"); return e ? atoi(e) : 1; }();
+    if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<128, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
+    return;
+  }
   const bool scaled = a.scale != 1.0f;
 #define PCY_ATTN_LAUNCH(DHV, QTV, ROWS)                                                                                    \
   do {                                                                                                                      \

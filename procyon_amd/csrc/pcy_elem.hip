@@ -478,7 +478,57 @@ __global__ __launch_bounds__(NT) void acc_finish_kernel(const float* __restrict_
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) out[i] = f2bf(acc[i]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 path (BASELINE configs[4], no reference counterpart): per-row symmetric OCP e4m3 quantisation of a bf16 matrix.
+// One workgroup per row, two passes over the (L2-resident) row: amax, then q = e4m3_rne(x / scale) with the smallest
+// power-of-two scale >= 2^-126 that brings the row maximum to <= 448 (1.0 for an all-zero row): the division is exact, and
+// a one-ulp difference in the row maximum cannot re-bucket the whole row.  oracle/fp8_ref.py::quant_rows restates exactly this.
+__device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int ldx, int K, unsigned char* __restrict__ q,
+                                                             float* __restrict__ scale) {
+  __shared__ float red[4];
+  const size_t r = blockIdx.x;
+  const bf16_t* xr = x + r * ldx;
+  float amax = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(lo_bf(w[j])), fabsf(hi_bf(w[j]))));
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sc = 1.f;
+  if (amax > 0.f) {
+    int e0 = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;     // amax = 1.m * 2^(e0+8); 448 = 1.75 * 2^8
+    e0 = e0 < -126 ? -126 : e0;
+    const float s0 = __uint_as_float((uint32_t)(e0 + 127) << 23);
+    sc = amax <= 448.f * s0 ? s0 : 2.f * s0;
+  }
+  const float inv = 1.f / sc;   // exact: sc is a power of two
+  if (threadIdx.x == 0) scale[r] = sc;
+  unsigned char* qr = q + r * (size_t)K;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + k);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = clamp448(lo_bf(w[j]) * inv); f[2 * j + 1] = clamp448(hi_bf(w[j]) * inv); }
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *reinterpret_cast<uint2*>(qr + k) = make_uint2((uint32_t)lo, (uint32_t)hi);
+  }
+}
+
 }  // namespace
+
+void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale) {
+  if (rows > 0) hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(rows), dim3(256), 0, s, x, ldx, K, q, scale);
+}
 
 void pcy_launch_acc_rows(hipStream_t s, const bf16_t* src, int lds_, const int32_t* rows, float* acc, int nrows, int d, int first) {
   if (nrows > 0) hipLaunchKernelGGL(acc_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, rows, acc, d, first);

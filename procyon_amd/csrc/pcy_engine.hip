@@ -474,6 +474,22 @@ int pcy_attn_decode(pcy_ctx* c, void* qkv, int ld, void* kcache, void* vcache, v
   return check_launch("pcy_attn_decode");
 }
 
+int pcy_quant_rows_fp8(pcy_ctx* c, const void* x, int ldx, int rows, int K, void* q_out, float* scale_out) {
+  if (rows < 0 || K <= 0 || K % 8 || ldx % 8) return fail(1, "pcy_quant_rows_fp8: K=%d ldx=%d must be multiples of 8", K, ldx);
+  pcy_launch_quant_rows_fp8(c->stream, (const bf16_t*)x, ldx, rows, K, (unsigned char*)q_out, scale_out);
+  return check_launch("pcy_quant_rows_fp8");
+}
+int pcy_gemm_fp8(pcy_ctx* c, const void* A8, const float* sa, const void* W8, const float* sw, const void* resid, int ldr,
+                 void* C, int ldc, int M, int N, int K, int epi) {
+  if (K <= 0 || K % 128) return fail(1, "pcy_gemm_fp8: K=%d must be a multiple of 128", K);
+  if (epi != EPI_STORE && epi != EPI_RESID && epi != EPI_SWIGLU) return fail(1, "pcy_gemm_fp8: epilogue %d unsupported", epi);
+  if (epi == EPI_SWIGLU && N % 32) return fail(1, "pcy_gemm_fp8: SwiGLU needs N %% 32 == 0");
+  PcyGemmArgs a{};
+  a.A = (const bf16_t*)A8; a.W = (const bf16_t*)W8; a.C = (bf16_t*)C; a.resid = (const bf16_t*)resid;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.ldr = ldr; a.epi = epi; a.fp8 = 1; a.sa = sa; a.sw = sw;
+  pcy_launch_gemm(c->stream, a);
+  return check_launch("pcy_gemm_fp8");
+}
 int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, void* sims_out) {
   if (D % 64) return fail(1, "pcy_retrieval_scores: D=%d must be a multiple of 64", D);
   const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256);
@@ -576,8 +592,10 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   const size_t need = align_up((size_t)M * d * 2, 256) * 2 + align_up((size_t)M * qkvw * 2, 256) + align_up((size_t)M * H * dh * 2, 256) +
                       align_up((size_t)M * F * 2, 256) + align_up((size_t)Hkv * dh * vt_total * 2, 256) +
                       align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + align_up((size_t)(n_sum_rows + 1) * d * 6, 256) +
-                      (M <= 1024 ? align_up((size_t)8 * M * qkvw * 4, 256) : 0) + 4096;
+                      (M <= 1024 ? align_up((size_t)8 * M * qkvw * 4, 256) : 0) + 4096 +
+                      (m->layers_fp8 ? align_up((size_t)M * (F > H * dh ? F : H * dh), 256) + align_up((size_t)M * 4, 256) : 0);
   if (n_sum_rows > 0 && (!sum_rows || !hidden_sum_out)) return fail(1, "pcy_llama_prefill: sum_rows / hidden_sum_out missing");
+  if (m->layers_fp8 && (d % 128 || F % 128 || (H * dh) % 128)) return fail(1, "pcy_llama_prefill: the fp8 path needs d, ffn, H*dh %% 128 == 0");
   if (int r = c->reserve(need)) return r;
   Carver cv(c->ws);
   bf16_t* x = cv.take<bf16_t>((size_t)M * d);
@@ -592,14 +610,26 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   float* hsum = cv.take<float>((size_t)(n_sum_rows + 1) * d);      // ret_token_access='all': fp32 sum of the L+1 hidden states
   bf16_t* hsum_tmp = cv.take<bf16_t>((size_t)(n_sum_rows + 1) * d);
   hipStream_t s = c->stream;
+  // fp8 weight path: every projection = per-token e4m3 quantisation of its bf16 input + the fp8 MFMA GEMM
+  unsigned char* a8 = m->layers_fp8 ? cv.take<unsigned char>((size_t)M * (F > H * dh ? F : H * dh)) : nullptr;
+  float* sa8 = m->layers_fp8 ? cv.take<float>((size_t)M) : nullptr;
+  auto linear8 = [&](const bf16_t* A, int K, const void* W8, const float* sw, const bf16_t* resid, bf16_t* Cout, int ldc, int N, int epi) {
+    pcy_launch_quant_rows_fp8(s, A, K, M, K, a8, sa8);
+    PcyGemmArgs g{};
+    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)W8; g.C = Cout; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = ldc;
+    g.ldr = ldc; g.epi = epi; g.fp8 = 1; g.sa = sa8; g.sw = sw;
+    pcy_launch_gemm(s, g);
+  };
   HIP_TRY(hipMemcpyAsync(x, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   // hidden_states = (embeddings, output of layers 0..L-2, final-normed output of layer L-1)  [HF LlamaModel.forward]
   pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 1);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
+    const pcy_llama_layer_fp8* L8 = m->layers_fp8 ? &m->layers_fp8[l] : nullptr;
     pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
-    linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
+    if (L8) linear8(xn, d, L8->wqkv, L8->sqkv, nullptr, qkv, qkvw, qkvw, EPI_STORE);
+    else linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
     pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
     pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
                           (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
@@ -609,8 +639,15 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     t.o = ao; t.ldo = H * dh; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = B; t.max_len = T; t.H = H; t.Hkv = Hkv; t.dh = dh;
     t.causal = 1; t.scale = 1.0f / sqrtf((float)dh);
     pcy_launch_attn(s, t);
-    linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes);
+    if (L8) linear8(ao, H * dh, L8->wo, L8->so, x, x, d, d, EPI_RESID);
+    else linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes);
     pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
+    if (L8) {
+      linear8(xn, d, L8->wgu, L8->sgu, nullptr, act, F, 2 * F, EPI_SWIGLU);
+      linear8(act, F, L8->wdown, L8->sdown, x, x, d, d, EPI_RESID);
+      if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
+      continue;
+    }
     if (M <= 8) {
       PcyGemvArgs u{};
       u.W = (const bf16_t*)L.wgu; u.x = xn; u.y = act; u.N = F; u.K = d; u.B = M; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;

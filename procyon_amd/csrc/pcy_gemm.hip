@@ -70,7 +70,7 @@ __device__ __forceinline__ void tile_origin(const PcyGemmArgs& a, int tile, int&
 // All global reads of the epilogue (bias: 16 values per lane, residual: 16 x 8 B per lane) are issued up front as
 // independent vector loads -- element-wise loads inside the rounding chain serialised ~64 L2 round trips per tile
 // (20 us of the 37 us a K=1280 tile took).
-template <int EPI, int WTN = 4, int WTM = 4>
+template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true>
 __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int m0, int n0, int wm, int wn, int fr, int fq) {
   m0 += wm * WTM * 16 - wm * 64;   // the code below adds wm * 64 / wn * 64 (the 4 x 4 layout)
   n0 += wn * WTN * 16 - wn * 64;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
     }
     return;
   }
-  if (EPI == EPI_STORE && a.rope_cos != nullptr) {
+  if (EPI == EPI_STORE && ROPE_OK && a.rope_cos != nullptr) {
     // fused rotary: a head = 4 consecutive 16-feature tiles, this lane holds features e..e+3 (tile t) and their partners
     // e+32.. (tile t+2) of the same token.  All loads are issued in batches ahead of the arithmetic: bias once, the
     // positions of the WTM tokens once, then per token its four cos and four sin quads (shared by every head).
@@ -393,7 +393,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(PcyGemmArgs a, int s
 // = 4 x 8 MFMA tiles.  Per 32-k step a wave reads 12 fragments for 32 MFMAs (the 128x128 kernel: 8 for 16), which takes
 // the LDS read time from 100 % to 75 % of the MFMA time of a CU, and the 256-wide tile halves the L2 traffic per flop.
 // 128 KiB of LDS (2 stages) -> one workgroup per CU, two waves per SIMD.
-template <int EPI>
+// F8 = true: the same kernel over OCP e4m3 operands.  A 128-byte LDS row then holds 128 k (instead of 64 bf16), the byte
+// geometry of staging, swizzle and fragment reads is unchanged, and a lane's two 16-byte fragments of a row (pieces fq and
+// 4 + fq) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) -- A and B use the same k -> slot map, which is all
+// a dot product needs.  Twice the k per MFMA issue slot at the MX rate = 2x the bf16 flops for the same LDS / global bytes.
+// The per-token / per-output-row dequantisation scales are applied to the fp32 accumulators in front of the epilogue.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+  return (i32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -413,9 +424,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = a.K / BK;
-  stage_tile<BK, TBM, NW>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TBN, NW>(a.W, a.K, n0, a.N, 0, smem + TILE_A, wave, lane);
+  // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
+  const int nk = F8 ? a.K / 128 : a.K / BK;
+  const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
+  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -424,23 +437,62 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     const char* Wcur = Acur + TILE_A;
     if (kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
+    if constexpr (F8) {
+      i32x8 xf[WTM];
 #pragma unroll
-    for (int kb = 0; kb < BK / 32; ++kb) {
-      bf16x8 xf[WTM], wf[WTN];
+      for (int j = 0; j < WTM; ++j)
+        xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
 #pragma unroll
-      for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
-#pragma unroll
-      for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
-#pragma unroll
-      for (int i = 0; i < WTN; ++i)
+      for (int i = 0; i < WTN; ++i) {
+        const i32x8 wf = cat_frag(lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq), lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, 4 + fq));
 #pragma unroll
         for (int j = 0; j < WTM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < BK / 32; ++kb) {
+        bf16x8 xf[WTM], wf[WTN];
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i)
+#pragma unroll
+          for (int j = 0; j < WTM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
+  }
+  if constexpr (F8) {
+    // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
+    float sx[WTM];
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = m0 + wm * WTM * 16 + j * 16 + fr;
+      sx[j] = a.sa[m < a.M ? m : a.M - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < WTN; ++i) {
+      const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sw = a.sw[n + r < a.N ? n + r : a.N - 1];
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) acc[i][j][r] = (acc[i][j][r] * sx[j]) * sw;
+      }
+    }
+    // the epilogue in two halves of 64 features: its up-front residual loads (64 VGPRs for the whole 64 x 128 wave tile)
+    // plus the scale registers would spill
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+    return;
   }
   gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
@@ -521,6 +573,23 @@ __global__ __launch_bounds__(512) void gemm_kernel_pp(PcyGemmArgs a) {
 }
 
 template <int EPI>
+void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
+  constexpr int smem = 2 * (256 + 256) * 64 * 2;
+  const int tiles_big = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  PcyGemmArgs b = a;
+  const int tn = (a.N + 255) / 256;
+  long gnb = (5L << 19) / ((long)256 * a.K);
+  if (gnb < 2) gnb = 2;
+  b.gn = (int)(gnb > tn ? tn : gnb);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
+}
+
+template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   static const int bk = [] { const char* e = getenv("PCY_GEMM_BK"); return e ? atoi(e) : 64; }();
@@ -573,6 +642,14 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (gn_env > 0) gn = gn_env;
   a.gn = (int)(gn < 1 ? 1 : (gn > tiles_n ? tiles_n : gn));
   { static const int dbg = [] { const char* e = getenv("PCY_GEMM_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+  if (a.fp8) {   // e4m3 operands: the 256 x 256 kernel for every M (callers check K % 128, lda % 16)
+    switch (a.epi) {
+      case EPI_RESID: launch_fp8<EPI_RESID>(s, a); break;
+      case EPI_SWIGLU: launch_fp8<EPI_SWIGLU>(s, a); break;
+      default: launch_fp8<EPI_STORE>(s, a); break;
+    }
+    return;
+  }
   // split-K: few tiles, long K, plain / residual epilogue, a workspace supplied by the caller
   if (a.splitk_ws && (a.epi == EPI_STORE || a.epi == EPI_RESID) && a.rope_cos == nullptr && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (a.resid == nullptr || a.ldr % 4 == 0)) {

@@ -33,9 +33,14 @@ struct PcyGemmArgs {
   // optional split-K workspace (fp32 [splits][M][N]); the launcher splits K when the tile count under-fills the chip
   float* splitk_ws; size_t splitk_ws_bytes;
   int dbg;              // timing experiments only (PCY_GEMM_DBG): 1 = no global->LDS loads after the prologue, 2 = no LDS fragment reads
+  // fp8 path (BASELINE configs[4]): A and W point to OCP e4m3 bytes ([M,K] lda bytes / [N,K]), K % 128 == 0;
+  // C = epi( bf16-rounding chain of ((acc * sa[m]) * sw[n]) ), sa / sw = per-token / per-output-row dequantisation scales
+  int fp8; const float* sa; const float* sw;
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 
+// per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)
+void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale);
 void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int d, float eps, int cast);
 void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps);
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,

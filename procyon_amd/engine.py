@@ -83,6 +83,25 @@ class Context:
                                   N, K, B, epi), "pcy_gemv")
         return out
 
+    def quant_rows_fp8(self, x):
+        """Per-row symmetric OCP e4m3 quantisation of a bf16 matrix [rows,K] -> (q uint8 [rows,K], scale fp32 [rows])."""
+        _chk_bf16(x)
+        rows, K = x.shape
+        q = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+        sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.check(self.lib.pcy_quant_rows_fp8(self.h, _p(x), x.stride(0), rows, K, _p(q), _p(sc)), "pcy_quant_rows_fp8")
+        return q, sc
+
+    def gemm_fp8(self, A8, sa, W8, sw, resid=None, epi=L.EPI_STORE, out=None):
+        """epi(((A8 . W8^T) * sa[:,None]) * sw[None,:]) -> bf16; A8 [M,K], W8 [N,K] uint8 (e4m3 bits), sa [M], sw [N] fp32."""
+        M, K = A8.shape
+        N = W8.shape[0]
+        Nout = N // 2 if epi == L.EPI_SWIGLU else N
+        out = torch.empty(M, Nout, dtype=BF16, device=A8.device) if out is None else out
+        L.check(self.lib.pcy_gemm_fp8(self.h, _p(A8), _p(sa), _p(W8), _p(sw), _p(resid), 0 if resid is None else resid.shape[1],
+                                      _p(out), Nout, M, N, K, epi), "pcy_gemm_fp8")
+        return out
+
     def rmsnorm(self, x, w, eps=1e-5, cast=0):
         _chk_bf16(x, w)
         y = torch.empty_like(x)
@@ -263,7 +282,9 @@ class GenState:
 class LlamaEngine:
     """HF-Llama-architecture decoder behind `LlamaPostTokenization.forward` (pmc_llama.py:546-596)."""
 
-    def __init__(self, sd, cfg: LlamaConfig, device=None, ctx=None, free_source=False):
+    def __init__(self, sd, cfg: LlamaConfig, device=None, ctx=None, free_source=False, fp8_prefill=False):
+        """fp8_prefill: additionally keep per-output-channel e4m3 copies of the four projections of every layer and run
+        the prefill's projections on the fp8 MFMA path (BASELINE configs[4]; `set_fp8(False)` switches back to bf16)."""
         self.ctx = ctx or Context.get(device)
         self.cfg = cfg
         dev = self.ctx.device
@@ -293,6 +314,26 @@ class LlamaEngine:
                                 cfg.max_pos, cfg.rms_eps, 0 if cfg.rms_cast == "hf5" else 1, self.embed.data_ptr(),
                                 self.final_norm.data_ptr(), self.lm_head.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(),
                                 C.cast(arr, C.POINTER(L.LlamaLayer)))
+        self._arr8 = None
+        if fp8_prefill:
+            self.quantize_fp8()
+
+    def quantize_fp8(self):
+        """e4m3 copies + per-row scales of wqkv / wo / wgu / wdown (8 GB on top of the 16 GB of a Llama-3-8B), fp8 path on."""
+        if self._arr8 is None:
+            self._keep8 = []
+            arr8 = (L.LlamaLayerFp8 * self.cfg.n_layers)()
+            for l, ws in enumerate(self._keep):
+                qs = [self.ctx.quant_rows_fp8(w) for w in ws[:4]]
+                self._keep8.append(qs)
+                arr8[l] = L.LlamaLayerFp8(*[q.data_ptr() for q, _ in qs], *[sc.data_ptr() for _, sc in qs])
+            self._arr8 = arr8
+        self.set_fp8(True)
+
+    def set_fp8(self, on):
+        if on and self._arr8 is None:
+            raise ValueError("no fp8 weights: construct with fp8_prefill=True or call quantize_fp8()")
+        self.desc.layers_fp8 = C.cast(self._arr8, C.POINTER(L.LlamaLayerFp8)) if on else C.POINTER(L.LlamaLayerFp8)()
 
     def new_cache(self, B, Tmax):
         return KVCache(self.cfg, B, Tmax, self.device)
