@@ -21,6 +21,43 @@ constexpr int GEMM_THREADS = 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
+// The ESM GELU chain (five bf16 tensors, pcy_common.h::gelu_esm_chain) is a FUNCTION bf16 -> bf16, so the fc1 epilogue looks
+// it up instead of evaluating ~45 VALU instructions per output (139 of the 591 us of that GEMM at M = 32832):
+// g_gelu_lut[s*3072 + (|bits| - (110 << 7))] for 2^-17 <= |x| < 2^7, filled once per device by the chain itself (bit-identical
+// by construction); values outside the table take the chain.  Once the mainloop has ended the table (12 KiB) is copied over the
+// dead tile buffers in LDS and gathered with ds_read_u16.
+constexpr int GELU_LUT_E0 = 110, GELU_LUT_HALF = 24 * 128, GELU_LUT_N = 2 * GELU_LUT_HALF;
+__device__ uint16_t g_gelu_lut[GELU_LUT_N];
+__global__ void gelu_lut_build_kernel() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= GELU_LUT_N) return;
+  const uint32_t bits = (uint32_t)((i % GELU_LUT_HALF) + (GELU_LUT_E0 << 7)) | (i >= GELU_LUT_HALF ? 0x8000u : 0u);
+  g_gelu_lut[i] = f2bf(gelu_esm_chain(__uint_as_float(bits << 16)));
+}
+// all threads of the workgroup; `lds` = start of the (no longer read) tile buffers
+template <int NT>
+__device__ __forceinline__ void gelu_lut_to_lds(char* lds) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < GELU_LUT_N * 2 / 16; i += NT)
+    reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(g_gelu_lut)[i];
+  __syncthreads();
+}
+// Branch-free (a divergent fall-back to the chain at each of the 128 unrolled call sites made hipcc keep the epilogue as a
+// loop and move the accumulators to scratch: 591 -> 2593 us).  Outside the table the chain has closed forms:
+//   |x| <  2^-17: erf term rounds away, 1 + t3 = 1          -> bf16(x * 0.5)
+//   |x| >= 2^7  : erf = +-1 -> t4 = 2 or 0                  -> x   or   bf16(x * 0.5) * 0  (= -0, NaN for -inf, as the chain)
+__device__ __forceinline__ float gelu_esm_lut(float v /* bf16-valued */, const uint16_t* lut) {
+  const uint32_t b = __float_as_uint(v) >> 16;
+  const uint32_t mag = b & 0x7fffu;
+  const uint32_t idx = mag - (uint32_t)(GELU_LUT_E0 << 7);
+  const bool in = idx < (uint32_t)GELU_LUT_HALF;
+  const float t = __uint_as_float((uint32_t)lut[(in ? idx : 0u) + ((b >> 15) ? GELU_LUT_HALF : 0)] << 16);
+  const float half = rbf(v * 0.5f);
+  const float big = (b >> 15) ? half * 0.0f : v;
+  const float out = mag < (uint32_t)(GELU_LUT_E0 << 7) ? half : big;
+  return in ? t : out;
+}
+
 // stage a [128 rows][BK k] bf16 tile with 1-KiB wave-instructions (LDS image lane-linear).  A row holds CPR = BK/8
 // 16-byte chunks; LDS chunk position c' of row r holds global chunk c' ^ swz(r), the same XOR is applied on the read side:
 //   BK=64 (128-B rows): swz = r & 7        BK=32 (64-B rows): swz = (r >> 2) & 3      -> conflict-free ds_read_b128
@@ -71,7 +108,8 @@ __device__ __forceinline__ void tile_origin(const PcyGemmArgs& a, int tile, int&
 // independent vector loads -- element-wise loads inside the rounding chain serialised ~64 L2 round trips per tile
 // (20 us of the 37 us a K=1280 tile took).
 template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true>
-__device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int m0, int n0, int wm, int wn, int fr, int fq) {
+__device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int m0, int n0, int wm, int wn, int fr, int fq,
+                                              const uint16_t* gelu_lut = nullptr) {
   m0 += wm * WTM * 16 - wm * 64;   // the code below adds wm * 64 / wn * 64 (the 4 x 4 layout)
   n0 += wn * WTN * 16 - wn * 64;
   const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
@@ -229,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
       }
       if (EPI == EPI_GELU_ESM) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_esm_chain(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_lut ? gelu_esm_lut(v[r], gelu_lut) : gelu_esm_chain(v[r]);
       }
       if (vec_ok) {
         *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
@@ -294,6 +332,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     __syncthreads();
   }
 
+  if constexpr (EPI == EPI_GELU_ESM) {
+    gelu_lut_to_lds<GEMM_THREADS>(smem);
+    gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    return;
+  }
   gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
@@ -494,6 +537,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
     return;
   }
+  if constexpr (EPI == EPI_GELU_ESM) {
+    gelu_lut_to_lds<512>(smem);
+    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    return;
+  }
   gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
@@ -672,7 +720,17 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     case EPI_STORE: launch<EPI_STORE>(s, a); break;
     case EPI_RESID: launch<EPI_RESID>(s, a); break;
     case EPI_GELU_ERF: launch<EPI_GELU_ERF>(s, a); break;
-    case EPI_GELU_ESM: launch<EPI_GELU_ESM>(s, a); break;
+    case EPI_GELU_ESM: {
+      static bool lut_built[64] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev >= 0 && dev < 64 && !lut_built[dev]) {   // once per device, on the caller's stream (ordered before the first use)
+        hipLaunchKernelGGL(gelu_lut_build_kernel, dim3((GELU_LUT_N + 255) / 256), dim3(256), 0, s);
+        lut_built[dev] = true;
+      }
+      launch<EPI_GELU_ESM>(s, a);
+      break;
+    }
     case EPI_SWIGLU: launch<EPI_SWIGLU>(s, a); break;
   }
 }

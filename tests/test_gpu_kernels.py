@@ -309,3 +309,23 @@ def test_decode_batch20_full_width_layer():
     assert rel_err(st.logits.cpu(), ro["logits"][:, -1]) < 1e-2
     agree = (st.logits.cpu().float().argmax(-1) == ro["logits"][:, -1].float().argmax(-1)).float().mean()
     assert agree >= 0.9
+
+
+@pytest.mark.parametrize("M", [64, 2048])
+def test_gemm_esm_gelu_epilogue_every_bf16_value(ctx, M):
+    """The ESM GELU epilogue looks the five-rounding chain up in a table (2^-17 <= |x| < 2^7) and uses closed forms outside
+    it: every one of the 65536 bf16 bit patterns through both GEMM kernels (128x128 at M = 64, 256x256 at M = 2048) must
+    give exactly what the reference's op-by-op bf16 chain x * 0.5 * (1.0 + erf(x / sqrt(2))) gives on the CPU."""
+    import math
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    vals = bits.view(BF)                                   # [65536] every bf16 value
+    W = vals.view(1024, 64).contiguous()                   # output[m][n] = W[n][m % 64] (A = identity rows, zero bias)
+    A = torch.zeros(M, 64, dtype=BF)
+    A[torch.arange(M), torch.arange(M) % 64] = 1.0
+    out = ctx.gemm(A.cuda(), W.cuda(), torch.zeros(1024, dtype=BF).cuda(), None, 3).cpu()[:64]   # [64, 1024] = W^T
+    x = W.t().contiguous()
+    # 0 * inf inside the MFMA turns the infinite / NaN patterns into NaN before the epilogue sees them, and -0 arrives as +0
+    # (the accumulator starts at +0): compare every other pattern (65278 of them) bit for bit
+    finite = torch.isfinite(x.float()) & (x.view(torch.int16) != -32768)
+    ref = x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    assert torch.equal(out[finite].view(torch.int16), ref[finite].view(torch.int16))
