@@ -1,0 +1,79 @@
+"""BASELINE.json configs[2..4] on ONE MI355X through the model-level API (synthetic ProCyon-Full weights):
+  config 3 unit rate : retrieval embedding of N 1024-residue proteins (forward_sequences, batch 32)        -> proteins/s
+  config 4           : batch 32, residue lengths uniform in [256, 2048] (seed 7; > 1024 are split into chunks),
+                       512-token prompts, 512 greedy tokens                                                 -> tokens/s
+  config 5           : 256 six-slot QA prompts (T ~ 450) scored as P(yes) / P(no), bf16 and fp8 weight path -> pairs/s
+Prints one JSON object; committed under profiles/."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from procyon_amd import synth
+from procyon_amd import synthetic_model as SM
+
+def sync(): torch.cuda.synchronize()
+res = {}
+model = SM.build("full", device="cuda", max_new_tokens=512)
+
+# ---- config 3 (per-GPU unit rate; the 8-GPU job shards N = 100k and all-gathers once) ----
+N, rb = int(os.environ.get("C3_N", 512)), 32
+def embed_all():
+    outs = []
+    for i in range(0, N, rb):
+        toks = synth.protein_tokens([1024] * rb, seed=1000 + i)
+        outs.append(model.forward_sequences(toks)["shared"])
+    return torch.cat(outs)
+embed_all(); sync(); t0 = time.perf_counter(); z = embed_all(); sync(); dt = time.perf_counter() - t0
+res["config3_retrieval_embed"] = {"proteins": N, "residues": 1024, "batch": rb, "proteins_per_s": round(N / dt, 1), "out_shape": list(z.shape)}
+
+# ---- config 4 ----
+g = torch.Generator().manual_seed(7)
+lens = torch.randint(256, 2049, (32,), generator=g).tolist()
+prot = synth.protein_tokens(lens, seed=7)
+words = lambda b: " ".join([f"w{(17 * b + 31 * i) % 50000}" for i in range(254)] + ["<|protein|>"] + [f"w{(13 * b + 7 * i) % 50000}" for i in range(254)]) + " [ANSWER]"
+def inputs4():
+    return {"data": {"seq": prot.clone(), "seq_idx": torch.arange(32), "text": [], "drug": None},
+            "input": {"seq": [[b] for b in range(32)], "text": [[] for _ in range(32)], "drug": None},
+            "target": {"seq": None, "text": None, "drug": None}, "instructions": [words(b) for b in range(32)]}
+model.generate(inputs4(), max_len=8, method="greedy"); sync()
+t0 = time.perf_counter(); toks, *_ = model.generate(inputs4(), max_len=512, method="greedy"); sync(); dt = time.perf_counter() - t0
+res["config4_batch32_mixed"] = {"rows": 32, "residues_min_max": [min(lens), max(lens)], "protein_chunks": int(sum((l + 1023) // 1024 for l in lens)),
+                                "prompt_tokens": 512, "new_tokens": 512, "seconds": round(dt, 3), "tokens_per_s": round(32 * 512 / dt, 1),
+                                "tokens_shape": list(toks.shape)}
+
+# ---- config 5 ----
+P, chunk = 256, 64
+plen = [805] + [int(x) for x in torch.randint(8, 41, (P + 2,), generator=g)]   # receptor + peptides
+prot5 = synth.protein_tokens(plen, seed=11)
+filler = lambda n, s: " ".join(f"w{(s + 3 * i) % 50000}" for i in range(n))
+tmpl = (filler(140, 1) + " <|protein|> binds <|protein|> ? [ANSWER] yes " + filler(140, 2) + " <|protein|> binds <|protein|> ? [ANSWER] no "
+        + filler(140, 3) + " <|protein|> binds <|protein|> ? [ANSWER]")
+def inputs5(lo):
+    return {"data": {"seq": prot5.clone(), "seq_idx": torch.arange(prot5.shape[0]), "text": [], "drug": None},
+            "input": {"seq": [[0, 1, 0, 2, 0, 3 + lo + i] for i in range(chunk)], "text": [[] for _ in range(chunk)], "drug": None},
+            "target": {"seq": None, "text": None, "drug": None}, "instructions": [tmpl] * chunk}
+def score_all():
+    ys, ls = [], []
+    for lo in range(0, P, chunk):
+        lg = model.forward(inputs5(lo), retrieval=False)["outputs"].logits[:, 0].float()
+        p = lg.softmax(-1)
+        ys.append(torch.stack([p[:, model.yes_token], p[:, model.no_token]], 1))
+        ls.append(lg[:, ::61].clone())          # a 1/61 sample of every answer-row logit vector
+    return torch.cat(ys), torch.cat(ls)
+out = {}
+for mode in ("bf16", "fp8"):
+    if mode == "fp8": model.text_encoder.engine.quantize_fp8()
+    score_all(); sync(); t0 = time.perf_counter(); y, lg = score_all(); sync(); dt = time.perf_counter() - t0
+    out[mode] = (y.cpu(), dt, lg.cpu())
+model.text_encoder.engine.set_fp8(False)
+y16, y8 = out["bf16"][0], out["fp8"][0]
+l16, l8 = out["bf16"][2], out["fp8"][2]
+res["config5_pair_scoring"] = {"pairs": P, "slots_per_prompt": 6, "prompt_tokens": int(len(tmpl.split())),
+                               "bf16_pairs_per_s": round(P / out["bf16"][1], 1), "fp8_pairs_per_s": round(P / out["fp8"][1], 1),
+                               # random-init weights: the answer-row distribution is nearly flat (P(yes) ~ 1/vocab), so yes-vs-no is a coin
+                               # flip inside the quantisation noise; the meaningful agreement figures are the logit-vector distance and
+                               # the ratio of the probabilities
+                               "answer_logits_rel_err_fp8_vs_bf16": float((l8 - l16).norm() / l16.norm()),
+                               "median_P_yes_ratio_fp8_over_bf16": float((y8[:, 0] / y16[:, 0]).median()),
+                               "yes_no_agreement_random_weights": float(((y16[:, 0] > y16[:, 1]) == (y8[:, 0] > y8[:, 1])).float().mean()),
+                               "mean_P_yes_bf16": float(y16[:, 0].mean())}
+print(json.dumps(res))
