@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--retrieval-proteins", type=int, default=128, help="proteins per rank in the retrieval leg")
+    ap.add_argument("--retrieval-proteins", type=int, default=125, help="proteins per rank in the retrieval leg")
     return ap.parse_args()
 
 
@@ -195,7 +195,8 @@ def main():
     from procyon_amd.distributed import embed_sharded
     nprot = a.retrieval_proteins * world
     plen = a.residues if a.geometry == "full" else 100
-    rb = 32   # proteins per engine call ("batch size chosen by the engine", BASELINE configs[2])
+    # proteins per engine call: "batch size chosen by the engine" (BASELINE configs[2]) -> EsmEngine.preferred_batch
+    rb = model.protein_seq_encoder.engine.preferred_batch(plen + 2)
     tok_fn = lambda idx: synth.protein_tokens([plen] * len(idx), seed=1000 + (idx[0] if len(idx) else 0))
     embed_sharded(model, tok_fn, rb * world, batch_size=rb)   # untimed: workspace growth, first-launch effects
     barrier(); t0 = time.perf_counter()

@@ -23,11 +23,13 @@ def shard_indices(n_total: int, rank: int, world: int):
     return idx[rank * per:(rank + 1) * per]
 
 
-def embed_sharded(model_or_fn, token_fn, n_total, batch_size=16, rank=None, world=None, group=None):
+def embed_sharded(model_or_fn, token_fn, n_total, batch_size=None, rank=None, world=None, group=None):
     """Embed proteins [0, n_total) across the process group and return the [n_total, D] matrix on every rank.
 
     model_or_fn: a `UnifiedProCyon` (uses forward_sequences(...)["shared"], evaluate/framework/procyon.py:318-319)
     or any callable tokens -> [b, D].  token_fn(list_of_indices) -> token matrix for those proteins.
+    batch_size=None lets the engine choose (`EsmEngine.preferred_batch` on the first protein's token count; 16 for a
+    plain callable).
     """
     import torch.distributed as td
     dist = td.is_available() and td.is_initialized()
@@ -38,6 +40,11 @@ def embed_sharded(model_or_fn, token_fn, n_total, batch_size=16, rank=None, worl
     fn = model_or_fn if callable(model_or_fn) and not hasattr(model_or_fn, "forward_sequences") else \
         (lambda toks: model_or_fn.forward_sequences(toks)["shared"])
     mine = shard_indices(n_total, rank, world)
+    if batch_size is None:
+        batch_size = 16
+        eng = getattr(getattr(model_or_fn, "protein_seq_encoder", None), "engine", None)
+        if eng is not None and hasattr(eng, "preferred_batch") and len(mine):
+            batch_size = eng.preferred_batch(int(token_fn(mine[:1]).shape[1]))
     outs = []
     for s in range(0, len(mine), batch_size):
         idx = mine[s:s + batch_size]

@@ -548,6 +548,26 @@ class EsmEngine:
                               1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
                               self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
 
+    def preferred_batch(self, tokens_per_protein, lo=16, hi=40, n_cu=256):
+        """Proteins per engine call for retrieval-style bulk encoding ("batch size chosen by the engine", BASELINE configs[2]).
+        The four GEMMs of a layer run in rounds of 256 (256 x 256 tiles) or 512 (128 x 128: the o projection) workgroups, so
+        throughput follows how well B x S tokens fill the last round of each; beyond ~40 proteins the activations outgrow the
+        256 MiB Infinity Cache and throughput declines.  Score = flop-weighted tile-round efficiency - 0.0015 B, fitted on
+        ESM2-650M at S = 1026: batch 25 -> 455 proteins/s, 32 -> 419, 26 -> 392, 37 -> 448, 38 -> 434, 64 -> 411."""
+        d, F, S = self.cfg.d, self.cfg.ffn, int(tokens_per_protein)
+        best, best_score = lo, -1.0
+        for B in range(lo, hi + 1):
+            M, tot, cost = B * S, 0, 0
+            for N, K, t in ((3 * d, d, 256), (d, d, 128 if d < 2560 else 256), (F, d, 256), (d, F, 256)):
+                tiles = -(-M // t) * -(-N // t)
+                slots = n_cu * (1 if t == 256 else 2)
+                cost += -(-tiles // slots) * slots * t * t * K
+                tot += M * N * K
+            score = tot / cost - 0.0015 * B
+            if score > best_score:
+                best, best_score = B, score
+        return best
+
     # ---- packing ---------------------------------------------------------------------------------
     @staticmethod
     def pack(rows, mask_pads=True):

@@ -15,7 +15,8 @@ res = {}
 model = SM.build("full", device="cuda", max_new_tokens=512)
 
 # ---- config 3 (per-GPU unit rate; the 8-GPU job shards N = 100k and all-gathers once) ----
-N, rb = int(os.environ.get("C3_N", 512)), 32
+N = int(os.environ.get("C3_N", 500))
+rb = model.protein_seq_encoder.engine.preferred_batch(1026)   # 25 for ESM2-650M at 1024 residues
 def embed_all():
     outs = []
     for i in range(0, N, rb):
