@@ -247,6 +247,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     return;
   }
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->fused_err && m->n_layers <= AO_MAX_LAYERS;
   if (try_ao) hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, s, c->ao_sync);
   for (int l = 0; l < m->n_layers; ++l) {
@@ -255,7 +256,11 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
     g.rms_cast = m->rms_cast; g.N = qkvw; g.K = d; g.B = B; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
     g.splitk_ws = sk_ws; g.splitk_ws_bytes = sk_bytes;
-    if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, B, d, m->rms_eps, m->rms_cast); g.x = xn; g.rms_w = nullptr; }
+    if (batched) {   // (the previous layer's down projection may have written xn already, fused into its K-split finish)
+      if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, B, d, m->rms_eps, m->rms_cast);
+      xn_ready = 0;
+      g.x = xn; g.rms_w = nullptr;
+    }
     pcy_launch_gemv(s, g);
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
@@ -267,6 +272,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
+    if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
     if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->fused_err))) {
       pcy_launch_attn_decode(s, t);
       pcy_launch_gemv(s, o);
@@ -274,17 +280,28 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
     u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
-    if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, B, d, m->rms_eps, m->rms_cast); u.x = xn; u.rms_w = nullptr; }
+    if (batched) {
+      if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, B, d, m->rms_eps, m->rms_cast);
+      xn_ready = 0;
+      u.x = xn; u.rms_w = nullptr;
+    }
     pcy_launch_gemv(s, u);
     PcyGemvArgs w{};
     w.W = (const bf16_t*)L.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.B = B; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
     w.splitk_ws = sk_ws; w.splitk_ws_bytes = sk_bytes;
+    if (batched && B <= 32) {
+      w.next_rms_w = (const bf16_t*)(l + 1 < m->n_layers ? m->layers[l + 1].ln1 : m->final_norm);
+      w.next_xn = xn; w.fused_next = &xn_ready; w.rms_eps = m->rms_eps; w.rms_cast = m->rms_cast;
+    }
     pcy_launch_gemv(s, w);
   }
   PcyGemvArgs h{};
   h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
   h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = B; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
-  if (batched) { pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, xn, B, d, m->rms_eps, m->rms_cast); h.x = xn; h.rms_w = nullptr; }
+  if (batched) {
+    if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, xn, B, d, m->rms_eps, m->rms_cast);
+    h.x = xn; h.rms_w = nullptr;
+  }
   pcy_launch_gemv(s, h);
 }
 

@@ -15,6 +15,10 @@ struct PcyGemvArgs {
   int plain_loads;      // debug A/B: 0 = non-temporal weight loads (default), 1 = default cache policy
   // optional fp32 workspace [ksplit][B][N] for the batched (B > 4) kernel's K-split partial sums
   float* splitk_ws; size_t splitk_ws_bytes;
+  // optional (batched K-split path with the residual epilogue only): the finish kernel also writes
+  // next_xn = RMSNorm(y) * next_rms_w (rms_eps / rms_cast above) and sets *fused_next = 1; otherwise *fused_next stays 0 and
+  // the caller launches the norm itself.  Same summation order as rmsnorm_kernel -> identical bits.
+  const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
