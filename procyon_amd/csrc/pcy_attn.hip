@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_kernel(PcyAttnArgs a) {
 // The per-wave global fragment loads of attn_kernel made the kernel L2-bandwidth bound (5.6 GB of fragment traffic per
 // ESM layer at batch 32); this cuts it 4x.  Arithmetic and rounding are identical to attn_kernel.
 template <int DH, int QT>
-__global__ __launch_bounds__(256) void attn_lds_kernel(PcyAttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_lds_kernel(PcyAttnArgs a) {
   constexpr int KB = DH / 32, NT = DH / 16, QROWS = QT * 16;
   constexpr int KCH = DH / 8;                  // 16-B chunks per key row
   constexpr int KLD = (32 * KCH) / 256;        // K chunks per thread (1 for DH=64, 2 for DH=128)
@@ -684,7 +684,11 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   // block once per workgroup: Llama-3-8B pair-scoring prefill 870 -> 932 TFLOP/s (bf16), 1350 -> 1490 (fp8 weights).
   // PCY_ATTN_VAR=2 selects the register-fragment kernel again; PCY_ATTN_LDS_QT = q tiles per wave (1 or 2).
   if (var != 2 && a.dh == 128) {
-    static const int qt = [] { const char* e = getenv("PCY_ATTN_LDS_QT"); return e ? atoi(e) : 1; }();
+    // two q tiles per wave halve the K / Vt fragment reads per MFMA (the LDS pipe is the limiter at one); capped at 256
+    // VGPRs (amdgpu_waves_per_eu(2): 211 used, no spills -- uncapped the compiler took 260 and one wave per SIMD, slower):
+    // 938 -> 975 TFLOP/s (bf16), 1555 -> 1664 (fp8 weights) on the pair-scoring prefill
+    static const int qt_env = [] { const char* e = getenv("PCY_ATTN_LDS_QT"); return e ? atoi(e) : 0; }();
+    const int qt = qt_env ? qt_env : (a.max_len > 64 ? 2 : 1);
     if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<128, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
     return;
