@@ -688,7 +688,10 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
     // VGPRs (amdgpu_waves_per_eu(2): 211 used, no spills -- uncapped the compiler took 260 and one wave per SIMD, slower):
     // 938 -> 975 TFLOP/s (bf16), 1555 -> 1664 (fp8 weights) on the pair-scoring prefill
     static const int qt_env = [] { const char* e = getenv("PCY_ATTN_LDS_QT"); return e ? atoi(e) : 0; }();
-    const int qt = qt_env ? qt_env : (a.max_len > 64 ? 2 : 1);
+    // ... but a small grid (one 512-token prompt: 4 x 32 workgroups of two tiles) is a latency chain per workgroup: keep one
+    // tile per wave until two-tile workgroups alone fill the chip twice
+    const long wg2 = (long)((a.max_len + 127) / 128) * a.H * a.nseq;
+    const int qt = qt_env ? qt_env : (wg2 >= 512 ? 2 : 1);
     if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<128, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
     return;

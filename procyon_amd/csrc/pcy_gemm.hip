@@ -644,7 +644,17 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
   static const int big_min_m = [] { const char* e = getenv("PCY_GEMM_BIG_M"); return e ? atoi(e) : 2048; }();
   // 256x256 tiles pay off where the mainloop dominates (measured, M = 32832: qkv 734 -> 804, fc2 827 -> 911 TFLOP/s);
   // for N = K = 1280 they do not; the ESM GELU epilogue is a wash since the rational erf (fc1 679 vs 700)
-  const bool big_ok = a.M >= big_min_m && EPI != EPI_GELU_ERF &&
+  // Below big_min_m rows the choice follows how well each tiling fills the chip: 128x128 tiles run two per CU (512 slots),
+  // 256x256 one per CU with a ~14 % better mainloop.  Llama-3-8B gate/up at one 512-token prompt: 896 small tiles = 1.75
+  // rounds vs 224 big tiles = one round -> 148 -> 113 us (prefill 12.7 -> 11.6 ms); at M = 256 or 768 the small tiles fit better.
+  bool size_ok = a.M >= big_min_m;
+  if (!size_ok && a.M >= 256) {
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128), t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512) * a.M / (double)(((a.M + 127) / 128) * 128);
+    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256) * a.M / (double)(((a.M + 255) / 256) * 256);
+    size_ok = e256 * 1.14 > e128;
+  }
+  const bool big_ok = size_ok && EPI != EPI_GELU_ERF &&
                       (a.N >= 2560 || (a.N >= 256 && a.K >= 2560));
   if (big_ok) {
     constexpr int smem = 2 * (256 + 256) * 64 * 2;
