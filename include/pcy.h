@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 2
+#define PCY_ABI_VERSION 3
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -177,9 +177,11 @@ typedef struct {
   int32_t* tokens_out;       /* [B, max_steps] */
   float* logprob;            /* [B] running sum of log_softmax(logits)[token] */
   void* logits;              /* [B, vocab] logits of the latest step */
-  void* logits_all;          /* optional [max_steps, B, vocab] */
+  void* logits_all;          /* optional record [max_steps, B, logits_all_ld] of every step's logits; may be PINNED HOST memory
+                              * (hipHostMalloc): the rows then cross PCIe during the following decode steps */
   const uint8_t* keep;       /* optional [B, Tmax] decode key mask ("clean" mode); NULL = reference quirk Q1 */
   int32_t max_steps;
+  int32_t logits_all_ld;     /* row stride of logits_all in elements; 0 = vocab.  A multiple of 8 enables 16-byte stores */
 } pcy_gen_state;
 /* one decode step: next_tok -> logits (and K/V appended at slot *pos); does not pick or advance */
 int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);

@@ -51,7 +51,7 @@ class KvCache(C.Structure):
 
 class GenState(C.Structure):
     _fields_ = [("pos", vp), ("step", vp), ("next_tok", vp), ("tokens_out", vp), ("logprob", vp), ("logits", vp),
-                ("logits_all", vp), ("keep", vp), ("max_steps", i32)]
+                ("logits_all", vp), ("keep", vp), ("max_steps", i32), ("logits_all_ld", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/pcy.h declares
@@ -107,7 +107,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pcy_abi_version() != 2:
+    if lib.pcy_abi_version() != 3:
         raise PcyError("libpcy.so ABI version mismatch")
     _lib = lib
     return lib

@@ -41,6 +41,7 @@ struct pcy_ctx {
   // captured decode step
   hipGraphExec_t graph = nullptr;
   const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const void* graph_key2[2] = {nullptr, nullptr};
   int graph_B = 0;
   int graph_fused = 0;
   // persistent decode kernel: device copy of the per-layer weight pointers + progress flags
@@ -305,15 +306,34 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   pcy_launch_gemv(s, h);
 }
 
-__global__ void store_logits_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ all, const int32_t* step_dev, size_t n) {
-  const size_t base = (size_t)(*step_dev) * n;
-  for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) all[base + i] = logits[i];
+// Record of the per-step logits (the reference returns it on the CPU, model_unified.py:892,917-921).  `all` may be PINNED
+// HOST memory: the rows then cross PCIe while the next decode step runs, instead of as one 65 MB (batch 1, 256 tokens) to
+// 4.2 GB (batch 32, 512 tokens) device-to-host copy after the loop -- batch-32 generation 8.3 -> see DESIGN.md ms per token end to end.
+// Row (step, b) starts at all + (step*B + b)*ld; with ld % 8 == 0 every row is 16-byte aligned and is written with 16-byte
+// stores (the source rows have the odd stride V, so they are gathered with 2-byte loads from L2).
+__global__ void store_logits_kernel(const bf16_t* __restrict__ logits, bf16_t* __restrict__ all, const int32_t* step_dev,
+                                    int B, int V, int ld) {
+  const size_t step = (size_t)(*step_dev);
+  const int chunks = (V + 7) / 8;
+  const bool vec = (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(all) & 15) == 0);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)B * chunks; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / chunks), c = (int)(i % chunks);
+    const bf16_t* src = logits + (size_t)b * V + c * 8;
+    bf16_t* dst = all + (step * B + b) * ld + c * 8;
+    if (vec && c * 8 + 8 <= V) {
+      const uint32_t w0 = src[0] | ((uint32_t)src[1] << 16), w1 = src[2] | ((uint32_t)src[3] << 16);
+      const uint32_t w2 = src[4] | ((uint32_t)src[5] << 16), w3 = src[6] | ((uint32_t)src[7] << 16);
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w0, w1, w2, w3);
+    } else {
+      for (int e = 0; e < 8 && c * 8 + e < V; ++e) dst[e] = src[e];
+    }
+  }
 }
 void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos, int Tmax) {
   hipStream_t s = c->stream;
   if (st->logits_all)
-    hipLaunchKernelGGL(store_logits_kernel, dim3(64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)st->logits_all,
-                       st->step, (size_t)B * m->vocab);
+    hipLaunchKernelGGL(store_logits_kernel, dim3(B >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits,
+                       (bf16_t*)st->logits_all, st->step, B, m->vocab, st->logits_all_ld > 0 ? st->logits_all_ld : m->vocab);
   // partials live at the tail of the decode workspace carve (same offsets as enqueue_decode)
   Carver cv(c->ws);
   const int qkvw = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
@@ -719,7 +739,9 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     return check_launch("pcy_llama_greedy");
   }
   const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
-  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != B || c->graph_fused != decode_mode()) {
+  const void* key2[2] = {st->logits_all, (const void*)(intptr_t)st->logits_all_ld};
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || memcmp(key2, c->graph_key2, sizeof(key2)) != 0 ||
+      c->graph_B != B || c->graph_fused != decode_mode()) {
     c->drop_graph();
     hipGraph_t g = nullptr;
     hipStream_t user = c->stream;
@@ -735,6 +757,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
     hipGraphDestroy(g);
     memcpy(c->graph_key, key, sizeof(key));
+    memcpy(c->graph_key2, key2, sizeof(key2));
     c->graph_B = B;
     c->graph_fused = decode_mode();
   }

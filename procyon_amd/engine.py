@@ -324,12 +324,22 @@ class GenState:
         self.tokens_out = torch.zeros(B, max_steps, dtype=torch.int32, device=device)
         self.logprob = torch.zeros(B, dtype=torch.float32, device=device)
         self.logits = torch.empty(B, vocab, dtype=BF16, device=device)
-        self.logits_all = torch.empty(max_steps, B, vocab, dtype=BF16, device=device) if keep_logits else None
+        # the per-step logits record is what the reference returns on the CPU: pinned host memory written by the decode steps
+        # themselves (rows padded to a multiple of 8 elements for 16-byte stores); PCY_LOGITS_HOST=0 keeps it on the device
+        self.logits_all = self._logits_host = None
+        ld = vocab
+        if keep_logits:
+            if os.environ.get("PCY_LOGITS_HOST", "1") != "0":
+                ld = (vocab + 7) // 8 * 8
+                self._logits_host = torch.empty(max_steps, B, ld, dtype=BF16, pin_memory=True)
+                self.logits_all = self._logits_host[:, :, :vocab]
+            else:
+                self.logits_all = torch.empty(max_steps, B, vocab, dtype=BF16, device=device)
         self.keep = keep
         self.c = L.GenState(self.pos.data_ptr(), self.step.data_ptr(), self.next_tok.data_ptr(), self.tokens_out.data_ptr(),
                             self.logprob.data_ptr(), self.logits.data_ptr(),
                             0 if self.logits_all is None else self.logits_all.data_ptr(),
-                            0 if keep is None else keep.data_ptr(), max_steps)
+                            0 if keep is None else keep.data_ptr(), max_steps, ld)
 
 
 class LlamaEngine:
@@ -464,6 +474,8 @@ class LlamaEngine:
         self.pick(cache, st, B, advance_pos=False)
         if max_len > 1:
             self.greedy_steps(cache, st, B, max_len - 1, use_graph)
+        if st._logits_host is not None:
+            torch.cuda.current_stream(self.device).synchronize()      # the record lives in host memory: complete before it is handed out
         la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
         return st.tokens_out.long(), st.logprob, la, (st, cache)
 

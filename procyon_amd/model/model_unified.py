@@ -396,7 +396,10 @@ class UnifiedProCyon:
             out_list.append(out.cpu())
             lp_list.append(total.cpu())
             logit_list.append(torch.stack(logits_all, 1).cpu())
-        return torch.stack(out_list, dim=1), torch.stack(lp_list).T, torch.stack(logit_list, dim=1)
+        # one text per instance (every caller in the reference): a view instead of a host-to-host copy of the [B, max_len, V] record
+        # (4.2 GB at batch 32 x 512 tokens)
+        logits_out = logit_list[0].unsqueeze(1) if len(logit_list) == 1 else torch.stack(logit_list, dim=1)
+        return torch.stack(out_list, dim=1), torch.stack(lp_list).T, logits_out
 
     @torch.no_grad()
     def _generate_beam_search(self, input_embeds, attn_mask, max_len=64, beam_size=5, beam_group_size=5,
