@@ -242,16 +242,16 @@ def test_decode_persistent_kernel_matches_layered(monkeypatch):
     assert rel_err(a[2], ref[2]) < 5e-3 and rel_err(a[3], ref[3]) < 5e-3
 
 
-def test_decode_attn_o_fused_launch_bit_identical(monkeypatch):
+@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (1100, 6, 2)])
+def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
     """PCY_ATTN_O (default on): decode attention and o projection in one launch -- Wo rows wait in registers while the
     attention workgroups run, hand-over by per-workgroup flags.  Same per-lane accumulation order, reduction tree and
     rounding points as the two-launch path, so logits, tokens and the appended K/V must be BIT-identical to PCY_ATTN_O=0,
     eager and under hipGraph replay, over enough steps that a stale flag or a missed hand-over would show; no watchdog."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
-    kw = dict(vocab=4096, d=4096, n_layers=3, n_heads=32, n_kv_heads=8, ffn=14336)
-    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=512))
-    T, N = 300, 24
+    kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))   # T = 1100: more than one 1024-key group
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
