@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 3
+#define PCY_ABI_VERSION 4
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -185,12 +185,34 @@ typedef struct {
 } pcy_gen_state;
 /* one decode step: next_tok -> logits (and K/V appended at slot *pos); does not pick or advance */
 int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
+/* the same step as ONE replayed hipGraph (captured on first use per model / cache / state / batch): for host-driven loops that
+ * do their own selection between steps (sampling, diverse beam search).  next_tok and *pos are read from device memory. */
+int pcy_llama_decode_graph(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
 /* argmax of state->logits (lowest index on ties) -> next_tok / tokens_out[step], logprob, ++pos? no: ++step only
  * when advance_pos == 0 (used on the prefill logits), ++pos and ++step otherwise */
 int pcy_greedy_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int advance_pos);
 /* n_steps x (decode + pick) with no host synchronisation; use_graph != 0 replays a captured hipGraph */
 int pcy_llama_greedy(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int n_steps,
                      int use_graph);
+/* Diverse beam search bookkeeping of ONE step on the device (`_generate_beam_search`, model_unified.py:782-833): per prompt
+ * and beam group, top-`group_size` of  log_softmax(logits) (model dtype) + running score - diversity_penalty * (count of the
+ * token among the picks of the earlier groups at this step);  at step 0 only the first beam of a group is expanded.  Updates
+ * the token histories, the running scores, `src` (parent slot of every slot: feed it to pcy_kv_reorder), `next_tok`, ++*step,
+ * ++*pos (from step 1 on) and raises *done once every row holds `eos_id`; a launch with *done set changes nothing.
+ * logits [B*beam, vocab] bf16.  All pointers are device memory; state layout in the struct below (BB = B * beam). */
+typedef struct {
+  int32_t* out; int32_t max_len;   /* [2][BB][max_len] token histories; buffer (*step & 1) is current; zero-initialised */
+  float* cur; float* cur_new;      /* [BB] running scores (zero-initialised) + scratch */
+  int32_t* next_tok;               /* [BB] */
+  int32_t* src;                    /* [BB] */
+  int32_t* anc;                    /* optional [max_len][BB]: src of every step (to permute a per-slot logits record afterwards) */
+  uint8_t* has_eos;                /* [2][BB] zero-initialised */
+  int32_t* blk_eos; int32_t* ticket;   /* [B], [1] zero-initialised */
+  int32_t* pos; int32_t* step; int32_t* done;   /* device scalars */
+  int32_t eos_id;
+} pcy_beam_state;
+int pcy_beam_step(pcy_ctx*, const void* logits, int vocab, int B, int beam, int group_size, float diversity_penalty,
+                  const pcy_beam_state* state);
 /* KV rows gather for beam search: cache[:, dst] = cache[:, src[dst]] over slots [0,t) (model_unified.py:830-832) */
 int pcy_kv_reorder(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const int32_t* src_rows, int B, int t);
 

@@ -54,6 +54,11 @@ class GenState(C.Structure):
                 ("logits_all", vp), ("keep", vp), ("max_steps", i32), ("logits_all_ld", i32)]
 
 
+class BeamState(C.Structure):
+    _fields_ = [("out", vp), ("max_len", i32), ("cur", vp), ("cur_new", vp), ("next_tok", vp), ("src", vp), ("anc", vp),
+                ("has_eos", vp), ("blk_eos", vp), ("ticket", vp), ("pos", vp), ("step", vp), ("done", vp), ("eos_id", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/pcy.h declares
 SIGNATURES = {
     "pcy_abi_version": (ci, []),
@@ -79,8 +84,10 @@ SIGNATURES = {
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp]),
     "pcy_llama_decode": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci]),
+    "pcy_llama_decode_graph": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci]),
     "pcy_greedy_pick": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci]),
     "pcy_llama_greedy": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, ci]),
+    "pcy_beam_step": (ci, [vp, vp, ci, ci, ci, ci, C.c_float, C.POINTER(BeamState)]),
     "pcy_kv_reorder": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, ci, ci]),
 }
 
@@ -107,7 +114,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pcy_abi_version() != 3:
+    if lib.pcy_abi_version() != 4:
         raise PcyError("libpcy.so ABI version mismatch")
     _lib = lib
     return lib

@@ -524,6 +524,143 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One step of the reference's diverse beam search bookkeeping (`_generate_beam_search`, model_unified.py:782-833) as ONE
+// launch: grid = B prompts, one 1024-thread workgroup each, the beam groups of a prompt processed in order (group k's
+// Hamming penalty depends on what groups < k chose at this step).  Per prompt:
+//   row statistics   max and log-sum-exp of each of its `beam` logit rows (one wave per row)
+//   candidates       s(r, v) = float(bf16((x[r][v] - max_r) - lse_r)) + cur[r] - penalty * #{earlier picks of this step == v}
+//                    = the reference's  log_softmax(logits) (model dtype) + cur (fp32)  with the in-place bincount penalty
+//   selection        top-g over the group's inc x V candidates (inc = 1 at step 0) by g rounds of a block-wide arg-max; ties
+//                    go to the lowest flat index (torch.topk leaves the order of equal values unspecified)
+//   commit           token histories (double-buffered rows: new row = parent's row + the token), running scores, parent
+//                    slots (`src`, for the KV reorder and the logits record), next-step tokens, "row holds an EOS" flags
+// The last workgroup to finish advances *step / *pos and raises *done when every row holds an EOS (model_unified.py:833);
+// once *done is set a launch changes nothing, so the host may queue steps ahead and look at the flag only now and then.
+struct BeamPick { float s; int c; };
+__device__ __forceinline__ bool beam_better(float s, int c, float bs, int bc) { return s > bs || (s == bs && c < bc); }
+
+__global__ __launch_bounds__(1024) void beam_step_kernel(const bf16_t* __restrict__ logits, int V, int beam, int g, float penalty,
+                                                         PcyBeamState st, int B) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(bsm);                    // [(V + 31) / 32] tokens picked earlier in this step
+  const int nwords = (V + 31) / 32;
+  __shared__ float rmax[32], rlse[32], red_s[16];
+  __shared__ int red_c[16], sel_tok[32], nsel_s;
+  __shared__ BeamPick pick_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, base = b * beam, BB = B * beam;
+  if (*st.done) {
+    if (tid < beam) st.src[base + tid] = base + tid;
+    return;
+  }
+  const int i = *st.step;
+  const int32_t* out_old = st.out + (size_t)(i & 1) * BB * st.max_len;
+  int32_t* out_new = st.out + (size_t)((i + 1) & 1) * BB * st.max_len;
+  const uint8_t* eos_old = st.has_eos + (size_t)(i & 1) * BB;
+  uint8_t* eos_new = st.has_eos + (size_t)((i + 1) & 1) * BB;
+  // ---- row statistics: wave w takes rows w, w + 16, ...
+  for (int r = wave; r < beam; r += 16) {
+    const bf16_t* x = logits + (size_t)(base + r) * V;
+    float m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, bf2f(x[v]));
+    m = wave_max(m);
+    float se = 0.f;
+    for (int v = lane; v < V; v += 64) se += expf(bf2f(x[v]) - m);
+    se = wave_sum(se);
+    if (lane == 0) { rmax[r] = m; rlse[r] = logf(se); }
+  }
+  for (int w = tid; w < nwords; w += 1024) bitmap[w] = 0;
+  if (tid == 0) nsel_s = 0;
+  __syncthreads();
+  const int groups = beam / g;
+  for (int k = 0; k < groups; ++k) {
+    const int gs = k * g, inc = (i == 0) ? 1 : g;
+    float prev_s = INFINITY;
+    int prev_c = -1;
+    const int nsel = nsel_s;
+    for (int j = 0; j < g; ++j) {
+      float bs = -INFINITY;
+      int bc = 0x7fffffff;
+      for (int r = 0; r < inc; ++r) {
+        const bf16_t* x = logits + (size_t)(base + gs + r) * V;
+        const float m = rmax[gs + r], l = rlse[gs + r], cr = st.cur[base + gs + r];
+        for (int v = tid; v < V; v += 1024) {
+          float sc = rbf((bf2f(x[v]) - m) - l) + cr;
+          if (bitmap[v >> 5] & (1u << (v & 31))) {
+            int cnt = 0;
+            for (int q = 0; q < nsel; ++q) cnt += sel_tok[q] == v;
+            sc -= penalty * (float)cnt;
+          }
+          const int c = r * V + v;
+          const bool eligible = sc < prev_s || (sc == prev_s && c > prev_c);
+          if (eligible && beam_better(sc, c, bs, bc)) { bs = sc; bc = c; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float os = __shfl_xor(bs, o, 64);
+        const int oc = __shfl_xor(bc, o, 64);
+        if (beam_better(os, oc, bs, bc)) { bs = os; bc = oc; }
+      }
+      if (lane == 0) { red_s[wave] = bs; red_c[wave] = bc; }
+      __syncthreads();
+      if (tid == 0) {
+        float fs = red_s[0];
+        int fc = red_c[0];
+        for (int w = 1; w < 16; ++w)
+          if (beam_better(red_s[w], red_c[w], fs, fc)) { fs = red_s[w]; fc = red_c[w]; }
+        pick_s = BeamPick{fs, fc};
+      }
+      __syncthreads();
+      const BeamPick pk = pick_s;
+      prev_s = pk.s; prev_c = pk.c;
+      // commit slot gs + j: parent row gs + pk.c / V (an OLD row: the old buffers are never written in this launch)
+      const int parent = base + gs + pk.c / V, tok = pk.c % V, slot = base + gs + j;
+      for (int q = tid; q < i; q += 1024) out_new[(size_t)slot * st.max_len + q] = out_old[(size_t)parent * st.max_len + q];
+      if (tid == 0) {
+        out_new[(size_t)slot * st.max_len + i] = tok;
+        st.src[slot] = parent;
+        st.next_tok[slot] = tok;
+        st.cur_new[slot] = pk.s;
+        eos_new[slot] = (uint8_t)((i > 0 ? eos_old[parent] : 0) | (tok == st.eos_id));
+        if (st.anc) st.anc[(size_t)i * BB + slot] = parent;
+      }
+      __syncthreads();   // pick_s may be overwritten in the next round
+    }
+    // this group's picks join the penalty set of the later groups
+    if (tid < g) {
+      const int tok = out_new[(size_t)(base + gs + tid) * st.max_len + i];
+      atomicOr(&bitmap[tok >> 5], 1u << (tok & 31));
+      sel_tok[nsel + tid] = tok;
+    }
+    __syncthreads();
+    if (tid == 0) nsel_s = nsel + g;
+    __syncthreads();
+  }
+  // running scores: cur <- cur_new for this prompt's rows (a group reads only its OWN rows of cur, before it writes them)
+  if (tid < beam) st.cur[base + tid] = st.cur_new[base + tid];
+  __syncthreads();
+  if (tid == 0) {
+    // the reference tests (out == eos).any(dim=1) on rows that are ZERO-initialised up to max_len (model_unified.py:833):
+    // with eos_id == 0 the padding itself satisfies it while the row is not full
+    int all_eos = 1;
+    for (int r = 0; r < beam; ++r) all_eos &= (eos_new[base + r] | (st.eos_id == 0 && i + 1 < st.max_len));
+    st.blk_eos[b] = all_eos;
+    __threadfence();
+    const int ticket = atomicAdd(st.ticket, 1);
+    if (ticket == B - 1) {       // last workgroup of the step
+      __threadfence();
+      int d = 1;
+      for (int q = 0; q < B; ++q) d &= reinterpret_cast<volatile int32_t*>(st.blk_eos)[q];
+      *st.ticket = 0;
+      *st.step = i + 1;
+      if (i > 0) *st.pos += 1;   // the step-0 logits come from the prefill: the cache length is still the prompt length
+      if (d) *st.done = 1;
+    }
+  }
+}
+
 }  // namespace
 
 void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale) {
@@ -597,4 +734,8 @@ void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* ds
 }
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps) {
   if (rows > 0) hipLaunchKernelGGL(l2norm_rows_kernel, dim3(rows), dim3(NT), 0, s, x, y, d, eps);
+}
+void pcy_launch_beam_step(hipStream_t s, const bf16_t* logits, int V, int B, int beam, int g, float penalty, const PcyBeamState& st) {
+  const size_t smem = (size_t)((V + 31) / 32) * 4;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(1024), smem, s, logits, V, beam, g, penalty, st, B);
 }

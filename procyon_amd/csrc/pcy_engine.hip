@@ -41,9 +41,10 @@ struct pcy_ctx {
   // captured decode step
   hipGraphExec_t graph = nullptr;
   const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  const void* graph_key2[2] = {nullptr, nullptr};
+  const void* graph_key2[4] = {nullptr, nullptr, nullptr, nullptr};
   int graph_B = 0;
   int graph_fused = 0;
+  int graph_kind = 0;                 // 0: decode + greedy pick (pcy_llama_greedy), 1: decode only (pcy_llama_decode_graph)
   // persistent decode kernel: device copy of the per-layer weight pointers + progress flags
   PcyFusedLayer* fused_tab = nullptr;
   unsigned* fused_xch = nullptr;      // exchange storage: flags + tagged vectors + act (zeroed before every launch)
@@ -344,18 +345,25 @@ void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, 
                          st->logprob, st->pos, st->step, advance_pos, partials);
 }
 
-__global__ void kv_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int32_t* __restrict__ rows,
-                                 int Hkv, int Tmax, int t, int dh, int to_tmp) {
-  // grid (B, Hkv); to_tmp: dst(tmp,[B,Hkv,t,dh]) = src(cache)[rows[b]] ; else dst(cache)[b] = src(tmp)[b]
-  const int b = blockIdx.x, h = blockIdx.y;
+// Beam-search cache reorder, cache[:, b] = cache[:, rows[b]] over slots [0, t), for EVERY layer and for K and V in two
+// launches (gather into a scratch copy, copy back): grid (B, Hkv, 2L).  Rows that keep their place (rows[b] == b: most rows
+// once the beams of a group have settled) are skipped in both passes.  The per-layer version took 4 launches per layer
+// (128 launches, ~1 ms of a 8.8 ms beam step at beam 10).
+__global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, bf16_t* __restrict__ tmp,
+                                 const int32_t* __restrict__ rows, int B, int Bcache, int Hkv, int Tmax, int t, int dh, int to_tmp) {
+  const int b = blockIdx.x, h = blockIdx.y, lw = blockIdx.z, l = lw >> 1;
+  const int src_b = rows[b];
+  if (src_b == b) return;
+  bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh;
+  bf16_t* scratch = tmp + (size_t)lw * B * Hkv * t * dh;
   const size_t n8 = (size_t)t * dh / 8;
   const uint4* sp; uint4* dp;
   if (to_tmp) {
-    sp = reinterpret_cast<const uint4*>(src + ((size_t)rows[b] * Hkv + h) * Tmax * dh);
-    dp = reinterpret_cast<uint4*>(dst + ((size_t)b * Hkv + h) * t * dh);
+    sp = reinterpret_cast<const uint4*>(cache + ((size_t)src_b * Hkv + h) * Tmax * dh);
+    dp = reinterpret_cast<uint4*>(scratch + ((size_t)b * Hkv + h) * t * dh);
   } else {
-    sp = reinterpret_cast<const uint4*>(src + ((size_t)b * Hkv + h) * t * dh);
-    dp = reinterpret_cast<uint4*>(dst + ((size_t)b * Hkv + h) * Tmax * dh);
+    sp = reinterpret_cast<const uint4*>(scratch + ((size_t)b * Hkv + h) * t * dh);
+    dp = reinterpret_cast<uint4*>(cache + ((size_t)b * Hkv + h) * Tmax * dh);
   }
   for (size_t i = threadIdx.x; i < n8; i += blockDim.x) dp[i] = sp[i];
 }
@@ -726,6 +734,41 @@ int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   return check_launch("pcy_greedy_pick");
 }
 
+namespace {
+// capture (once per model / cache / state / batch) and replay the decode step; kind 0 = decode + greedy pick, 1 = decode only
+int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps, int kind) {
+  const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
+  // everything a captured kernel argument was derived from: pointers AND the cache geometry (an allocator may hand a cache of a
+  // different capacity the address of the previous one)
+  const void* key2[4] = {st->logits_all, (const void*)(intptr_t)st->logits_all_ld, (const void*)(intptr_t)kv->Tmax,
+                         (const void*)(intptr_t)((kv->B << 8) ^ st->max_steps)};
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || memcmp(key2, c->graph_key2, sizeof(key2)) != 0 ||
+      c->graph_B != B || c->graph_fused != decode_mode() || c->graph_kind != kind) {
+    c->drop_graph();
+    hipGraph_t g = nullptr;
+    hipStream_t user = c->stream;
+    c->stream = c->cap_stream;
+    hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e0 == hipSuccess) {
+      enqueue_decode(c, m, kv, st, B);
+      if (kind == 0) enqueue_pick(c, m, st, B, 1, kv->Tmax);
+      e0 = hipStreamEndCapture(c->cap_stream, &g);
+    }
+    c->stream = user;
+    if (e0 != hipSuccess) return fail(2, "decode-step graph capture failed: %s", hipGetErrorString(e0));
+    HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    memcpy(c->graph_key, key, sizeof(key));
+    memcpy(c->graph_key2, key2, sizeof(key2));
+    c->graph_B = B;
+    c->graph_fused = decode_mode();
+    c->graph_kind = kind;
+  }
+  for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
+  return 0;
+}
+}  // namespace
+
 int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
                      int use_graph) {
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
@@ -738,46 +781,41 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
     }
     return check_launch("pcy_llama_greedy");
   }
-  const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
-  const void* key2[2] = {st->logits_all, (const void*)(intptr_t)st->logits_all_ld};
-  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || memcmp(key2, c->graph_key2, sizeof(key2)) != 0 ||
-      c->graph_B != B || c->graph_fused != decode_mode()) {
-    c->drop_graph();
-    hipGraph_t g = nullptr;
-    hipStream_t user = c->stream;
-    c->stream = c->cap_stream;
-    hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
-    if (e0 == hipSuccess) {
-      enqueue_decode(c, m, kv, st, B);
-      enqueue_pick(c, m, st, B, 1, kv->Tmax);
-      e0 = hipStreamEndCapture(c->cap_stream, &g);
-    }
-    c->stream = user;
-    if (e0 != hipSuccess) return fail(2, "decode-step graph capture failed: %s", hipGetErrorString(e0));
-    HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
-    hipGraphDestroy(g);
-    memcpy(c->graph_key, key, sizeof(key));
-    memcpy(c->graph_key2, key2, sizeof(key2));
-    c->graph_B = B;
-    c->graph_fused = decode_mode();
-  }
-  for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
-  return 0;
+  return replay_decode_graph(c, m, kv, st, B, n_steps, 0);
+}
+
+int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+  if (B > kv->B) return fail(1, "pcy_llama_decode_graph: B=%d exceeds cache rows %d", B, kv->B);
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_fused(c, m)) return r;
+  return replay_decode_graph(c, m, kv, st, B, 1, 1);
+}
+
+int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, int group_size, float diversity_penalty,
+                  const pcy_beam_state* st) {
+  if (B <= 0 || beam <= 0 || beam > 32 || group_size <= 0 || beam % group_size)
+    return fail(1, "pcy_beam_step: beam=%d (1..32) must be a multiple of group_size=%d", beam, group_size);
+  if (vocab <= 0 || (size_t)((vocab + 31) / 32) * 4 > 60000) return fail(1, "pcy_beam_step: vocab %d unsupported", vocab);
+  PcyBeamState b{};
+  b.out = st->out; b.max_len = st->max_len; b.cur = st->cur; b.cur_new = st->cur_new; b.next_tok = st->next_tok; b.src = st->src;
+  b.anc = st->anc; b.has_eos = st->has_eos; b.blk_eos = st->blk_eos; b.ticket = st->ticket; b.pos = st->pos; b.step = st->step;
+  b.done = st->done; b.eos_id = st->eos_id;
+  pcy_launch_beam_step(c->stream, (const bf16_t*)logits, vocab, B, beam, group_size, diversity_penalty, b);
+  return check_launch("pcy_beam_step");
 }
 
 int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t) {
-  const int Hkv = m->n_kv_heads, dh = m->head_dim;
+  const int Hkv = m->n_kv_heads, dh = m->head_dim, L = m->n_layers;
   if (t <= 0) return 0;
-  const size_t tmp_elems = (size_t)B * Hkv * t * dh;
+  if ((t * dh) % 8) return fail(1, "pcy_kv_reorder: t * head_dim must be a multiple of 8");
+  const size_t tmp_elems = (size_t)2 * L * B * Hkv * t * dh;
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
   bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
-  const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
-  for (int l = 0; l < m->n_layers; ++l)
-    for (int which = 0; which < 2; ++which) {
-      bf16_t* cache = (bf16_t*)(which ? kv->v : kv->k) + l * layer_stride;
-      hipLaunchKernelGGL(kv_gather_kernel, dim3(B, Hkv), dim3(256), 0, c->stream, cache, tmp, src_rows, Hkv, kv->Tmax, t, dh, 1);
-      hipLaunchKernelGGL(kv_gather_kernel, dim3(B, Hkv), dim3(256), 0, c->stream, tmp, cache, src_rows, Hkv, kv->Tmax, t, dh, 0);
-    }
+  const dim3 grid(B, Hkv, 2 * L);
+  hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
+                     kv->Tmax, t, dh, 1);
+  hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
+                     kv->Tmax, t, dh, 0);
   return check_launch("pcy_kv_reorder");
 }
 

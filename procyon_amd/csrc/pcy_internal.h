@@ -105,6 +105,19 @@ void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, 
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
                             int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos,
                             void* partials /* B*64*16 bytes of scratch */);
+// device-side state of the diverse beam search (pcy_beam_step); every pointer is device memory, BB = B * beam rows
+struct PcyBeamState {
+  int32_t* out; int32_t max_len;   // [2][BB][max_len] token histories, buffer (step & 1) is current
+  float* cur; float* cur_new;      // [BB] running scores (+ scratch)
+  int32_t* next_tok;               // [BB] tokens fed to the next decode step
+  int32_t* src;                    // [BB] parent slot of every slot after this step (KV reorder, logits record)
+  int32_t* anc;                    // optional [max_len][BB] record of `src` per step
+  uint8_t* has_eos;                // [2][BB]
+  int32_t* blk_eos; int32_t* ticket;   // [B], [1]
+  int32_t* pos; int32_t* step; int32_t* done;   // device scalars: cache length, step index, all-rows-hold-an-EOS flag
+  int32_t eos_id;
+};
+void pcy_launch_beam_step(hipStream_t s, const bf16_t* logits, int V, int B, int beam, int g, float penalty, const PcyBeamState& st);
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps);

@@ -342,6 +342,31 @@ class GenState:
                             0 if keep is None else keep.data_ptr(), max_steps, ld)
 
 
+class BeamState:
+    """Device-side state of the diverse beam search (pcy_beam_step): token histories (double-buffered), running scores,
+    parent slots per step, EOS flags, step / position / done scalars."""
+
+    def __init__(self, B, beam, max_len, eos_id, prompt_len, device):
+        BB = B * beam
+        z = lambda *shape, dtype=torch.int32: torch.zeros(*shape, dtype=dtype, device=device)
+        self.B, self.beam, self.BB, self.max_len = B, beam, BB, max_len
+        self.out = z(2, BB, max_len)
+        self.cur, self.cur_new = z(BB, dtype=torch.float32), z(BB, dtype=torch.float32)
+        self.next_tok, self.src, self.anc = z(BB), z(BB), z(max_len, BB)
+        self.has_eos = z(2, BB, dtype=torch.uint8)
+        self.blk_eos, self.ticket = z(B), z(1)
+        self.pos = torch.full((1,), prompt_len, dtype=torch.int32, device=device)
+        self.step, self.done = z(1), z(1)
+        self.c = L.BeamState(self.out.data_ptr(), max_len, self.cur.data_ptr(), self.cur_new.data_ptr(), self.next_tok.data_ptr(),
+                             self.src.data_ptr(), self.anc.data_ptr(), self.has_eos.data_ptr(), self.blk_eos.data_ptr(),
+                             self.ticket.data_ptr(), self.pos.data_ptr(), self.step.data_ptr(), self.done.data_ptr(), int(eos_id))
+
+    def tokens(self):
+        """[BB, steps] int64 histories after the steps run so far (syncs)."""
+        steps = int(self.step)
+        return self.out[steps & 1, :, :steps].long(), steps
+
+
 class LlamaEngine:
     """HF-Llama-architecture decoder behind `LlamaPostTokenization.forward` (pmc_llama.py:546-596)."""
 
@@ -444,6 +469,16 @@ class LlamaEngine:
 
     def decode(self, cache: KVCache, st: GenState, B):
         L.check(self.ctx.lib.pcy_llama_decode(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode")
+
+    def decode_graph(self, cache: KVCache, st: GenState, B):
+        """decode step as one replayed hipGraph (~190 launches otherwise): loops that select between steps on the device."""
+        L.check(self.ctx.lib.pcy_llama_decode_graph(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode_graph")
+
+    def beam_step(self, logits, bs: "BeamState", group_size, diversity_penalty):
+        """one step of the reference's diverse-beam bookkeeping on the device (pcy_beam_step); logits [BB, vocab] bf16."""
+        _chk_bf16(logits)
+        L.check(self.ctx.lib.pcy_beam_step(self.ctx.h, _p(logits), logits.shape[1], bs.B, bs.beam, group_size, float(diversity_penalty),
+                                           C.byref(bs.c)), "pcy_beam_step")
 
     def pick(self, cache: KVCache, st: GenState, B, advance_pos):
         L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, int(advance_pos)),

@@ -8,13 +8,28 @@ import torch
 from ..engine import GenState, KVCache, LlamaConfig, LlamaEngine
 
 
-class _Past(list):
+class _Past:
     """past_key_values: indexable [layer][0|1] -> [B,Hkv,t,dh] VIEWS of the engine cache, so the in-place row
-    re-indexing the reference's beam search performs (model_unified.py:830-832) acts on the live cache."""
+    re-indexing the reference's beam search performs (model_unified.py:830-832) acts on the live cache.  The views are
+    built on access (a decode loop that never looks at them does not pay 2L tensor slicings per step)."""
 
     def __init__(self, cache: KVCache, t: int):
-        super().__init__([[cache.k[l, :, :, :t], cache.v[l, :, :, :t]] for l in range(cache.k.shape[0])])
         self.cache, self.t = cache, t
+
+    def __len__(self):
+        return self.cache.k.shape[0]
+
+    def __getitem__(self, l):
+        if isinstance(l, slice):
+            return [self[i] for i in range(len(self))[l]]
+        if l < 0:
+            l += len(self)
+        if not 0 <= l < len(self):
+            raise IndexError(l)
+        return [self.cache.k[l, :, :, :self.t], self.cache.v[l, :, :, :self.t]]
+
+    def __iter__(self):
+        return (self[l] for l in range(len(self)))
 
 
 class LlamaPostTokenization:
@@ -77,7 +92,7 @@ class LlamaPostTokenization:
         st = self._state
         st.pos.fill_(t)
         st.next_tok.copy_(input_ids.view(-1).to(torch.int32))
-        eng.decode(cache, st, B)
+        eng.decode_graph(cache, st, B)
         return SimpleNamespace(logits=st.logits.clone().view(B, 1, -1), past_key_values=_Past(cache, t + 1),
                                hidden_states=None, loss=None)
 
