@@ -795,12 +795,16 @@ int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, in
                   const pcy_beam_state* st) {
   if (B <= 0 || beam <= 0 || beam > 32 || group_size <= 0 || beam % group_size)
     return fail(1, "pcy_beam_step: beam=%d (1..32) must be a multiple of group_size=%d", beam, group_size);
-  if (vocab <= 0 || (size_t)((vocab + 31) / 32) * 4 > 60000) return fail(1, "pcy_beam_step: vocab %d unsupported", vocab);
+  if (vocab <= 0 || vocab > 163840) return fail(1, "pcy_beam_step: vocab %d unsupported (<= 163840)", vocab);
   PcyBeamState b{};
   b.out = st->out; b.max_len = st->max_len; b.cur = st->cur; b.cur_new = st->cur_new; b.next_tok = st->next_tok; b.src = st->src;
   b.anc = st->anc; b.has_eos = st->has_eos; b.blk_eos = st->blk_eos; b.ticket = st->ticket; b.pos = st->pos; b.step = st->step;
   b.done = st->done; b.eos_id = st->eos_id;
-  pcy_launch_beam_step(c->stream, (const bf16_t*)logits, vocab, B, beam, group_size, diversity_penalty, b);
+  // the partials live at the very end of the workspace the decode step was sized for (its last 4 KiB are slack), so that this
+  // call never re-allocates the workspace a captured decode graph points into
+  if (c->ws_bytes < pcy_beam_ws_bytes(B, beam) + 4096 && c->reserve(pcy_beam_ws_bytes(B, beam) + 4096)) return 2;
+  void* ws = c->ws + c->ws_bytes - align_up(pcy_beam_ws_bytes(B, beam), 256);
+  pcy_launch_beam_step(c->stream, (const bf16_t*)logits, vocab, B, beam, group_size, diversity_penalty, b, ws);
   return check_launch("pcy_beam_step");
 }
 
@@ -808,7 +812,9 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
   const int Hkv = m->n_kv_heads, dh = m->head_dim, L = m->n_layers;
   if (t <= 0) return 0;
   if ((t * dh) % 8) return fail(1, "pcy_kv_reorder: t * head_dim must be a multiple of 8");
-  const size_t tmp_elems = (size_t)2 * L * B * Hkv * t * dh;
+  // scratch sized for the cache capacity, not for t: a workspace that grows step by step would be re-allocated (and the
+  // captured decode graph dropped) several times per beam search
+  const size_t tmp_elems = (size_t)2 * L * B * Hkv * kv->Tmax * dh;
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
   bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
   const dim3 grid(B, Hkv, 2 * L);

@@ -117,7 +117,9 @@ struct PcyBeamState {
   int32_t* pos; int32_t* step; int32_t* done;   // device scalars: cache length, step index, all-rows-hold-an-EOS flag
   int32_t eos_id;
 };
-void pcy_launch_beam_step(hipStream_t s, const bf16_t* logits, int V, int B, int beam, int g, float penalty, const PcyBeamState& st);
+size_t pcy_beam_ws_bytes(int B, int beam);   // scratch of pcy_launch_beam_step (row-statistics partials)
+void pcy_launch_beam_step(hipStream_t s, const bf16_t* logits, int V, int B, int beam, int g, float penalty, const PcyBeamState& st,
+                          void* ws);
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps);

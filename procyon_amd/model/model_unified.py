@@ -407,64 +407,67 @@ class UnifiedProCyon:
         """`_generate_beam_search` (model_unified.py:702-842): diverse beam search with the reference's exact
         bookkeeping (step-0 single-beam top-g, in-place Hamming penalty carried in the score, bf16 log-softmax +
         fp32 running score, EOS-anywhere stop).  The transformer steps run on the engine; the per-step
-        O(B x groups) bookkeeping is the reference's sequence of torch ops on the model's device."""
+        O(B x groups) bookkeeping is `pcy_beam_step` (one launch; ties between equal candidate scores go to the lowest flat
+        index, where torch.topk leaves the order unspecified)."""
         B = input_embeds.shape[0]
         BB = B * beam_size
         V = self.text_encoder.model.vocab_size
         if beam_size % beam_group_size != 0:
             raise ValueError("beam_group_size must evenly divide beam_size, got: "
                              f"{beam_size} % {beam_group_size} != 0")
-        groups = beam_size // beam_group_size
         emb_rep = torch.repeat_interleave(input_embeds, repeats=beam_size, dim=0)
         mask_rep = torch.repeat_interleave(attn_mask, repeats=beam_size, dim=0)
         dev = self.device
-        cur = torch.zeros((BB,), device=dev)
-        out = torch.zeros(BB, max_len, dtype=torch.int64, device=dev)
         enc = self.text_encoder
+        eng = enc.engine
+        if beam_size > 32:
+            raise ValueError("beam_size > 32 is not supported by the device-side beam step")
+        from ..engine import BeamState, GenState
+        T = emb_rep.shape[1]
         keep_new = enc.max_new_tokens
         enc.max_new_tokens = max(keep_new, max_len)
-        past = None
-        # logits record [BB, steps, V]: preallocated on the device and reordered there (the reference keeps it on the host and
-        # pays a host copy of the whole record per group and step, model_unified.py:827-829)
-        out_logits = torch.empty(BB, max_len, V, dtype=emb_rep.dtype, device=dev)
-        steps = 0
-        eng = enc.engine
-        ident = torch.arange(BB, device=dev)
+        # Everything per step stays on the device and nothing synchronises: the decode step is ONE replayed hipGraph reading the
+        # next tokens and the position from device memory, the reference's per-group bookkeeping is ONE launch (pcy_beam_step),
+        # the KV reorder two (rows that keep their place are skipped).  The logits record is kept per SLOT and step and is
+        # re-indexed once at the end along the parent chain (the reference re-indexes the whole history on the host in every
+        # group of every step, model_unified.py:827-829).  The EOS stop (:833) is decided on the device; once it has fired the
+        # queued steps change nothing, so the host looks at the flag only every few steps.
+        o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
+                logit_positions=torch.full((BB,), T - 1), want_hidden=False)
+        cache = o.past_key_values.cache
+        bs = BeamState(B, beam_size, max_len, self.tokenizer.eos_token_id, prompt_len=T, device=dev)
+        st = GenState(BB, V, 1, dev)
+        st.pos, st.next_tok = bs.pos, bs.next_tok                  # the decode graph reads what the beam step writes
+        st.c.pos, st.c.next_tok = bs.pos.data_ptr(), bs.next_tok.data_ptr()
+        rec = torch.empty(max_len, BB, V, dtype=emb_rep.dtype, device=dev)
+        logits = o.logits[:, -1, :].contiguous()
         for i in range(max_len):
-            if i == 0:
-                o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
-                        logit_positions=torch.full((BB,), emb_rep.shape[1] - 1), want_hidden=False)
-            else:
-                o = enc(input_ids=out[:, i - 1].unsqueeze(-1), use_cache=True, past_key_values=past)
-            past = o.past_key_values
-            logits = o.logits[:, -1, :]
-            out_logits[:, i] = logits
-            steps = i + 1
-            log_probs = torch.log_softmax(logits, dim=-1) + cur[:, None]
-            src = ident.clone()
-            for b in range(B):
-                bs0 = b * beam_size
-                for k in range(groups):
-                    inc = 1 if i == 0 else beam_group_size
-                    gs = bs0 + k * beam_group_size
-                    ge = gs + beam_group_size
-                    lp = log_probs[gs:gs + inc]
-                    if k != 0:
-                        # = diversity_penalty * torch.bincount(out[bs0:gs, i], minlength=V) without bincount's device sync
-                        counts = torch.zeros(V, device=dev).scatter_add_(0, out[bs0:gs, i], torch.ones(gs - bs0, device=dev))
-                        lp -= diversity_penalty * counts
-                    top_v, top_i = lp.ravel().topk(beam_group_size)
-                    orig = (top_i // V) + gs
-                    out[gs:ge] = out[orig]
-                    out[torch.arange(gs, ge, device=dev), i] = top_i % V
-                    cur[gs:ge] = top_v
-                    out_logits[gs:ge, :steps] = out_logits[orig, :steps]
-                    src[gs:ge] = orig
-            if not torch.equal(src, ident):
-                eng.kv_reorder(past.cache, src, past.t)  # one gather per layer instead of per-group row copies
-            if torch.all((out == self.tokenizer.eos_token_id).any(dim=1)).item():
+            if i > 0:
+                if T + i > cache.Tmax:
+                    raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
+                eng.decode_graph(cache, st, BB)
+                logits = st.logits
+            rec[i].copy_(logits)
+            eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
+            eng.kv_reorder(cache, bs.src, T + i)
+            if (i & 7) == 7 and int(bs.done):
                 break
-        out, cur, out_logits = out.cpu(), cur.cpu(), out_logits[:, :steps].cpu()
+        out, steps = bs.tokens()                                   # synchronises
+        anc = bs.anc[:steps].long()
+        slot = torch.arange(BB, device=dev)
+        idx = torch.empty(steps, BB, dtype=torch.long, device=dev)
+        for s_ in range(steps - 1, -1, -1):                        # the record of step s is re-indexed by the parents of steps >= s
+            slot = anc[s_][slot]
+            idx[s_] = slot
+        # [BB, steps, V] on the device, then ONE copy into pinned host memory (a pageable destination moves the 2.5 MB per step
+        # and beam-10 record at a few GB/s: ~1 ms per generated token)
+        out_logits_dev = rec[:steps].gather(1, idx[:, :, None].expand(steps, BB, V)).transpose(0, 1).contiguous()
+        out_logits = torch.empty(out_logits_dev.shape, dtype=out_logits_dev.dtype, pin_memory=True)
+        out_logits.copy_(out_logits_dev, non_blocking=True)
+        full = torch.zeros(BB, max_len, dtype=torch.int64)
+        full[:, :steps] = out.cpu()
+        out, cur = full, bs.cur.cpu()
+        torch.cuda.current_stream(dev).synchronize()
         enc.max_new_tokens = keep_new
         return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
 
