@@ -380,17 +380,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; l[qt] = 0.f; }
-    {
-      uint4 kr[KLD];
-      fetch_k(0, kr);
-      __syncthreads();                         // previous readers of buffer 0 are done
-      put_k(smem, kr);
-      __syncthreads();
-    }
-    for (int kb0 = 0, cur = 0; kb0 < kend; kb0 += 32, cur ^= 1) {
-      uint4 kr[KLD];
-      const bool more = kb0 + 32 < kend;
-      if (more) fetch_k(kb0 + 32, kr);
+    // Key blocks travel global -> registers -> LDS.  A block is requested TWO iterations before it is read (two register sets
+    // ka / kb_): with one iteration of look-ahead every 32-key step waited for a full L2 / HBM round trip (the matrix pipe
+    // was busy 8.7 % of the time on the Llama prefill shape, PMC).
+    auto p1_step = [&](int kb0, int cur) {
       const char* kbuf = smem + cur * KTILE;
       if (active) {
 #pragma unroll
@@ -412,8 +405,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
           m[qt] = mn;
         }
       }
-      if (more) put_k(smem + (cur ^ 1) * KTILE, kr);
+    };
+    {
+      uint4 ka[KLD], kb_[KLD];
+      fetch_k(0, ka);
+      __syncthreads();                         // previous readers of buffer 0 are done
+      put_k(smem, ka);
+      if (32 < kend) fetch_k(32, ka);          // block 1 -> ka
       __syncthreads();
+#define PCY_P1_STEP(NEXT, FAR)                                                          \
+      {                                                                                 \
+        if (kb0 + 64 < kend) fetch_k(kb0 + 64, FAR);      /* block i+2 */               \
+        p1_step(kb0, cur);                                                              \
+        if (kb0 + 32 < kend) put_k(smem + (cur ^ 1) * KTILE, NEXT);   /* block i+1 */   \
+        __syncthreads();                                                                \
+        kb0 += 32; cur ^= 1;                                                            \
+      }
+      int kb0 = 0, cur = 0;
+      while (kb0 < kend) {
+        PCY_P1_STEP(ka, kb_)
+        if (kb0 >= kend) break;
+        PCY_P1_STEP(kb_, ka)
+      }
+#undef PCY_P1_STEP
     }
     bool empty_row = false;
 #pragma unroll
@@ -433,17 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int n = 0; n < NT; ++n) oacc[qt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   char* kb_base = smem;
   char* vb_base = smem + 2 * KTILE;
-  {
-    uint4 kr[KLD], vr[VLD];
-    fetch_k(0, kr); fetch_v(0, vr);
-    __syncthreads();
-    put_k(kb_base, kr); put_v(vb_base, vr);
-    __syncthreads();
-  }
-  for (int kb0 = 0, cur = 0; kb0 < kend; kb0 += 32, cur ^= 1) {
-    uint4 kr[KLD], vr[VLD];
-    const bool more = kb0 + 32 < kend;
-    if (more) { fetch_k(kb0 + 32, kr); fetch_v(kb0 + 32, vr); }
+  auto p2_step = [&](int kb0, int cur) {
     const char* kbuf = kb_base + cur * KTILE;
     const char* vbuf = vb_base + cur * VTILE;
     if (active) {
@@ -458,8 +462,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         for (int n = 0; n < NT; ++n) oacc[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vfrag(vbuf, n), oacc[qt][n], 0, 0, 0);
       }
     }
-    if (more) { put_k(kb_base + (cur ^ 1) * KTILE, kr); put_v(vb_base + (cur ^ 1) * VTILE, vr); }
+  };
+  {
+    uint4 ka[KLD], va[VLD], kb_[KLD], vb_[VLD];
+    fetch_k(0, ka); fetch_v(0, va);
     __syncthreads();
+    put_k(kb_base, ka); put_v(vb_base, va);
+    if (32 < kend) { fetch_k(32, ka); fetch_v(32, va); }
+    __syncthreads();
+#define PCY_P2_STEP(KN, VN, KF, VF)                                                                        \
+    {                                                                                                      \
+      if (kb0 + 64 < kend) { fetch_k(kb0 + 64, KF); fetch_v(kb0 + 64, VF); }                               \
+      p2_step(kb0, cur);                                                                                   \
+      if (kb0 + 32 < kend) { put_k(kb_base + (cur ^ 1) * KTILE, KN); put_v(vb_base + (cur ^ 1) * VTILE, VN); } \
+      __syncthreads();                                                                                     \
+      kb0 += 32; cur ^= 1;                                                                                 \
+    }
+    int kb0 = 0, cur = 0;
+    while (kb0 < kend) {
+      PCY_P2_STEP(ka, va, kb_, vb_)
+      if (kb0 >= kend) break;
+      PCY_P2_STEP(kb_, vb_, ka, va)
+    }
+#undef PCY_P2_STEP
   }
   if (!active) return;
 #pragma unroll
