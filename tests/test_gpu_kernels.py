@@ -408,3 +408,23 @@ def test_beam_step_kernel_matches_reference_bookkeeping(ctx, monkeypatch, B, bea
     for s_ in range(n - 1, -1, -1):
         slot = anc[s_][slot]
         assert torch.equal(rec[s_].cpu()[slot], lg_ref.view(BB, -1, V)[:, s_]), s_
+
+
+@pytest.mark.parametrize("M", [64, 2048])
+def test_gemm_swiglu_epilogue_every_bf16_gate_value(ctx, M):
+    """The SwiGLU epilogue of both GEMM kernels (128x128 at M = 64, 256x256 at M = 2048): every bf16 pattern as the gate value,
+    up = 1, must equal torch's F.silu on the bf16 tensor bit for bit.  (A table-lookup version of bf16(silu(g)) like the ESM
+    GELU one passed this test too but bought nothing on the Llama gate/up GEMM -- 987 vs 991 TFLOP/s end to end -- and was
+    dropped.)"""
+    from procyon_amd import _lib as L
+    from procyon_amd.engine import interleave_gate_up
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    gate = torch.cat([bits, bits]).view(BF).view(2048, 64).contiguous()        # [F = 2048, K = 64]: every pattern twice
+    up = torch.ones(2048, 64, dtype=BF)
+    A = torch.zeros(M, 64, dtype=BF)
+    A[torch.arange(M), torch.arange(M) % 64] = 1.0
+    out = ctx.gemm(A.cuda(), interleave_gate_up(gate.cuda(), up.cuda()), None, None, L.EPI_SWIGLU).cpu()[:64]   # [64, F]: silu(gate[f][m])
+    x = gate.t().contiguous()
+    ok = torch.isfinite(x.float()) & (x.view(torch.int16) != -32768)           # inf / NaN become NaN in the MFMA, -0 arrives as +0
+    ref = F.silu(x)
+    assert torch.equal(out[ok].view(torch.int16), ref[ok].view(torch.int16))
