@@ -143,6 +143,7 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t)
     value = world * a.tokens * a.steps / dt
+    ctx.sync()   # raises if a cross-workgroup hand-over of the fused decode launches ever hit its watchdog (results would be invalid)
 
     # ---- phases + decode-only rate (outside the timed region) --------------------------------------
     one_step(record=True)
