@@ -545,6 +545,120 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
+// Persistent variant of gemm_kernel_big for the ESM fc1 GEMM (EPI_GELU_ESM, K = 1280: 20 k-steps per tile, so the first-stage
+// round trip and the table-lookup epilogue are a large share of a tile).  The other epilogues keep gemm_kernel_big: inside a
+// tile loop their register demand passes 256 VGPRs (measured: spills, fp8 prefill -12 %).
+template <int EPI, bool F8 = false>
+__global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
+  constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
+  constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
+  extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
+  char* smem = smem_dyn;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // workgroup b computes tiles b, b + gridDim.x, ... (gridDim.x = min(tiles, CUs), a multiple of 8 or the whole grid, so b % 8
+  // -- the XCD -- is the same for all of them and each XCD still walks one contiguous run of the rasterised tile order).  The
+  // first k-stage of the NEXT tile is requested before the epilogue of the current one: its L2 / HBM round trip runs under
+  // the table lookups and stores (fc1 548 -> 526 us at M = 32832).
+  constexpr bool PERSIST = true;
+  const int ntiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
+  const int xq = ntiles >> 3, xr = ntiles & 7;
+  auto tile_of = [&](int vb) { const int xcd = vb & 7; return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (vb >> 3); };
+  int m0, n0;
+  tile_origin<TBM, TBN>(a, tile_of(blockIdx.x), m0, n0);
+  // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
+  const int nk = F8 ? a.K / 128 : a.K / BK;
+  const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
+  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int vb = blockIdx.x; PERSIST ? vb < ntiles : vb == (int)blockIdx.x; vb += gridDim.x) {
+  f32x4 acc[WTN][WTM];
+#pragma unroll
+  for (int i = 0; i < WTN; ++i)
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // stage 0 of this tile has landed; every wave has left the previous tile's epilogue
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* Acur = smem + cur * (TILE_A + TILE_W);
+    const char* Wcur = Acur + TILE_A;
+    if (kt + 1 < nk) {
+      char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+    }
+    if constexpr (F8) {
+      i32x8 xf[WTM];
+#pragma unroll
+      for (int j = 0; j < WTM; ++j)
+        xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) {
+        const i32x8 wf = cat_frag(lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq), lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, 4 + fq));
+#pragma unroll
+        for (int j = 0; j < WTM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < BK / 32; ++kb) {
+        bf16x8 xf[WTM], wf[WTN];
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+#pragma unroll
+        for (int i = 0; i < WTN; ++i)
+#pragma unroll
+          for (int j = 0; j < WTM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // next tile: origin + its first k-stage into buffer 0 (all waves passed the barrier that ended the last k-step, so no
+  // wave still reads LDS; the ESM GELU table goes to buffer 1)
+  const int nvb = vb + gridDim.x;
+  int nm0 = 0, nn0 = 0;
+  if (PERSIST && nvb < ntiles) {
+    tile_origin<TBM, TBN>(a, tile_of(nvb), nm0, nn0);
+    stage_tile<BK, TBM, NW>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
+    stage_tile<BK, TBN, NW>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
+  }
+  if constexpr (F8) {
+    // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
+    float sx[WTM];
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = m0 + wm * WTM * 16 + j * 16 + fr;
+      sx[j] = a.sa[m < a.M ? m : a.M - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < WTN; ++i) {
+      const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sw = a.sw[n + r < a.N ? n + r : a.N - 1];
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) acc[i][j][r] = (acc[i][j][r] * sx[j]) * sw;
+      }
+    }
+    // the epilogue in two halves of 64 features: its up-front residual loads (64 VGPRs for the whole 64 x 128 wave tile)
+    // plus the scale registers would spill
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+  } else if constexpr (EPI == EPI_GELU_ESM) {
+    gelu_lut_to_lds<512>(smem + TILE_A + TILE_W);
+    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
+  } else {
+    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
+  }
+  m0 = nm0; n0 = nn0;
+  }   // tile loop
+}
+
 // ------------------------------------------------------------------------------------------------
 // Large-M variant, 8-wave PING-PONG: same 256 x 256 tile / BK = 32 / four LDS stages, but the two waves of every SIMD
 // run half a step out of phase.  Every wave alternates  R: 12 x ds_read_b128 (its fragments of one 32-k step)  and
@@ -679,7 +793,16 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
       }
-      hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
+      if constexpr (EPI == EPI_GELU_ESM) {
+        static bool configured_p = false;
+        if (!configured_p) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          configured_p = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
+      }
     }
     return;
   }
