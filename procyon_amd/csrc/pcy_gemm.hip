@@ -134,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
     }
     return;
   }
-  if (EPI == EPI_STORE && ROPE_OK && a.rope_cos != nullptr) {
+  if constexpr (EPI == EPI_STORE && ROPE_OK) if (a.rope_cos != nullptr) {
     // fused rotary: a head = 4 consecutive 16-feature tiles, this lane holds features e..e+3 (tile t) and their partners
     // e+32.. (tile t+2) of the same token.  All loads are issued in batches ahead of the arithmetic: bias once, the
     // positions of the WTM tokens once, then per token its four cos and four sin quads (shared by every head).
@@ -338,6 +338,65 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     return;
   }
   gemm_epilogue<EPI>(a, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-problem variant: 64 x 64 tile (2x2 waves of 32 x 32), same mainloop and the same per-element accumulation order as
+// gemm_kernel, so a row's result does not depend on which of the two ran (the packing invariance of the ESM encoder holds).
+// For GEMMs whose 128 x 128 tiling leaves most of the chip idle: one 1024-residue protein through ESM2-650M gives fc2
+// 9 x 10 = 90 tiles for 512 slots (80 us of a 217 us layer); 64 x 64 tiles give 340.
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_small(PcyGemmArgs a) {
+  constexpr int BK = 64, TM = 64, TN = 64, WTM = 2, WTN = 2;
+  constexpr int TILE_A = TM * BK * 2, TILE_W = TN * BK * 2;   // 8 KiB each
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (TILE_A + TILE_W)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  int m0, n0;
+  tile_origin<TM, TN>(a, tile, m0, n0);
+  f32x4 acc[WTN][WTM];
+#pragma unroll
+  for (int i = 0; i < WTN; ++i)
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = a.K / BK;
+  stage_tile<BK, TM, 4>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, TN, 4>(a.W, a.K, n0, a.N, 0, smem + TILE_A, wave, lane);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* Acur = smem + cur * (TILE_A + TILE_W);
+    const char* Wcur = Acur + TILE_A;
+    if (kt + 1 < nk) {
+      char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+      stage_tile<BK, TM, 4>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TN, 4>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+    }
+#pragma unroll
+    for (int kb = 0; kb < BK / 32; ++kb) {
+      bf16x8 xf[WTM], wf[WTN];
+#pragma unroll
+      for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < WTN; ++i)
+#pragma unroll
+        for (int j = 0; j < WTM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if constexpr (EPI == EPI_GELU_ESM) {
+    gelu_lut_to_lds<GEMM_THREADS>(smem);
+    gemm_epilogue<EPI, WTN, WTM, false>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    return;
+  }
+  gemm_epilogue<EPI, WTN, WTM, false>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -805,6 +864,19 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
       }
     }
     return;
+  }
+  // fewer than 192 tiles of 128 x 128 (of 512 slots): 64 x 64 tiles -- four times the workgroups, same arithmetic per element
+  if constexpr (EPI != EPI_SWIGLU) {
+    if (tiles < 192 && a.rope_cos == nullptr && bk == 64) {
+      const int tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+      PcyGemmArgs b = a;
+      const int tn64 = (a.N + 63) / 64;
+      long g64 = (5L << 19) / ((long)64 * a.K * 2);
+      if (g64 < 4) g64 = 4;
+      b.gn = (int)(g64 > tn64 ? tn64 : g64);
+      hipLaunchKernelGGL((gemm_kernel_small<EPI>), dim3(tiles64), dim3(GEMM_THREADS), 0, s, b);
+      return;
+    }
   }
   if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
