@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcy.so")
+LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY_LIB: A/B of experimental builds
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)

@@ -81,6 +81,19 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
   }
 }
 
+// one 1-KiB piece (instruction i of this wave) of stage_tile
+template <int BK, int ROWS, int NW>
+__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
+                                            char* lds_tile, int wave, int lane, int i) {
+  constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = ROWS / RPI;
+  const int inst = wave * (NINST / NW) + i;
+  const int r = inst * RPI + lane / CPR;
+  const int c = (lane % CPR) ^ swz<BK>(r);
+  int gr = row0 + r;
+  gr = gr < nrows_valid ? gr : nrows_valid - 1;
+  __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
+}
+
 template <int BK>
 __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK>(row)) << 4));
@@ -311,7 +324,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     const int cur = kt & 1;
     const char* Acur = smem + cur * 2 * TILE_B;
     const char* Wcur = Acur + TILE_B;
-    if (kt + 1 < nk) {
+#ifndef PCY_G128_VARIANT
+#define PCY_G128_VARIANT 0
+#endif
+    // (PCY_G128_VARIANT 1 = the split + priority schedule of gemm_kernel_big: no gain here, two workgroups per CU already overlap:
+    // ESM wo 638 vs 641, Llama qkv T512 482 vs 530 TFLOP/s)
+    if ((!PCY_G128_VARIANT || BK != 64) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
       stage_tile<BK>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
       stage_tile<BK>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
@@ -323,11 +341,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
       for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
+      if (PCY_G128_VARIANT && BK == 64 && kt + 1 < nk) {   // as in gemm_kernel_big: half of the next stage behind each kb's reads
+        char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
+        if (kb == 0) stage_tile<BK>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+        else stage_tile<BK>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
+      }
+      if (PCY_G128_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      if (PCY_G128_VARIANT) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
@@ -537,7 +562,17 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     const int cur = kt & 1;
     const char* Acur = smem + cur * (TILE_A + TILE_W);
     const char* Wcur = Acur + TILE_A;
-    if (kt + 1 < nk) {
+// PCY_BIG_VARIANT (bits): 1 = the next stage's DMA is issued in two halves, A behind the first 32-k step's fragment reads and
+// W behind the second's, instead of all eight pieces at the top of the k-step; 2 = s_setprio(1) around each block of 32 MFMAs.
+// Measured at 4096^3 / ESM qkv / ESM fc2: neither 1195 / 783 / 925 TFLOP/s, split only 1161 / 766 / 890, priority only 1198 /
+// 783 / 932, BOTH 1258 / 822-842 / 976-997 (shipped); one piece after every 8 MFMAs (bit 4) 1164 / 780 / 890.
+#ifndef PCY_BIG_VARIANT
+#define PCY_BIG_VARIANT 3
+#endif
+#ifndef PCY_F8_VARIANT
+#define PCY_F8_VARIANT 0
+#endif
+    if (((F8 && !PCY_F8_VARIANT) || (!F8 && !(PCY_BIG_VARIANT & 1))) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
       stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
       stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
@@ -547,13 +582,24 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 #pragma unroll
       for (int j = 0; j < WTM; ++j)
         xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
+      // PCY_F8_VARIANT 1: the A stage behind the x fragment reads, the W stage after half of the MFMAs, priority raised
+      // (measured no better than the plain order on the fp8 prefill: 1609-1615 vs 1619-1620 TFLOP/s; off)
+      if (PCY_F8_VARIANT && kt + 1 < nk)
+        stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
+      if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
         const i32x8 wf = cat_frag(lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq), lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, 4 + fq));
 #pragma unroll
         for (int j = 0; j < WTM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        if (PCY_F8_VARIANT && i == WTN / 2 - 1 && kt + 1 < nk) {
+          __builtin_amdgcn_s_setprio(0);
+          stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
+          __builtin_amdgcn_s_setprio(1);
+        }
       }
+      if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
       for (int kb = 0; kb < BK / 32; ++kb) {
@@ -562,11 +608,26 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
         for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
         for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+        if ((PCY_BIG_VARIANT & 1) && !(PCY_BIG_VARIANT & 4) && kt + 1 < nk) {   // one operand's stage behind each kb's fragment reads
+          char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+        }
+        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < WTN; ++i)
+        for (int i = 0; i < WTN; ++i) {
 #pragma unroll
           for (int j = 0; j < WTM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          if ((PCY_BIG_VARIANT & 4) && (i & 1) && kt + 1 < nk) {   // one DMA piece after every 8 MFMAs
+            char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+            if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
+            if (kb == 0) stage_piece<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane, i >> 1);
+            else stage_piece<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane, i >> 1);
+            if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
+          }
+        }
+        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
       }
     }
     __syncthreads();
@@ -642,7 +703,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
     const int cur = kt & 1;
     const char* Acur = smem + cur * (TILE_A + TILE_W);
     const char* Wcur = Acur + TILE_A;
-    if (kt + 1 < nk) {
+    if ((F8 || !(PCY_BIG_VARIANT & 1)) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
       stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
       stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
@@ -667,11 +728,18 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
         for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
         for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+        if ((PCY_BIG_VARIANT & 1) && kt + 1 < nk) {
+          char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+        }
+        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < WTN; ++i)
 #pragma unroll
           for (int j = 0; j < WTM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
       }
     }
     __syncthreads();
@@ -810,6 +878,9 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
+#ifndef PCY_BIG_MIN_N
+#define PCY_BIG_MIN_N 1280   // with the split + priority schedule the 256 x 256 kernel also wins at N = K = 1280 (ESM wo: 167-177 -> 152-157 us)
+#endif
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
@@ -828,7 +899,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
     size_ok = e256 * 1.14 > e128;
   }
   const bool big_ok = size_ok && EPI != EPI_GELU_ERF &&
-                      (a.N >= 2560 || (a.N >= 256 && a.K >= 2560));
+                      (a.N >= PCY_BIG_MIN_N || (a.N >= 256 && a.K >= 2560));
   if (big_ok) {
     constexpr int smem = 2 * (256 + 256) * 64 * 2;
     const int tiles_big = ((a.M + 255) / 256) * ((a.N + 255) / 256);
