@@ -565,7 +565,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 // PCY_BIG_VARIANT (bits): 1 = the next stage's DMA is issued in two halves, A behind the first 32-k step's fragment reads and
 // W behind the second's, instead of all eight pieces at the top of the k-step; 2 = s_setprio(1) around each block of 32 MFMAs.
 // Measured at 4096^3 / ESM qkv / ESM fc2: neither 1195 / 783 / 925 TFLOP/s, split only 1161 / 766 / 890, priority only 1198 /
-// 783 / 932, BOTH 1258 / 822-842 / 976-997 (shipped); one piece after every 8 MFMAs (bit 4) 1164 / 780 / 890.
+// 783 / 932, BOTH 1258 / 822-842 / 976-997 (shipped); one piece after every 8 MFMAs (bit 4) 1164 / 780 / 890; the whole stage behind the
+// first sub-step 1192-1212 / 783-822 / 930-940; two pieces before and two in the middle of each sub-step: equal to the shipped one.
 #ifndef PCY_BIG_VARIANT
 #define PCY_BIG_VARIANT 3
 #endif
