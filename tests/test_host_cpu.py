@@ -161,3 +161,27 @@ def test_checkpoint_args_load_without_reference_package(tmp_path):
     import pytest
     with pytest.raises(NotImplementedError, match="zero_to_fp32"):
         from_pretrained(checkpoint_dir=str(tmp_path))
+
+
+def test_engine_batch_chooser_and_lazy_past_views():
+    """Host logic that needs no GPU: EsmEngine.preferred_batch (GEMM tile-round fit) and the lazy past_key_values views of the
+    LlamaPostTokenization mirror (live views of the cache, built on access, list protocol of the reference's tuple-of-tuples)."""
+    from types import SimpleNamespace
+    import torch
+    from procyon_amd.engine import EsmConfig, EsmEngine
+    from procyon_amd.model.pmc_llama import _Past
+    fake = SimpleNamespace(cfg=EsmConfig(d=1280, n_layers=33, n_heads=20, ffn=5120))
+    b = EsmEngine.preferred_batch(fake, 1026)
+    assert b == 25                                           # measured optimum for ESM2-650M at 1024 residues (DESIGN.md)
+    assert 16 <= EsmEngine.preferred_batch(fake, 258) <= 40 and 16 <= EsmEngine.preferred_batch(fake, 2050) <= 40
+    cache = SimpleNamespace(k=torch.zeros(3, 2, 4, 10, 8), v=torch.ones(3, 2, 4, 10, 8))
+    past = _Past(cache, 6)
+    assert len(past) == 3 and past[0][0].shape == (2, 4, 6, 8) and past[-1][1].shape == (2, 4, 6, 8)
+    assert len(list(past)) == 3 and len(past[1:]) == 2
+    past[1][0][1] = 7.0                                      # the reference's in-place re-indexing acts on the live cache
+    assert float(cache.k[1, 1, 0, 0, 0]) == 7.0 and float(cache.k[1, 1, 0, 6, 0]) == 0.0
+    try:
+        past[3]
+        assert False
+    except IndexError:
+        pass
