@@ -555,6 +555,8 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
   if ((int)blockIdx.x < n_attn) {
     constexpr int slices = DH / 16;
     const int unit = blockIdx.x;
+    a.xepoch = *epoch_p;   // (a.xflags / a.xmin set by the launcher; the epoch lives in device memory: graph replay freezes arguments)
+    a.xerr = err;
     if (dbg != 3) attn_dec_body<DH, G, 16>(a, smem, unit % slices, (unit / slices) % a.Hkv, unit / (slices * a.Hkv));
     // every wave: its (agent-scope, written-through) output stores have left; then the workgroup's flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -632,13 +634,21 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
 }
 
 template <int DH, int G>
-bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch, unsigned* flags, unsigned* err) {
+bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch, unsigned* flags, unsigned* err,
+                      unsigned* xflags) {
   const int n_attn = (DH / 16) * a.Hkv * a.B;
   const int n_o = n_cu - n_attn;
   if (n_o < 64) return false;
   const int rw = (o.N + n_o * 8 - 1) / (n_o * 8);
   if (rw > 4) return false;
   a.o_sc1 = 1;
+  // key split between the slice workgroups from PCY_AO_XMIN cached keys on (0 = never; read per call so that tests can compare):
+  // the exchange costs ~4 us per layer, the K reads it saves 9 ns per key -- measured decode step at t ~ 640 / 1700 / 3100:
+  // 3.25 / 3.67 / 4.29 ms without, 3.29 / 3.50 / 3.92 ms with the split; on from 1024 keys
+  const char* xe = getenv("PCY_AO_XMIN");
+  const int xmin = xe ? atoi(xe) : 1024;
+  a.xflags = (xmin > 0 && a.scratch) ? xflags : nullptr;
+  a.xmin = xmin;
   // timing experiments (results invalid): 1 = no wait for the attention, 2 = attention workgroups only, 3 = no attention
   static const int dbg = [] { const char* e = getenv("PCY_AO_DBG"); return e ? atoi(e) : 0; }();
   // The attention issues all of its cache reads (<= 1024 keys) in its first microsecond; 33.5 MB of weight reads queued at
@@ -747,14 +757,14 @@ void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a) {
 // Fused decode attention + o projection (see attn_o_kernel).  Returns false (nothing launched) when the shape is not
 // covered: batch 1, head_dim 128, G in {1,2,4,8}, K = H*dh = 4096 contiguous, residual epilogue without x staging.
 bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
-                       unsigned* flags, int max_flags, unsigned* err) {
+                       unsigned* flags, int max_flags, unsigned* err, unsigned* xflags) {
   if (a.B != 1 || o.B != 1 || a.dh != 128 || o.K != 4096 || o.rms_w || o.epi != EPI_RESID || a.dbg) return false;
   if ((a.dh / 16) * a.Hkv * a.B > max_flags || n_cu > 256) return false;
   switch (a.H / a.Hkv) {
-    case 1: return launch_attn_o_rw<128, 1>(s, a, o, n_cu, epoch, flags, err);
-    case 2: return launch_attn_o_rw<128, 2>(s, a, o, n_cu, epoch, flags, err);
-    case 4: return launch_attn_o_rw<128, 4>(s, a, o, n_cu, epoch, flags, err);
-    case 8: return launch_attn_o_rw<128, 8>(s, a, o, n_cu, epoch, flags, err);
+    case 1: return launch_attn_o_rw<128, 1>(s, a, o, n_cu, epoch, flags, err, xflags);
+    case 2: return launch_attn_o_rw<128, 2>(s, a, o, n_cu, epoch, flags, err, xflags);
+    case 4: return launch_attn_o_rw<128, 4>(s, a, o, n_cu, epoch, flags, err, xflags);
+    case 8: return launch_attn_o_rw<128, 8>(s, a, o, n_cu, epoch, flags, err, xflags);
   }
   return false;
 }

@@ -158,7 +158,17 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
   {
     // key fragments of the first two 16-key tiles of this wave, in flight while q / k_new are roped
     constexpr int PASS = NWV * 32;   // keys per block per iteration (2 tiles of 16 per wave)
-    auto key_of = [&](int j0, int tile) { return j0 + wave * 32 + tile * 16 + fr; };
+    // Key split (batch-1 fused launch only, a.xflags != nullptr, long enough caches): the DH/DS column-slice workgroups of a kv
+    // head all need ALL scores of the head, and so far each computed them itself from the head's whole K panel -- 256 B per
+    // key through ONE CU's in-flight window (~30 GB/s: 9 ns per cached key and layer).  Instead slice `bx` scores only the
+    // keys of chunk `bx` and the slices exchange their scores (fp32 bf16-valued, written through + one flag per workgroup,
+    // like the attention -> o hand-over) before the softmax.  Same MFMA code on the same operands: identical scores.
+    const bool xs_on = a.xflags != nullptr && nk >= a.xmin;
+    constexpr int SLICES = DH / DS;
+    const int ck = xs_on ? ((nk + SLICES * 16 - 1) / (SLICES * 16)) * 16 : nk;
+    const int klo = xs_on ? (bx * ck < nk ? bx * ck : nk) : 0;
+    const int khi = xs_on ? ((bx + 1) * ck < nk ? (bx + 1) * ck : nk) : nk;
+    auto key_of = [&](int j0, int tile) { return klo + j0 + wave * 32 + tile * 16 + fr; };
     auto load_tile = [&](int j, bf16x8 (&f)[KB]) {
       const int jc = j < t ? j : (t > 0 ? t - 1 : 0);   // (requesting the tiles before the position load returns, i.e. clamping
                                                        // to Tmax instead of t, measured slower: 3.41 vs 3.38 ms/token)
@@ -173,7 +183,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     auto load_group = [&](int j0) {
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp)
-        if (pp == 0 || j0 + pp * PASS < nk) {
+        if (pp == 0 || klo + j0 + pp * PASS < khi) {
           load_tile(key_of(j0 + pp * PASS, 0), kt[pp][0]);
           load_tile(key_of(j0 + pp * PASS, 1), kt[pp][1]);
         }
@@ -205,12 +215,12 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
       else qf[kb] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 
-    for (int j0 = 0; j0 < nk; j0 += NP * PASS) {
+    for (int j0 = 0; klo + j0 < khi; j0 += NP * PASS) {
       if (j0 > 0) load_group(j0);
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
         const int jb = j0 + pp * PASS;
-        if (jb < nk) {
+        if (klo + jb < khi) {
 #pragma unroll
           for (int tile = 0; tile < 2; ++tile) {
             const int j = key_of(jb, tile);
@@ -222,7 +232,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
               acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kb], kf, acc, 0, 0, 0);
             }
             // D[row = head = fq*4 + r][col = key fr]
-            if (j < nk) {
+            if (j < khi) {
               const bool kept = (keep && j < t) ? keep[j] != 0 : true;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -236,6 +246,37 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     }
   }
   lds_barrier();
+  if (a.xflags != nullptr && nk >= a.xmin) {
+    constexpr int SLICES = DH / DS;
+    const int ck = ((nk + SLICES * 16 - 1) / (SLICES * 16)) * 16;
+    const int klo = bx * ck < nk ? bx * ck : nk, khi = (bx + 1) * ck < nk ? (bx + 1) * ck : nk;
+    unsigned* xs = reinterpret_cast<unsigned*>(a.scratch) + ((size_t)b * a.H + kvh * G) * scld;   // [G][Tmax + 1] of this kv head
+    unsigned* fl = a.xflags + ((size_t)b * a.Hkv + kvh) * SLICES;
+    const int cnt = khi - klo;
+    for (int i = tid; i < G * cnt; i += NT) {
+      const int g = i / cnt, j = klo + i % cnt;
+      __hip_atomic_store(xs + (size_t)g * scld + j, __float_as_uint(sc[g * scld + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its written-through stores have left
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fl + bx, a.xepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      unsigned spins = 0;
+      for (;;) {
+        const bool ok = lane >= SLICES || __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.xepoch;
+        if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 18)) { if (lane == 0 && a.xerr) __hip_atomic_store(a.xerr, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < G * nk; i += NT) {
+      const int g = i / nk, j = i % nk;
+      if (j >= klo && j < khi) continue;
+      sc[g * scld + j] = __uint_as_float(__hip_atomic_load(xs + (size_t)g * scld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    lds_barrier();
+  }
   if (a.dbg == 2) { if (tid == 0) a.o[(size_t)b * a.ldo + kvh * G * DH + c0] = f2bf(sc[0]); return; }
   // ---- phase B ----
   {

@@ -206,7 +206,7 @@ __device__ __forceinline__ void attn_role(const PcyFusedDecArgs& a, char* role) 
   const int qkvw = (a.H + 2 * a.Hkv) * DH;
   bf16_t* stage = reinterpret_cast<bf16_t*>(role + attn_dec_smem_bytes(G, 16, DH, a.Tmax));   // [qkvw] this kv head's q/k/v
   bool dead = a.nowait != 0;
-  PcyDecAttnArgs t;
+  PcyDecAttnArgs t{};
   t.qkv = stage; t.ld = qkvw; t.o = a.ao; t.ldo = a.H * DH; t.pos_dev = a.pos_dev;
   t.cos_t = a.cos_t; t.sin_t = a.sin_t; t.keep = a.keep; t.ld_keep = a.ld_keep; t.scratch = nullptr;
   t.B = a.B; t.H = a.H; t.Hkv = a.Hkv; t.dh = DH; t.Tmax = a.Tmax; t.scale = a.scale; t.dbg = 0;

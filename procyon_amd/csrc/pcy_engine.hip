@@ -180,7 +180,7 @@ int ensure_fused(pcy_ctx* c, const pcy_llama_desc* m) {
     HIP_TRY(hipMemset(c->fused_err, 0, 64));
   }
   if (!c->ao_sync) {
-    const size_t bytes = (size_t)(64 + AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);
+    const size_t bytes = (size_t)(64 + 2 * AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);   // epoch, attention->o flags, score-exchange flags
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ao_sync), bytes));
     HIP_TRY(hipMemset(c->ao_sync, 0, bytes));
   }
@@ -275,7 +275,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
-    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->fused_err))) {
+    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->fused_err,
+                                       c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
       pcy_launch_attn_decode(s, t);
       pcy_launch_gemv(s, o);
     }

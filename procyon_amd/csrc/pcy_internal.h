@@ -87,13 +87,17 @@ struct PcyDecAttnArgs {
   // persistent decode kernel only (zero otherwise): cache length + 1 if already known; `o` written through to memory
   // with agent-scope stores
   int t_plus1; int o_sc1;
+  // key split across the column-slice workgroups of a kv head (fused batch-1 launch only; nullptr = every workgroup scores all
+  // keys): flags [B*Hkv*DH/DS] for THIS launch, epoch value of this decode step, minimum cache length, watchdog word;
+  // `scratch` ([B*H*(Tmax+1)] fp32) carries the exchanged scores
+  unsigned* xflags; unsigned xepoch; int xmin; unsigned* xerr;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;
 // decode attention + o projection (EPI_RESID GEMV over the attention output) in one launch; false = shape not covered,
 // nothing launched.  epoch: device word that differs between consecutive calls on the same `flags` (max_flags words).
 bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
-                       unsigned* flags, int max_flags, unsigned* err);
+                       unsigned* flags, int max_flags, unsigned* err, unsigned* xflags = nullptr);
 
 // pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
 size_t pcy_pool_ws_bytes(int nprot, int d);

@@ -242,7 +242,7 @@ def test_decode_persistent_kernel_matches_layered(monkeypatch):
     assert rel_err(a[2], ref[2]) < 5e-3 and rel_err(a[3], ref[3]) < 5e-3
 
 
-@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (1100, 6, 2)])
+@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (600, 10, 2), (1100, 6, 2)])   # 600 / 1100: key split + score exchange on
 def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
     """PCY_ATTN_O (default on): decode attention and o projection in one launch -- Wo rows wait in registers while the
     attention workgroups run, hand-over by per-workgroup flags.  Same per-lane accumulation order, reduction tree and
@@ -254,6 +254,8 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
     eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))   # T = 1100: more than one 1024-key group
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
+
+    monkeypatch.setenv("PCY_AO_XMIN", "384")   # key split + score exchange between the slice workgroups from 384 keys on (default 1024)
 
     def run(ao, use_graph):
         monkeypatch.setenv("PCY_ATTN_O", "1" if ao else "0")

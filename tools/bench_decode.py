@@ -7,7 +7,7 @@ from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 kw = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
 eng = LlamaEngine(synth.llama_state_dict(**kw, device="cuda"), LlamaConfig(**kw, max_pos=4096), free_source=True)
 ctx = Context.get()
-T, N = 512, 256
+T, N = int(os.environ.get("T", 512)), 256
 emb = (torch.randn(1, T, 4096, device="cuda") * 0.02).bfloat16()
 cache = eng.new_cache(1, T + N)
 st = GenState(1, kw["vocab"], N, "cuda")
