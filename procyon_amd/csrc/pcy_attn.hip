@@ -643,10 +643,11 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   if (rw > 4) return false;
   a.o_sc1 = 1;
   // key split between the slice workgroups from PCY_AO_XMIN cached keys on (0 = never; read per call so that tests can compare):
-  // the exchange costs ~4 us per layer, the K reads it saves 9 ns per key -- measured decode step at t ~ 640 / 1700 / 3100:
-  // 3.25 / 3.67 / 4.29 ms without, 3.29 / 3.50 / 3.92 ms with the split; on from 1024 keys
+  // the exchange costs ~3 us per layer (eight gather loads per thread in flight; ~4 us with a load -> LDS store pair per
+  // iteration), the K reads it saves 9 ns per key -- measured decode step at t ~ 540 / 660 / 1700 / 3100: 3.228 / 3.264 / 3.67 /
+  // 4.29 ms without, 3.238 / 3.262 / 3.44 / 3.92 ms with the split; on from 768 keys
   const char* xe = getenv("PCY_AO_XMIN");
-  const int xmin = xe ? atoi(xe) : 1024;
+  const int xmin = xe ? atoi(xe) : 768;
   a.xflags = (xmin > 0 && a.scratch) ? xflags : nullptr;
   a.xmin = xmin;
   // timing experiments (results invalid): 1 = no wait for the attention, 2 = attention workgroups only, 3 = no attention

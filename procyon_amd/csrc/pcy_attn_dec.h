@@ -270,10 +270,26 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
       }
     }
     __syncthreads();
-    for (int i = tid; i < G * nk; i += NT) {
-      const int g = i / nk, j = i % nk;
-      if (j >= klo && j < khi) continue;
-      sc[g * scld + j] = __uint_as_float(__hip_atomic_load(xs + (size_t)g * scld + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // the other slices' scores: eight independent agent-scope loads per thread in flight, then the LDS stores (a load -> store
+    // pair per iteration paid one memory round trip each)
+    constexpr int UB = 8;
+    for (int i0 = tid; i0 < G * nk; i0 += NT * UB) {
+      unsigned v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int i = i0 + u * NT;
+        const int g = i / nk, j = i - g * nk;
+        v[u] = 0;
+        if (i < G * nk) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(v[u]) : "v"(xs + (size_t)g * scld + j) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        asm volatile("" : "+v"(v[u]));
+        const int i = i0 + u * NT;
+        const int g = i / nk, j = i - g * nk;
+        if (i < G * nk && !(j >= klo && j < khi)) sc[g * scld + j] = __uint_as_float(v[u]);
+      }
     }
     lds_barrier();
   }
