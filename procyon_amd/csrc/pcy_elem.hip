@@ -749,8 +749,86 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(const bf16_t* __restric
   }
 }
 
+// RMSNorm + per-token e4m3 quantisation in one pass (fp8 prefill: the norm's bf16 output is only ever the quantiser's input).
+// The normalised values are exactly those of rmsnorm_kernel (same statistic order, same rounding points) and the scale /
+// codes exactly those of quant_rows_fp8_kernel on them, so the result is bit-identical to the two launches; d <= 8192.
+__global__ __launch_bounds__(NT) void rmsnorm_quant_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int d, float eps,
+                                                              int cast, unsigned char* __restrict__ q, float* __restrict__ scale) {
+  __shared__ float red[NT / 64];
+  __shared__ float redm[NT / 64];
+  constexpr int MAXI = 4;
+  const size_t r = blockIdx.x;
+  const bf16_t* xr = x + r * d;
+  uint4 xv[MAXI];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int k = threadIdx.x * 8 + it * NT * 8;
+    if (k < d) {
+      xv[it] = *reinterpret_cast<const uint4*>(xr + k);
+      const uint32_t u[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float a = lo_bf(u[j]), b = hi_bf(u[j]); ss += a * a + b * b; }
+    }
+  }
+  ss = block_sum<NT>(ss, red);
+  const float rstd = rsqrtf(ss / (float)d + eps);
+  float nv[MAXI][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int k = threadIdx.x * 8 + it * NT * 8;
+    if (k < d) {
+      const uint4 g = *reinterpret_cast<const uint4*>(w + k);
+      const uint32_t u[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = lo_bf(u[j]) * rstd, b = hi_bf(u[j]) * rstd;
+        if (cast == 0) { a = rbf(a); b = rbf(b); }
+        const uint32_t o = pack_bf(lo_bf(gg[j]) * a, hi_bf(gg[j]) * b);       // the bf16 tensor the reference materialises
+        nv[it][2 * j] = lo_bf(o); nv[it][2 * j + 1] = hi_bf(o);
+        amax = fmaxf(amax, fmaxf(fabsf(nv[it][2 * j]), fabsf(nv[it][2 * j + 1])));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float sc = 1.f;
+  if (amax > 0.f) {
+    int e0 = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    e0 = e0 < -126 ? -126 : e0;
+    const float s0 = __uint_as_float((uint32_t)(e0 + 127) << 23);
+    sc = amax <= 448.f * s0 ? s0 : 2.f * s0;
+  }
+  const float inv = 1.f / sc;
+  if (threadIdx.x == 0) scale[r] = sc;
+  unsigned char* qr = q + r * (size_t)d;
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int k = threadIdx.x * 8 + it * NT * 8;
+    if (k < d) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = clamp448(nv[it][e] * inv);
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      *reinterpret_cast<uint2*>(qr + k) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    }
+  }
+}
+
 }  // namespace
 
+bool pcy_launch_rmsnorm_quant_fp8(hipStream_t s, const bf16_t* x, const bf16_t* w, int rows, int d, float eps, int cast,
+                                  unsigned char* q, float* scale) {
+  if (d > 8192 || d % 8) return false;
+  if (rows > 0) hipLaunchKernelGGL(rmsnorm_quant_fp8_kernel, dim3(rows), dim3(NT), 0, s, x, w, d, eps, cast, q, scale);
+  return true;
+}
 void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale) {
   if (rows > 0) hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(rows), dim3(256), 0, s, x, ldx, K, q, scale);
 }

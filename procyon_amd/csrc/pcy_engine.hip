@@ -659,8 +659,15 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   // fp8 weight path: every projection = per-token e4m3 quantisation of its bf16 input + the fp8 MFMA GEMM
   unsigned char* a8 = m->layers_fp8 ? cv.take<unsigned char>((size_t)M * (F > H * dh ? F : H * dh)) : nullptr;
   float* sa8 = m->layers_fp8 ? cv.take<float>((size_t)M) : nullptr;
-  auto linear8 = [&](const bf16_t* A, int K, const void* W8, const float* sw, const bf16_t* resid, bf16_t* Cout, int ldc, int N, int epi) {
-    pcy_launch_quant_rows_fp8(s, A, K, M, K, a8, sa8);
+  // ln != nullptr: A is the raw hidden state, RMSNorm(A) * ln is what gets quantised (one fused pass; PCY_FP8_FUSED_NORM=0 = two launches)
+  auto linear8 = [&](const bf16_t* A, int K, const void* W8, const float* sw, const bf16_t* resid, bf16_t* Cout, int ldc, int N, int epi,
+                     const bf16_t* ln = nullptr) {
+    const char* fe = getenv("PCY_FP8_FUSED_NORM");
+    if (ln && !(fe && atoi(fe) == 0) && pcy_launch_rmsnorm_quant_fp8(s, A, ln, M, K, m->rms_eps, m->rms_cast, a8, sa8)) {
+    } else {
+      if (ln) { pcy_launch_rmsnorm(s, A, ln, xn, M, K, m->rms_eps, m->rms_cast); A = xn; }
+      pcy_launch_quant_rows_fp8(s, A, K, M, K, a8, sa8);
+    }
     PcyGemmArgs g{};
     g.A = (const bf16_t*)a8; g.W = (const bf16_t*)W8; g.C = Cout; g.resid = resid; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = ldc;
     g.ldr = ldc; g.epi = epi; g.fp8 = 1; g.sa = sa8; g.sw = sw;
@@ -673,9 +680,12 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
     const pcy_llama_layer_fp8* L8 = m->layers_fp8 ? &m->layers_fp8[l] : nullptr;
-    pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
-    if (L8) linear8(xn, d, L8->wqkv, L8->sqkv, nullptr, qkv, qkvw, qkvw, EPI_STORE);
-    else linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
+    if (L8) {
+      linear8(x, d, L8->wqkv, L8->sqkv, nullptr, qkv, qkvw, qkvw, EPI_STORE, (const bf16_t*)L.ln1);
+    } else {
+      pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
+      linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
+    }
     pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
     pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
                           (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
@@ -687,9 +697,9 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     pcy_launch_attn(s, t);
     if (L8) linear8(ao, H * dh, L8->wo, L8->so, x, x, d, d, EPI_RESID);
     else linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes);
-    pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
+    if (!L8) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
     if (L8) {
-      linear8(xn, d, L8->wgu, L8->sgu, nullptr, act, F, 2 * F, EPI_SWIGLU);
+      linear8(x, d, L8->wgu, L8->sgu, nullptr, act, F, 2 * F, EPI_SWIGLU, (const bf16_t*)L.ln2);
       linear8(act, F, L8->wdown, L8->sdown, x, x, d, d, EPI_RESID);
       if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
       continue;

@@ -45,6 +45,10 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)
 void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale);
+// RMSNorm(x) * w -> per-token e4m3 codes + scales in one pass, bit-identical to pcy_launch_rmsnorm + pcy_launch_quant_rows_fp8;
+// false (nothing launched) for d > 8192
+bool pcy_launch_rmsnorm_quant_fp8(hipStream_t s, const bf16_t* x, const bf16_t* w, int rows, int d, float eps, int cast,
+                                  unsigned char* q, float* scale);
 void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int d, float eps, int cast);
 void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps);
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,

@@ -155,3 +155,22 @@ def test_pair_scoring_fp8_agrees_with_bf16():
     assert torch.allclose(y8, y16, rtol=0.2, atol=1e-6) and torch.allclose(n8, n16, rtol=0.2, atol=1e-6)
     assert torch.equal(y8 > n8, y16 > n16)
     assert not torch.equal(p8, p16)        # the fp8 path really ran
+
+
+def test_fp8_prefill_fused_norm_quant_bit_identical(monkeypatch):
+    """RMSNorm + per-token quantisation in one pass (default) vs the two launches (PCY_FP8_FUSED_NORM=0): same statistic order,
+    same rounding points, same scale rule -> bit-identical logits, hidden states and K/V at full width (d = 4096, one group of
+    2048 elements per thread pass) and at the small geometry."""
+    for kw, B, T in ((dict(vocab=512, d=4096, n_layers=1, n_heads=32, n_kv_heads=8, ffn=14336), 2, 40),
+                     (dict(vocab=320, d=256, n_layers=2, n_heads=4, n_kv_heads=2, ffn=512), 3, 37)):
+        sd, LR, eng = _llama(kw)
+        torch.manual_seed(9)
+        emb = (torch.randn(B, T, kw["d"]) * 0.02).to(BF).cuda()
+        outs = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("PCY_FP8_FUSED_NORM", fused)
+            cache = eng.new_cache(B, T)
+            logits, hidden = eng.prefill(emb, None, cache, "last", want_hidden=True)
+            outs.append((logits.cpu(), hidden.cpu(), cache.k.cpu().clone(), cache.v.cpu().clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
