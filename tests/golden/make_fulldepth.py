@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Full-depth golden fixtures (run in the BUILD container only; ~64 GB of RAM, a few minutes of CPU).
+
+The oracle (oracle/llama_ref.py, oracle/esm_ref.py -- pinned bit-for-bit to transformers 5.15 on tiny and
+one-layer full-width geometries by make_golden.py) is driven over the FULL BASELINE configs[1] geometry on the
+seeded synthetic weights of procyon_amd/synth.py, twice:
+
+  * bf16  -- the reference's own arithmetic (every intermediate materialised in bf16);
+  * fp32  -- the same weights (bf16 values, upcast) with every op in fp32: the "truth" both bf16 pipelines
+             approximate.
+
+Llama-3-8B, 32 layers, prompts of T = 64 and T = 512 ids: last-row logits of the prefill + 8 cached decode steps,
+teacher-forced on the bf16 oracle's greedy tokens.  ESM2-650M, 33 layers, one 1024-residue protein: pooled
+embedding, shared-space embedding and the soft token of the 3-layer projectors.
+
+A logits vector has 128263 entries; the fixture keeps a column subset (every 61st column + the top-32 columns of
+either run at every step) plus full-vector statistics (norms, argmax, top-8, bf16-vs-fp32 error over ALL columns),
+so the files stay a few hundred KB.  The -m gpu test (tests/test_gpu_fulldepth.py) regenerates the same weights
+from the same seeds and asserts  err(HIP, fp32) <= 1.25 x err(oracle_bf16, fp32).
+
+    python tests/golden/make_fulldepth.py [llama] [esm]
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import esm_ref as ER  # noqa: E402
+from oracle import llama_ref as LR  # noqa: E402
+from oracle import procyon_ref as PR  # noqa: E402
+from procyon_amd import synth  # noqa: E402
+
+LLAMA = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
+ESM = dict(d=1280, n_layers=33, n_heads=20, ffn=5120)
+NDEC = 8
+
+
+def np_(t):
+    if isinstance(t, torch.Tensor):
+        if t.dtype == torch.bfloat16:
+            return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+        return t.contiguous().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{k: np_(v) for k, v in arrs.items()})
+    sz = os.path.getsize(os.path.join(HERE, name + ".npz"))
+    print(f"wrote {name}.npz ({sz / 1024:.0f} KB)", {k: tuple(np_(v).shape) for k, v in arrs.items()}, flush=True)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
+@torch.no_grad()
+def llama_run(sd, geom, ids, dtype, forced=None):
+    """prefill + NDEC cached steps through the oracle's own layer_forward, weights cast per layer to `dtype`
+    (bf16: no-op).  forced: tokens to feed (teacher forcing) or None = greedy on this run's own logits.
+    Returns logits [NDEC+1, V], final-normed hidden rows [NDEC+1, d], tokens [NDEC+1]."""
+    c = lambda t: t.to(dtype)
+    emb_w = sd["model.embed_tokens.weight"]
+    T = ids.shape[1]
+    past = [None] * geom.n_layers
+    logits_all, hid_all, toks = [], [], []
+    x_ids = ids
+    for step in range(NDEC + 1):
+        h = c(F.embedding(x_ids, emb_w))
+        B, Tq, _ = h.shape
+        t_past = 0 if past[0] is None else past[0][0].shape[2]
+        cos_t, sin_t = LR.rope_tables(geom, dtype, t_past + Tq)
+        cos = cos_t[t_past:t_past + Tq][None].expand(B, Tq, -1)
+        sin = sin_t[t_past:t_past + Tq][None].expand(B, Tq, -1)
+        add_mask = LR.build_additive_mask(None, B, Tq, t_past, dtype)
+        for i in range(geom.n_layers):
+            lw = {k: c(v) for k, v in LR._layer_weights(sd, i).items()}
+            h, past[i] = LR.layer_forward(h, lw, geom, cos, sin, add_mask, past[i])
+        h = LR.rms_norm(h, c(sd["model.norm.weight"]), geom.rms_eps, geom.rms_cast)
+        last = h[:, -1]
+        lg = F.linear(last, c(sd["lm_head.weight"]))[0]
+        logits_all.append(lg)
+        hid_all.append(last[0])
+        tok = int(lg.argmax()) if forced is None else int(forced[step])
+        toks.append(tok)
+        x_ids = torch.tensor([[tok]])
+        print(f"    {dtype} step {step}: argmax {int(lg.argmax())} fed {tok}", flush=True)
+    return torch.stack(logits_all), torch.stack(hid_all), torch.tensor(toks)
+
+
+def make_llama():
+    t0 = time.time()
+    sd = synth.llama_state_dict(**LLAMA)
+    print(f"llama weights generated in {time.time() - t0:.0f}s", flush=True)
+    geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
+    for T in (64, 512):
+        g = torch.Generator().manual_seed(4242 + T)
+        ids = torch.randint(0, 128000, (1, T), generator=g)
+        t0 = time.time()
+        lb, hb, toks = llama_run(sd, geom, ids, torch.bfloat16)
+        print(f"  T={T} bf16 oracle {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        lf, hf, _ = llama_run(sd, geom, ids, torch.float32, forced=toks)
+        print(f"  T={T} fp32 truth {time.time() - t0:.0f}s", flush=True)
+        V = lb.shape[1]
+        cols = set(range(0, V, 61))
+        for s in range(NDEC + 1):
+            cols |= set(lf[s].topk(32).indices.tolist()) | set(lb[s].float().topk(32).indices.tolist())
+        cols = torch.tensor(sorted(cols))
+        top_f = lf.topk(8, dim=-1)
+        top_b = lb.float().topk(8, dim=-1)
+        err_full = torch.tensor([rel(lb[s].float(), lf[s]) for s in range(NDEC + 1)])
+        err_cols = torch.tensor([rel(lb[s, cols].float(), lf[s, cols]) for s in range(NDEC + 1)])
+        print(f"  T={T}: bf16-vs-fp32 logits err full {err_full.tolist()}\n         cols {err_cols.tolist()}")
+        print(f"         argmax agree {(lb.float().argmax(-1) == lf.argmax(-1)).tolist()} "
+              f"fp32 top-2 margin {(top_f.values[:, 0] - top_f.values[:, 1]).tolist()}")
+        save(f"f1_llama8b_T{T}", ids=ids.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
+             logits_bf16=lb[:, cols], logits_fp32=lf[:, cols], hidden_bf16=hb, hidden_fp32=hf,
+             norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
+             top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values,
+             top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
+
+
+@torch.no_grad()
+def make_esm():
+    esd = synth.esm_state_dict(**ESM)
+    shared = synth.mlp_layers(3, 1280, 1280, 2560, 20)
+    token = synth.mlp_layers(3, 1280, 4096, 2560, 0)
+    toks = synth.protein_tokens([1024], seed=77)
+    out = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        t0 = time.time()
+        sd = {k: v.to(dt) for k, v in esd.items()}
+        h = ER.esm_forward(sd, ER.EsmGeom(**ESM), toks)
+        z = PR.protein_pooler(h, torch.zeros(1, dtype=torch.int64), toks == 1, method="mean")
+        sh = PR.mlp_forward(z, [(w.to(dt), b.to(dt)) for w, b in shared])
+        tk = PR.mlp_forward(z, [(w.to(dt), b.to(dt)) for w, b in token])
+        out[name] = (h[0, [0, 1, 511, 1024, 1025]], z[0], sh[0], tk[0])
+        print(f"  esm {name}: {time.time() - t0:.0f}s", flush=True)
+    names = ("hidden_rows", "pooled", "shared", "soft_token")
+    for n, a, b in zip(names, out["bf16"], out["fp32"]):
+        print(f"  esm {n}: bf16-vs-fp32 {rel(a.float(), b):.3e}")
+    save("f2_esm650m_1024", tokens=toks.to(torch.int32), rows=torch.tensor([0, 1, 511, 1024, 1025], dtype=torch.int32),
+         **{f"{n}_bf16": a for n, a in zip(names, out["bf16"])}, **{f"{n}_fp32": b for n, b in zip(names, out["fp32"])})
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["esm", "llama"]
+    torch.set_num_threads(os.cpu_count())
+    if "esm" in what:
+        make_esm()
+    if "llama" in what:
+        make_llama()
