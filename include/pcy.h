@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 4
+#define PCY_ABI_VERSION 5
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -37,6 +37,10 @@ enum { PCY_EPI_STORE = 0, PCY_EPI_RESID = 1, PCY_EPI_GELU_ERF = 2, PCY_EPI_GELU_
 enum { PCY_POOL_MEAN = 0, PCY_POOL_MEAN_CORRECTED = 1, PCY_POOL_MAX = 2 };
 
 int pcy_abi_version(void);
+/* Test instrumentation: number of GEMM launches that went to kernel family `kind` since the library was loaded
+ * (0: 128x128 tiles, 1: 64x64, 2: 256x256, 3: 256x256 persistent (ESM fc1 + GELU), 4: split-K, 5: fp8 256x256).  Parity
+ * tests use it to assert that they reach the kernel they claim to test. */
+unsigned long long pcy_debug_dispatch_count(int kind);
 const char* pcy_last_error(void);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream */
 int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out);

@@ -235,7 +235,7 @@ def sampling_probs(logits, temperature=1.0, nucleus_prob=None):
 
 @torch.no_grad()
 def beam_search(text_encoder, input_embeds, attn_mask, *, vocab_size, eos_id, max_len=64,
-                beam_size=5, beam_group_size=5, diversity_penalty=0.8):
+                beam_size=5, beam_group_size=5, diversity_penalty=0.8, trace=None):
     """Diverse beam search of `_generate_beam_search`
     (/root/reference/procyon/model/model_unified.py:702-842).
 
@@ -249,6 +249,8 @@ def beam_search(text_encoder, input_embeds, attn_mask, *, vocab_size, eos_id, ma
     dtype + fp32 running score (:782); no finished-beam handling, stop only when every
     beam holds an EOS somewhere in its (zero-initialised) row (:833; Q4).
     Returns tokens [B,beam,max_len] int64, scores [B,beam] fp32, logits [B,beam,steps,V].
+    trace (test instrumentation, optional list): receives (step, b, group, top-(g+1) candidate scores) for every selection,
+    i.e. the margins that decide whether a second implementation may legitimately pick differently.
     """
     B = input_embeds.shape[0]
     BB = B * beam_size
@@ -284,6 +286,8 @@ def beam_search(text_encoder, input_embeds, attn_mask, *, vocab_size, eos_id, ma
                     prev = out[beam_start:gs, i]
                     lp -= diversity_penalty * torch.bincount(prev, minlength=vocab_size)
                 top_v, top_i = lp.ravel().topk(beam_group_size)
+                if trace is not None:
+                    trace.append((i, b, k, lp.ravel().float().topk(beam_group_size + 1).values.clone()))
                 sel = top_i % vocab_size
                 orig = (top_i // vocab_size) + gs
                 out[gs:ge] = out[orig]

@@ -10,6 +10,9 @@ LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
+ABI_VERSION = 5
+# pcy_debug_dispatch_count kinds
+DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8 = range(6)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -62,6 +65,7 @@ class BeamState(C.Structure):
 # name -> (restype, argtypes); every symbol include/pcy.h declares
 SIGNATURES = {
     "pcy_abi_version": (ci, []),
+    "pcy_debug_dispatch_count": (C.c_ulonglong, [ci]),
     "pcy_last_error": (C.c_char_p, []),
     "pcy_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "pcy_ctx_destroy": (None, [vp]),
@@ -114,7 +118,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.pcy_abi_version() != 4:
+    if lib.pcy_abi_version() != ABI_VERSION:
         raise PcyError("libpcy.so ABI version mismatch")
     _lib = lib
     return lib

@@ -557,7 +557,12 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
     const int unit = blockIdx.x;
     a.xepoch = *epoch_p;   // (a.xflags / a.xmin set by the launcher; the epoch lives in device memory: graph replay freezes arguments)
     a.xerr = err;
-    if (dbg != 3) attn_dec_body<DH, G, 16>(a, smem, unit % slices, (unit / slices) % a.Hkv, unit / (slices * a.Hkv));
+    // unit -> (column slice, kv head): workgroup b runs on XCD b % 8, so with the kv head in the LOW digits the DH/16 slices of one
+    // kv head share an XCD -- and its L2: the head's K panel and V rows leave HBM once instead of once per slice
+    if (dbg != 3) {
+      if (a.unit_map) attn_dec_body<DH, G, 16>(a, smem, (unit / a.Hkv) % slices, unit % a.Hkv, unit / (slices * a.Hkv));
+      else attn_dec_body<DH, G, 16>(a, smem, unit % slices, (unit / slices) % a.Hkv, unit / (slices * a.Hkv));
+    }
     // every wave: its (agent-scope, written-through) output stores have left; then the workgroup's flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -650,6 +655,7 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   const int xmin = xe ? atoi(xe) : 768;
   a.xflags = (xmin > 0 && a.scratch) ? xflags : nullptr;
   a.xmin = xmin;
+  { const char* me = getenv("PCY_AO_MAP"); a.unit_map = me ? atoi(me) : 1; }
   // timing experiments (results invalid): 1 = no wait for the attention, 2 = attention workgroups only, 3 = no attention
   static const int dbg = [] { const char* e = getenv("PCY_AO_DBG"); return e ? atoi(e) : 0; }();
   // The attention issues all of its cache reads (<= 1024 keys) in its first microsecond; 33.5 MB of weight reads queued at

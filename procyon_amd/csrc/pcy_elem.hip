@@ -128,8 +128,10 @@ __global__ __launch_bounds__(NT) void layernorm_wave_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------ embedding lookup + soft-token splice (A5)
 __global__ __launch_bounds__(NT) void embed_gather_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
                                                           const bf16_t* __restrict__ soft, const int32_t* __restrict__ soft_map,
-                                                          bf16_t* __restrict__ out, int d) {
+                                                          bf16_t* __restrict__ out, int d, unsigned* __restrict__ epoch) {
   const int r = blockIdx.x;
+  // first launch of a decode step: also advances the epoch word of the step's in-launch hand-overs (was a launch of its own)
+  if (epoch && r == 0 && threadIdx.x == 0) *epoch += 1;
   const int sm = soft_map ? soft_map[r] : -1;
   const bf16_t* src = sm >= 0 ? soft + (size_t)sm * d : table + (size_t)ids[r] * d;
   for (int k = threadIdx.x * 8; k < d; k += NT * 8)
@@ -402,32 +404,36 @@ __global__ __launch_bounds__(PICK_NT) void pick_stage1_kernel(const bf16_t* __re
   if (threadIdx.x == 0) part[b * PICK_NB + c] = PickPartial{best, bi, (lo < hi) ? se : 0.f, 0};
 }
 
-__global__ __launch_bounds__(64) void pick_stage2_kernel(const bf16_t* __restrict__ logits, int V, const PickPartial* __restrict__ part,
-                                                         int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, int max_steps,
-                                                         float* __restrict__ logprob, const int32_t* __restrict__ step_dev) {
-  const int b = blockIdx.x, l = threadIdx.x;
-  const PickPartial pp = part[b * PICK_NB + l];
-  float best = pp.mx;
-  int bi = pp.idx;
+// one workgroup for all rows (wave w takes rows w, w + 4, ...), so that the step / position counters can be advanced by the
+// same launch once every row has read them (was a launch of its own)
+__global__ __launch_bounds__(256) void pick_stage2_kernel(const bf16_t* __restrict__ logits, int V, const PickPartial* __restrict__ part,
+                                                          int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, int max_steps,
+                                                          float* __restrict__ logprob, int32_t* __restrict__ step_dev, int32_t* __restrict__ pos_dev,
+                                                          int advance_pos, int B) {
+  const int l = threadIdx.x & 63;
+  const int step = *step_dev;
+  for (int b = threadIdx.x >> 6; b < B; b += 4) {
+    const PickPartial pp = part[b * PICK_NB + l];
+    float best = pp.mx;
+    int bi = pp.idx;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    float se = pp.se * expf(pp.mx - best);   // empty chunks: mx = -inf -> exp(-inf) = 0
+    se = wave_sum(se);
+    if (l == 0) {
+      // log_softmax in model dtype: bf16( x - max - log(sum exp(x - max)) ), x[tok] == max
+      const float lsm = rbf((bf2f(logits[(size_t)b * V + bi]) - best) - logf(se));
+      logprob[b] += lsm;
+      next_tok[b] = bi;
+      tokens_out[(size_t)b * max_steps + step] = bi;
+    }
   }
-  float se = pp.se * expf(pp.mx - best);   // empty chunks: mx = -inf -> exp(-inf) = 0
-  se = wave_sum(se);
-  if (l == 0) {
-    const int step = *step_dev;
-    // log_softmax in model dtype: bf16( x - max - log(sum exp(x - max)) ), x[tok] == max
-    const float lsm = rbf((bf2f(logits[(size_t)b * V + bi]) - best) - logf(se));
-    logprob[b] += lsm;
-    next_tok[b] = bi;
-    tokens_out[(size_t)b * max_steps + step] = bi;
-  }
-}
-__global__ void advance_kernel(int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
-  if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev += 1; }
+  __syncthreads();
+  if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev = step + 1; }
 }
 
 // ------------------------------------------------------------------ F.normalize(x, dim=-1) on a bf16 tensor
@@ -853,10 +859,10 @@ void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const
 }
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
-  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d);
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr);
 }
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d) {
-  pcy_launch_embed_gather(s, table, ids, nullptr, nullptr, out, rows, d);
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch) {
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch);
 }
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads) {
@@ -891,9 +897,8 @@ void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, 
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
                             int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials) {
   hipLaunchKernelGGL(pick_stage1_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, reinterpret_cast<PickPartial*>(partials));
-  hipLaunchKernelGGL(pick_stage2_kernel, dim3(B), dim3(64), 0, s, logits, V, reinterpret_cast<const PickPartial*>(partials), next_tok,
-                     tokens_out, max_steps, logprob, step_dev);
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev, advance_pos);
+  hipLaunchKernelGGL(pick_stage2_kernel, dim3(1), dim3(256), 0, s, logits, V, reinterpret_cast<const PickPartial*>(partials), next_tok,
+                     tokens_out, max_steps, logprob, step_dev, pos_dev, advance_pos, B);
 }
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {
   if (nrows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, dst, ldd, rows, d);

@@ -40,23 +40,17 @@ struct pcy_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // captured decode step
   hipGraphExec_t graph = nullptr;
-  const void* graph_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  const void* graph_key2[4] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int GRAPH_KEY_N = 16;
+  const void* graph_key[GRAPH_KEY_N] = {};
   int graph_B = 0;
-  int graph_fused = 0;
+  int graph_mode = 0;
   int graph_kind = 0;                 // 0: decode + greedy pick (pcy_llama_greedy), 1: decode only (pcy_llama_decode_graph)
-  // persistent decode kernel: device copy of the per-layer weight pointers + progress flags
-  PcyFusedLayer* fused_tab = nullptr;
-  unsigned* fused_xch = nullptr;      // exchange storage: flags + tagged vectors + act (zeroed before every launch)
-  size_t fused_xch_words = 0;
-  unsigned* fused_err = nullptr;      // sticky error word
-  const void* fused_key[2] = {nullptr, nullptr};
-  int fused_L = 0;
   int n_cu = 0;
+  unsigned* xwg_err = nullptr;        // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
-  unsigned long long* fused_trace = nullptr;   // PCY_FUSED_TRACE=<file>: wall-clock stamps of the last decode step
-  int fused_trace_n = 0;
+  char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
+  size_t beam_ws_bytes = 0;
 
   int reserve(size_t bytes) {
     if (bytes <= ws_bytes) return 0;
@@ -114,105 +108,30 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
 // ------------------------------------------------------------------ decode step (enqueue only)
 struct DecodeWs { bf16_t *x, *qkv, *ao, *act; };
 
-// PCY_DECODE_FUSED=1 selects the persistent decode kernel (pcy_decode.hip) for batch 1.  Off by default: on MI355X it
-// measures 3.41 ms/token against 3.38 for the layer-by-layer launches ("persistent decode kernel").
-// Read on every call so that one process can compare both paths.
-bool fused_enabled() {
-  const char* e = getenv("PCY_DECODE_FUSED");
-  return e && atoi(e) != 0;
-}
-
-bool fused_geometry(pcy_ctx* c, const pcy_llama_desc* m, int B, int Tmax, PcyFusedDecArgs& f) {
-  f = PcyFusedDecArgs{};
-  f.L = m->n_layers; f.vocab = m->vocab;
-  f.B = B; f.d = m->d; f.H = m->n_heads; f.Hkv = m->n_kv_heads; f.dh = m->head_dim; f.F = m->ffn; f.Tmax = Tmax;
-  const int units = B * m->n_kv_heads * (m->head_dim / 16);
-  f.n_attn = units < 64 ? units : 64;
-  f.n_stream = (c->n_cu < 256 ? c->n_cu : 256) - f.n_attn;
-  return c->n_cu >= 128 && pcy_fused_decode_supported(f);
-}
-
-bool fused_args(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B,
-                const bf16_t* x, PcyFusedDecArgs& f) {
-  if (!fused_enabled() || B != 1 || !c->fused_tab || !c->fused_xch) return false;
-  if (!fused_geometry(c, m, B, kv->Tmax, f)) return false;
-  if (pcy_fused_decode_words(f) > c->fused_xch_words) return false;
-  f.layers = c->fused_tab;
-  f.lm_head = (const bf16_t*)m->lm_head; f.final_norm = (const bf16_t*)m->final_norm; f.logits = (bf16_t*)st->logits;
-  f.x = x;
-  unsigned* w = c->fused_xch;
-  f.flags = w; w += 2 * PCY_FUSED_NFLAGS;
-  bf16_t* v = reinterpret_cast<bf16_t*>(w);
-  f.xres = v; v += f.d;
-  f.qkv = v; v += (size_t)(f.H + 2 * f.Hkv) * f.dh;
-  f.ao = v; v += f.d;
-  f.act = v;
-  f.err = c->fused_err;
-  f.kcache = (bf16_t*)kv->k; f.vcache = (bf16_t*)kv->v;
-  f.layer_stride = (size_t)kv->B * m->n_kv_heads * kv->Tmax * m->head_dim;
-  f.pos_dev = st->pos; f.cos_t = (const bf16_t*)m->rope_cos; f.sin_t = (const bf16_t*)m->rope_sin;
-  f.keep = st->keep; f.ld_keep = kv->Tmax;
-  f.rms_eps = m->rms_eps; f.rms_cast = m->rms_cast; f.scale = 1.0f / sqrtf((float)m->head_dim);
-  f.trace = c->fused_trace;
-  { static const int nw = [] { const char* e = getenv("PCY_FUSED_NOWAIT"); return e ? atoi(e) : 0; }(); f.nowait = nw; }
-  return true;
-}
-
 // PCY_ATTN_O=0 switches the fused attention + o-projection launch of the layered decode step off (default on; batch 1,
 // head_dim 128, d = 4096): 3.35 -> 3.28 ms/token.  Read on every call like PCY_DECODE_FUSED.
 bool attn_o_enabled() {
   const char* e = getenv("PCY_ATTN_O");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return (fused_enabled() ? 1 : 0) | (attn_o_enabled() ? 2 : 0); }
+int decode_mode() { return attn_o_enabled() ? 2 : 0; }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
-__global__ void bump_epoch_kernel(unsigned* epoch) { *epoch += 1; }
 
-// device table of the per-layer weight pointers; must run outside stream capture
-int ensure_fused(pcy_ctx* c, const pcy_llama_desc* m) {
+// device words of the in-launch hand-overs; must run outside stream capture
+int ensure_decode_state(pcy_ctx* c) {
   if (!c->n_cu) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->n_cu = prop.multiProcessorCount;
   }
-  if (!c->fused_err) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_err), 64));
-    HIP_TRY(hipMemset(c->fused_err, 0, 64));
+  if (!c->xwg_err) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->xwg_err), 64));
+    HIP_TRY(hipMemset(c->xwg_err, 0, 64));
   }
   if (!c->ao_sync) {
     const size_t bytes = (size_t)(64 + 2 * AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);   // epoch, attention->o flags, score-exchange flags
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ao_sync), bytes));
     HIP_TRY(hipMemset(c->ao_sync, 0, bytes));
-  }
-  if (!fused_enabled()) return 0;
-  {
-    PcyFusedDecArgs f;
-    if (fused_geometry(c, m, 1, 1, f) && pcy_fused_decode_words(f) > c->fused_xch_words) {
-      if (c->fused_xch) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->fused_xch)); c->fused_xch = nullptr; }
-      c->drop_graph();
-      c->fused_xch_words = pcy_fused_decode_words(f);
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_xch), c->fused_xch_words * sizeof(unsigned)));
-    }
-  }
-  const void* key[2] = {m, m->n_layers ? m->layers[0].wqkv : nullptr};
-  if (c->fused_tab && c->fused_L == m->n_layers && memcmp(key, c->fused_key, sizeof(key)) == 0) return 0;
-  if (c->fused_tab) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->fused_tab)); c->fused_tab = nullptr; }
-  c->drop_graph();
-  std::vector<PcyFusedLayer> tab(m->n_layers);
-  for (int l = 0; l < m->n_layers; ++l) {
-    const pcy_llama_layer& L = m->layers[l];
-    tab[l] = PcyFusedLayer{(const bf16_t*)L.wqkv, (const bf16_t*)L.wo, (const bf16_t*)L.wgu, (const bf16_t*)L.wdown,
-                           (const bf16_t*)L.ln1, (const bf16_t*)L.ln2};
-  }
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_tab), tab.size() * sizeof(PcyFusedLayer) + 64));
-  HIP_TRY(hipMemcpy(c->fused_tab, tab.data(), tab.size() * sizeof(PcyFusedLayer), hipMemcpyHostToDevice));
-  memcpy(c->fused_key, key, sizeof(key));
-  c->fused_L = m->n_layers;
-  if (getenv("PCY_FUSED_TRACE")) {
-    if (c->fused_trace) HIP_TRY(hipFree(c->fused_trace));
-    c->fused_trace_n = 256 * ((4 * m->n_layers + 1) * 4 + m->n_layers * 2);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fused_trace), c->fused_trace_n * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->fused_trace, 0, c->fused_trace_n * sizeof(unsigned long long)));
   }
   return 0;
 }
@@ -240,18 +159,10 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   const size_t sk_bytes = B > 4 ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   const bool batched = B > 4 && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
-  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d);
-  PcyFusedDecArgs fa;
-  if (fused_args(c, m, kv, st, B, x, fa)) {
-    // one persistent launch for the whole step (pcy_decode.hip)
-    (void)hipMemsetAsync(c->fused_xch, 0, 2 * PCY_FUSED_NFLAGS * sizeof(unsigned), s);
-    pcy_launch_decode_fused(s, fa);
-    return;
-  }
+  const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
+  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
-  const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->fused_err && m->n_layers <= AO_MAX_LAYERS;
-  if (try_ao) hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, s, c->ao_sync);
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
     PcyGemvArgs g{};
@@ -275,7 +186,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
-    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->fused_err,
+    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
                                        c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
       pcy_launch_attn_decode(s, t);
       pcy_launch_gemv(s, o);
@@ -375,6 +286,7 @@ __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict_
 extern "C" {
 
 int pcy_abi_version(void) { return PCY_ABI_VERSION; }
+unsigned long long pcy_debug_dispatch_count(int kind) { return (kind >= 0 && kind < PCY_DISPATCH_N) ? g_pcy_dispatch[kind] : 0; }
 const char* pcy_last_error(void) { return g_err; }
 
 int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out) {
@@ -397,11 +309,9 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   hipStreamSynchronize(c->stream);
   c->drop_graph();
   if (c->ws) hipFree(c->ws);
-  if (c->fused_tab) hipFree(c->fused_tab);
-  if (c->fused_xch) hipFree(c->fused_xch);
-  if (c->fused_err) hipFree(c->fused_err);
+  if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
-  if (c->fused_trace) hipFree(c->fused_trace);
+  if (c->beam_ws) hipFree(c->beam_ws);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
@@ -409,19 +319,11 @@ void pcy_ctx_destroy(pcy_ctx* c) {
 }
 int pcy_ctx_sync(pcy_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->fused_trace) {
-    std::vector<unsigned long long> t(c->fused_trace_n);
-    HIP_TRY(hipMemcpy(t.data(), c->fused_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (FILE* fp = fopen(getenv("PCY_FUSED_TRACE"), "w")) {
-      for (size_t i = 0; i < t.size(); ++i) fprintf(fp, "%llu\n", t[i]);
-      fclose(fp);
-    }
-  }
-  if (c->fused_err) {
+  if (c->xwg_err) {
     unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, c->fused_err, sizeof(err), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&err, c->xwg_err, sizeof(err), hipMemcpyDeviceToHost));
     if (err) {
-      HIP_TRY(hipMemset(c->fused_err, 0, sizeof(err)));
+      HIP_TRY(hipMemset(c->xwg_err, 0, sizeof(err)));
       return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (results invalid)");
     }
   }
@@ -734,7 +636,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_fused(c, m)) return r;
+  if (int r = ensure_decode_state(c)) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
@@ -748,13 +650,15 @@ int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
 namespace {
 // capture (once per model / cache / state / batch) and replay the decode step; kind 0 = decode + greedy pick, 1 = decode only
 int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps, int kind) {
-  const void* key[6] = {m, kv->k, st->pos, st->logits, c->ws, st->tokens_out};
-  // everything a captured kernel argument was derived from: pointers AND the cache geometry (an allocator may hand a cache of a
-  // different capacity the address of the previous one)
-  const void* key2[4] = {st->logits_all, (const void*)(intptr_t)st->logits_all_ld, (const void*)(intptr_t)kv->Tmax,
-                         (const void*)(intptr_t)((kv->B << 8) ^ st->max_steps)};
-  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || memcmp(key2, c->graph_key2, sizeof(key2)) != 0 ||
-      c->graph_B != B || c->graph_fused != decode_mode() || c->graph_kind != kind) {
+  // EVERYTHING a captured kernel argument was derived from: every pointer of the state / cache / model the enqueue functions
+  // read, AND the geometry (an allocator may hand a new state or a cache of another capacity the addresses of the previous one
+  // while e.g. the `keep` mask or the token buffer differ -- a stale graph would then run with dangling arguments)
+  const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, st->tokens_out, st->logprob,
+                                           st->logits, st->logits_all, st->keep, c->ws,
+                                           (const void*)(intptr_t)(((int64_t)st->logits_all_ld << 32) ^ kv->Tmax),
+                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ st->max_steps)};
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 ||
+      c->graph_B != B || c->graph_mode != decode_mode() || c->graph_kind != kind) {
     c->drop_graph();
     hipGraph_t g = nullptr;
     hipStream_t user = c->stream;
@@ -770,9 +674,8 @@ int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache*
     HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
     hipGraphDestroy(g);
     memcpy(c->graph_key, key, sizeof(key));
-    memcpy(c->graph_key2, key2, sizeof(key2));
     c->graph_B = B;
-    c->graph_fused = decode_mode();
+    c->graph_mode = decode_mode();
     c->graph_kind = kind;
   }
   for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
@@ -784,7 +687,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
                      int use_graph) {
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_fused(c, m)) return r;
+  if (int r = ensure_decode_state(c)) return r;
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       enqueue_decode(c, m, kv, st, B);
@@ -798,7 +701,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
 int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode_graph: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_fused(c, m)) return r;
+  if (int r = ensure_decode_state(c)) return r;
   return replay_decode_graph(c, m, kv, st, B, 1, 1);
 }
 
@@ -811,10 +714,15 @@ int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, in
   b.out = st->out; b.max_len = st->max_len; b.cur = st->cur; b.cur_new = st->cur_new; b.next_tok = st->next_tok; b.src = st->src;
   b.anc = st->anc; b.has_eos = st->has_eos; b.blk_eos = st->blk_eos; b.ticket = st->ticket; b.pos = st->pos; b.step = st->step;
   b.done = st->done; b.eos_id = st->eos_id;
-  // the partials live at the very end of the workspace the decode step was sized for (its last 4 KiB are slack), so that this
-  // call never re-allocates the workspace a captured decode graph points into
-  if (c->ws_bytes < pcy_beam_ws_bytes(B, beam) + 4096 && c->reserve(pcy_beam_ws_bytes(B, beam) + 4096)) return 2;
-  void* ws = c->ws + c->ws_bytes - align_up(pcy_beam_ws_bytes(B, beam), 256);
+  // row-statistics partials in an allocation of their own: never inside the decode workspace (a captured decode graph points
+  // into that one, and its tail belongs to the KV-reorder scratch)
+  const size_t need = align_up(pcy_beam_ws_bytes(B, beam), 256);
+  if (need > c->beam_ws_bytes) {
+    if (c->beam_ws) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->beam_ws)); c->beam_ws = nullptr; c->beam_ws_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->beam_ws), need * 2));
+    c->beam_ws_bytes = need * 2;
+  }
+  void* ws = c->beam_ws;
   pcy_launch_beam_step(c->stream, (const bf16_t*)logits, vocab, B, beam, group_size, diversity_penalty, b, ws);
   return check_launch("pcy_beam_step");
 }

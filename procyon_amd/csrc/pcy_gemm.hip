@@ -787,80 +787,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   }   // tile loop
 }
 
-// ------------------------------------------------------------------------------------------------
-// Large-M variant, 8-wave PING-PONG: same 256 x 256 tile / BK = 32 / four LDS stages, but the two waves of every SIMD
-// run half a step out of phase.  Every wave alternates  R: 12 x ds_read_b128 (its fragments of one 32-k step)  and
-// M: 32 x MFMA, with a workgroup barrier after each; waves 4-7 start with one extra barrier, so in every interval one
-// wave of each SIMD feeds the matrix core while the other one reads LDS.  In lockstep (gemm_kernel_big) all eight waves
-// read LDS together (768 clk of LDS pipe per 32-k step) and then all issue MFMAs (1024 clk): 1186 TFLOP/s at 4096^3.
-// Stage kt+3 is requested at the start of R(kt): its buffer was last read two intervals earlier, and it is first read
-// six intervals (~1.3 us) later; `s_waitcnt vmcnt(8)` before every barrier keeps exactly the two youngest stages in flight.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_kernel_pp(PcyGemmArgs a) {
-  constexpr int BK = 32, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8, NS = 4;
-  constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 16 KiB each
-  extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
-  char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int grp = wave >> 2;   // waves 0-3 / 4-7 land on SIMDs 0-3 each: one wave of each group per SIMD
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  int m0, n0;
-  tile_origin<TBM, TBN>(a, tile, m0, n0);
-  f32x4 acc[WTN][WTM];
-#pragma unroll
-  for (int i = 0; i < WTN; ++i)
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nk = a.K / BK;
-  const int fr = lane & 15, fq = lane >> 4;
-  auto stage = [&](int kt) {   // 2 + 2 one-KiB DMA instructions per wave
-    char* buf = smem + (kt % NS) * (TILE_A + TILE_W);
-    stage_tile<BK, TBM, NW>(a.A, a.lda, m0, a.M, kt * BK, buf, wave, lane);
-    stage_tile<BK, TBN, NW>(a.W, a.K, n0, a.N, kt * BK, buf + TILE_A, wave, lane);
-  };
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  // stage 0 complete for everybody (stages 1, 2 may stay in flight)
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();   // half a step behind group 0
-  for (int kt = 0; kt < nk; ++kt) {
-    // ---- R(kt)
-    if (kt + 3 < nk && a.dbg != 1) stage(kt + 3);
-    const char* Acur = smem + (kt % NS) * (TILE_A + TILE_W);
-    const char* Wcur = Acur + TILE_A;
-    bf16x8 xf[WTM], wf[WTN];
-    if (a.dbg != 2 || kt == 0) {
-#pragma unroll
-      for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq);
-#pragma unroll
-      for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq);
-    }
-    // the fragments are in registers (their buffer may be refilled two intervals from now) and the stage needed next
-    // has landed: the two youngest stages may stay in flight
-    if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- M(kt)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < WTN; ++i)
-#pragma unroll
-      for (int j = 0; j < WTM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();   // every wave passes the same number of barriers
-  gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
-}
+}  // namespace
+// which kernel a launch went to (test instrumentation behind pcy_debug_dispatch_count: parity tests assert that they reach the
+// kernel they claim to test)
+unsigned long long g_pcy_dispatch[PCY_DISPATCH_N] = {};
+namespace {
 
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
@@ -876,6 +807,7 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     configured = true;
   }
+  ++g_pcy_dispatch[PCY_DISPATCH_GEMM_FP8];
   hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
@@ -885,8 +817,7 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  static const int bk = [] { const char* e = getenv("PCY_GEMM_BK"); return e ? atoi(e) : 64; }();
-  static const int big_min_m = [] { const char* e = getenv("PCY_GEMM_BIG_M"); return e ? atoi(e) : 2048; }();
+  constexpr int big_min_m = 2048;
   // 256x256 tiles pay off where the mainloop dominates (measured, M = 32832: qkv 734 -> 804, fc2 827 -> 911 TFLOP/s);
   // for N = K = 1280 they do not; the ESM GELU epilogue is a wash since the rational erf (fc1 679 vs 700)
   // Below big_min_m rows the choice follows how well each tiling fills the chip: 128x128 tiles run two per CU (512 slots),
@@ -909,16 +840,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
     long gnb = (5L << 19) / ((long)256 * a.K * 2);
     if (gnb < 2) gnb = 2;
     b.gn = (int)(gnb > tn ? tn : gnb);
-    // PCY_GEMM_BIGV=3: the ping-pong schedule (experiment, 6 % slower at 4096^3)
-    static const int bigv = [] { const char* e = getenv("PCY_GEMM_BIGV"); return e ? atoi(e) : 1; }();
-    if (bigv == 3 && a.K % 32 == 0) {
-      static bool configured3 = false;
-      if (!configured3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_pp<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        configured3 = true;
-      }
-      hipLaunchKernelGGL((gemm_kernel_pp<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
-    } else {
+    {
       static bool configured = false;
       if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -930,8 +852,10 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           configured_p = true;
         }
+        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
         hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
       } else {
+        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
         hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
       }
     }
@@ -939,19 +863,20 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
   }
   // fewer than 192 tiles of 128 x 128 (of 512 slots): 64 x 64 tiles -- four times the workgroups, same arithmetic per element
   if constexpr (EPI != EPI_SWIGLU) {
-    if (tiles < 192 && a.rope_cos == nullptr && bk == 64) {
+    if (tiles < 192 && a.rope_cos == nullptr) {
       const int tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
       PcyGemmArgs b = a;
       const int tn64 = (a.N + 63) / 64;
       long g64 = (5L << 19) / ((long)64 * a.K * 2);
       if (g64 < 4) g64 = 4;
       b.gn = (int)(g64 > tn64 ? tn64 : g64);
+      ++g_pcy_dispatch[PCY_DISPATCH_GEMM_64];
       hipLaunchKernelGGL((gemm_kernel_small<EPI>), dim3(tiles64), dim3(GEMM_THREADS), 0, s, b);
       return;
     }
   }
-  if (bk == 32) hipLaunchKernelGGL((gemm_kernel<EPI, 32>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
+  ++g_pcy_dispatch[PCY_DISPATCH_GEMM_128];
+  hipLaunchKernelGGL((gemm_kernel<EPI, 64>), dim3(tiles), dim3(GEMM_THREADS), 0, s, a);
 }
 
 }  // namespace
@@ -963,10 +888,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   const long panel = (long)BN * a.K * 2;
   long gn = (5L << 19) / panel;           // 2.5 MiB of W panels per group
   if (gn < 4) gn = 4;                      // long-K panels: a narrower group loses more A reuse than it saves (measured)
-  static const int gn_env = [] { const char* e = getenv("PCY_GEMM_GN"); return e ? atoi(e) : 0; }();
-  if (gn_env > 0) gn = gn_env;
   a.gn = (int)(gn < 1 ? 1 : (gn > tiles_n ? tiles_n : gn));
-  { static const int dbg = [] { const char* e = getenv("PCY_GEMM_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   if (a.fp8) {   // e4m3 operands: the 256 x 256 kernel for every M (callers check K % 128, lda % 16)
     switch (a.epi) {
       case EPI_RESID: launch_fp8<EPI_RESID>(s, a); break;
@@ -986,6 +908,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     int splits = 1;
     while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
     if (splits > 1 && (size_t)splits * a.M * a.N * 4 <= a.splitk_ws_bytes) {
+      ++g_pcy_dispatch[PCY_DISPATCH_GEMM_SPLITK];
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
       if (a.epi == EPI_RESID) hipLaunchKernelGGL(gemm_splitk_epilogue<EPI_RESID>, dim3(eb < 2048 ? eb : 2048), dim3(256), 0, s, a, splits);

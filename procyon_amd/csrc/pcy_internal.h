@@ -36,12 +36,15 @@ struct PcyGemmArgs {
   const int32_t* rope_pos; const bf16_t* rope_cos; const bf16_t* rope_sin; int rope_ncols, rope_qcols, rope_mode; float rope_scale;
   // optional split-K workspace (fp32 [splits][M][N]); the launcher splits K when the tile count under-fills the chip
   float* splitk_ws; size_t splitk_ws_bytes;
-  int dbg;              // timing experiments only (PCY_GEMM_DBG): 1 = no global->LDS loads after the prologue, 2 = no LDS fragment reads
   // fp8 path (BASELINE configs[4]): A and W point to OCP e4m3 bytes ([M,K] lda bytes / [N,K]), K % 128 == 0;
   // C = epi( bf16-rounding chain of ((acc * sa[m]) * sw[n]) ), sa / sw = per-token / per-output-row dequantisation scales
   int fp8; const float* sa; const float* sw;
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
+// launch counters per kernel family (pcy_debug_dispatch_count)
+enum { PCY_DISPATCH_GEMM_128 = 0, PCY_DISPATCH_GEMM_64 = 1, PCY_DISPATCH_GEMM_BIG = 2, PCY_DISPATCH_GEMM_BIG_PERSIST = 3,
+       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_N = 8 };
+extern unsigned long long g_pcy_dispatch[PCY_DISPATCH_N];
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)
 void pcy_launch_quant_rows_fp8(hipStream_t s, const bf16_t* x, int ldx, int rows, int K, unsigned char* q, float* scale);
@@ -53,7 +56,8 @@ void pcy_launch_rmsnorm(hipStream_t s, const bf16_t* x, const bf16_t* w, bf16_t*
 void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int d, float eps);
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d);
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d);
+// epoch (optional): device word incremented by the launch (decode step: epoch of the in-launch hand-overs)
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch = nullptr);
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads);
 // rope on heads [0,nh) located at column col0 of a token-major buffer; pos[tok] = rotary position.
@@ -95,6 +99,7 @@ struct PcyDecAttnArgs {
   // keys): flags [B*Hkv*DH/DS] for THIS launch, epoch value of this decode step, minimum cache length, watchdog word;
   // `scratch` ([B*H*(Tmax+1)] fp32) carries the exchanged scores
   unsigned* xflags; unsigned xepoch; int xmin; unsigned* xerr;
+  int unit_map;                   // fused launch: 1 = kv head in the low digits of the workgroup index (slices of a head share an XCD)
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;
@@ -134,26 +139,3 @@ void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows,
 // acc[r][:] (fp32) = / += src[rows[r]][:]; out = bf16(acc)
 void pcy_launch_acc_rows(hipStream_t s, const bf16_t* src, int lds, const int32_t* rows, float* acc, int nrows, int d, int first);
 void pcy_launch_acc_finish(hipStream_t s, const float* acc, bf16_t* out, size_t n);
-
-// ---- persistent decode-step kernel (pcy_decode.hip), batch 1 ----
-struct PcyFusedLayer { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };   // wgu: gate/up interleaved by 16 rows
-constexpr int PCY_FUSED_NFLAGS = 256;   // progress flags of the streaming workgroups
-struct PcyFusedDecArgs {
-  const PcyFusedLayer* layers; int L;       // device table [L]
-  const bf16_t* lm_head; const bf16_t* final_norm; bf16_t* logits; int vocab;
-  const bf16_t* x;                          // [d] embedded token (written by the previous launch)
-  // vectors exchanged between workgroups inside the launch (agent-scope stores / loads, guarded by `flags`)
-  bf16_t *xres, *qkv, *ao, *act;            // residual stream [d], projections [(H+2Hkv)dh], attention output [H dh], [F]
-  bf16_t *kcache, *vcache; size_t layer_stride;   // layer l at + l*layer_stride, [B,Hkv,Tmax,dh]
-  const int32_t* pos_dev; const bf16_t *cos_t, *sin_t; const uint8_t* keep; int ld_keep;
-  unsigned* flags;                          // [2 * PCY_FUSED_NFLAGS] streaming, then attention workgroups; zero before every launch
-  unsigned* err;                            // sticky: != 0 after a dependency wait timed out (results invalid)
-  int B, d, H, Hkv, dh, F, Tmax; float rms_eps; int rms_cast; float scale;
-  int n_stream, n_attn;                     // workgroup roles; grid = n_stream + n_attn <= CU count
-  int nowait;                               // debug: skip every cross-workgroup wait (timing of the pure stream; results invalid)
-  unsigned long long* trace;                // optional [(4L+1)*4 + L*2] wall-clock stamps of workgroup 0 / attention wg 0
-};
-bool pcy_fused_decode_supported(const PcyFusedDecArgs& a);
-// 32-bit words of exchange storage (flags, then the exchanged vectors); the flags are zeroed before every launch
-size_t pcy_fused_decode_words(const PcyFusedDecArgs& a);
-void pcy_launch_decode_fused(hipStream_t s, const PcyFusedDecArgs& a);

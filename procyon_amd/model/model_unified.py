@@ -318,7 +318,6 @@ class UnifiedProCyon:
         return out
 
     # ------------------------------------------------------------------------------------------
-    @torch.no_grad()
     @staticmethod
     def from_pretrained(**kw):
         """`UnifiedProCyon.from_pretrained` (model_unified.py:1296-1394); see procyon_amd.checkpoint.from_pretrained."""
@@ -350,6 +349,15 @@ class UnifiedProCyon:
         mask[keep_idxs[0], indices[keep_idxs]] = 1
         return mask
 
+    def _sampling_probs(self, logits, temperature=1.0, nucleus_prob=None):
+        """Pre-sampling probability vector of `_generate_sampling` (model_unified.py:899-903): nucleus -> softmax(logits)
+        times the un-renormalised nucleus mask; otherwise softmax(logits / temperature).  In the logits' dtype, like the
+        reference."""
+        if nucleus_prob is not None:
+            probs = logits.softmax(dim=-1)
+            return probs * self._get_nucleus_mask(probs, nucleus_prob)
+        return (logits / temperature).softmax(dim=-1)
+
     @torch.no_grad()
     def _generate_sampling(self, input_embeds, attn_masks, max_len=64, num_text_per_instance=1, temperature=1.0,
                            greedy=False, nucleus_prob=None):
@@ -373,26 +381,25 @@ class UnifiedProCyon:
             total = torch.zeros(B, device=self.device)
             enc = self.text_encoder
             keep_new = enc.max_new_tokens
-            enc.max_new_tokens = max(keep_new, max_len)
-            for i in range(max_len):
-                if i == 0:
-                    o = enc(input_embeds=input_embeds, attn_masks=attn_masks, use_cache=True,
-                            logit_positions=torch.full((B,), input_embeds.shape[1] - 1), want_hidden=False)
-                else:
-                    o = enc(input_ids=out[:, -1:], use_cache=True, past_key_values=past)
-                past = o.past_key_values
-                logits = o.logits[:, -1, :]
-                logits_all.append(logits.clone())
-                log_probs = torch.log_softmax(logits, dim=-1)
-                if nucleus_prob is not None:
-                    probs = logits.softmax(dim=-1)
-                    probs *= self._get_nucleus_mask(probs, nucleus_prob)
-                else:
-                    probs = (logits / temperature).softmax(dim=-1)
-                nxt = torch.multinomial(probs.float(), 1)
-                total += log_probs[torch.arange(B, device=logits.device), nxt.squeeze(-1)].float()
-                out = nxt if out is None else torch.cat([out, nxt], dim=-1)
-            enc.max_new_tokens = keep_new
+            enc.max_new_tokens = max(keep_new, max_len)       # KV capacity of this call; restored whatever happens below
+            try:
+                for i in range(max_len):
+                    if i == 0:
+                        o = enc(input_embeds=input_embeds, attn_masks=attn_masks, use_cache=True,
+                                logit_positions=torch.full((B,), input_embeds.shape[1] - 1), want_hidden=False)
+                    else:
+                        o = enc(input_ids=out[:, -1:], use_cache=True, past_key_values=past)
+                    past = o.past_key_values
+                    logits = o.logits[:, -1, :]
+                    logits_all.append(logits.clone())
+                    log_probs = torch.log_softmax(logits, dim=-1)
+                    probs = self._sampling_probs(logits, temperature, nucleus_prob)
+                    # the reference draws on the probabilities in model dtype (model_unified.py:901,905)
+                    nxt = torch.multinomial(probs, 1)
+                    total += log_probs[torch.arange(B, device=logits.device), nxt.squeeze(-1)].float()
+                    out = nxt if out is None else torch.cat([out, nxt], dim=-1)
+            finally:
+                enc.max_new_tokens = keep_new
             out_list.append(out.cpu())
             lp_list.append(total.cpu())
             logit_list.append(torch.stack(logits_all, 1).cpu())
@@ -426,6 +433,16 @@ class UnifiedProCyon:
         T = emb_rep.shape[1]
         keep_new = enc.max_new_tokens
         enc.max_new_tokens = max(keep_new, max_len)
+        try:
+            return self._beam_search_body(emb_rep, mask_rep, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty)
+        finally:
+            enc.max_new_tokens = keep_new
+
+    def _beam_search_body(self, emb_rep, mask_rep, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty):
+        from ..engine import BeamState, GenState
+        dev = self.device
+        enc = self.text_encoder
+        eng = enc.engine
         # Everything per step stays on the device and nothing synchronises: the decode step is ONE replayed hipGraph reading the
         # next tokens and the position from device memory, the reference's per-group bookkeeping is ONE launch (pcy_beam_step),
         # the KV reorder two (rows that keep their place are skipped).  The logits record is kept per SLOT and step and is
@@ -468,7 +485,6 @@ class UnifiedProCyon:
         full[:, :steps] = out.cpu()
         out, cur = full, bs.cur.cpu()
         torch.cuda.current_stream(dev).synchronize()
-        enc.max_new_tokens = keep_new
         return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
 
     @torch.no_grad()

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} declared in pcy.h but not bound"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.pcy_abi_version() == 4
+    assert lib.pcy_abi_version() == _lib.ABI_VERSION
 
 
 def test_no_fallback_without_gpu():

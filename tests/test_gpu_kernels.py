@@ -311,24 +311,85 @@ def test_decode_batch20_full_width_layer():
     assert agree >= 0.9
 
 
+def dispatch_counts(ctx):
+    """launches per GEMM kernel family so far (pcy_debug_dispatch_count)"""
+    return [int(ctx.lib.pcy_debug_dispatch_count(k)) for k in range(6)]
+
+
 @pytest.mark.parametrize("M", [64, 2048])
 def test_gemm_esm_gelu_epilogue_every_bf16_value(ctx, M):
     """The ESM GELU epilogue looks the five-rounding chain up in a table (2^-17 <= |x| < 2^7) and uses closed forms outside
-    it: every one of the 65536 bf16 bit patterns through both GEMM kernels (128x128 at M = 64, 256x256 at M = 2048) must
-    give exactly what the reference's op-by-op bf16 chain x * 0.5 * (1.0 + erf(x / sqrt(2))) gives on the CPU."""
+    it: every one of the 65536 bf16 bit patterns through both kernel families -- 64x64 tiles at M = 64 and the persistent
+    256x256 kernel at M = 2048 (N = 2048 >= 1280 output features; the dispatch is asserted) -- must give exactly what the
+    reference's op-by-op bf16 chain x * 0.5 * (1.0 + erf(x / sqrt(2))) gives on the CPU."""
     import math
+    from procyon_amd import _lib as L
     bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
-    vals = bits.view(BF)                                   # [65536] every bf16 value
-    W = vals.view(1024, 64).contiguous()                   # output[m][n] = W[n][m % 64] (A = identity rows, zero bias)
+    vals = torch.cat([bits, bits]).view(BF)                # every bf16 value, twice
+    W = vals.view(2048, 64).contiguous()                   # output[m][n] = W[n][m % 64] (A = identity rows, zero bias)
     A = torch.zeros(M, 64, dtype=BF)
     A[torch.arange(M), torch.arange(M) % 64] = 1.0
-    out = ctx.gemm(A.cuda(), W.cuda(), torch.zeros(1024, dtype=BF).cuda(), None, 3).cpu()[:64]   # [64, 1024] = W^T
+    before = dispatch_counts(ctx)
+    out = ctx.gemm(A.cuda(), W.cuda(), torch.zeros(2048, dtype=BF).cuda(), None, 3).cpu()[:64]   # [64, 2048] = W^T
+    after = dispatch_counts(ctx)
+    which = L.DISPATCH_GEMM_BIG_PERSIST if M == 2048 else L.DISPATCH_GEMM_64
+    assert [a - b for a, b in zip(after, before)] == [1 if k == which else 0 for k in range(6)]
     x = W.t().contiguous()
     # 0 * inf inside the MFMA turns the infinite / NaN patterns into NaN before the epilogue sees them, and -0 arrives as +0
     # (the accumulator starts at +0): compare every other pattern (65278 of them) bit for bit
     finite = torch.isfinite(x.float()) & (x.view(torch.int16) != -32768)
     ref = x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
     assert torch.equal(out[finite].view(torch.int16), ref[finite].view(torch.int16))
+
+
+@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2100, 1536, 2560), (2304, 5120, 1280)])
+def test_gemm_256x256_kernels_vs_oracle(ctx, M, N, K, epi):
+    """The 256x256 kernels -- gemm_kernel_big<STORE | RESID | SWIGLU> and gemm_kernel_big_persist<GELU_ESM>: the ESM retrieval leg
+    and every batched prefill GEMM -- directly against the oracle's Linear (+ residual / ESM GELU / SwiGLU), with the dispatch
+    asserted (M >= 2048, N >= 1280; M = 2100 leaves a ragged last row tile)."""
+    from procyon_amd import _lib as L
+    from procyon_amd.engine import interleave_gate_up
+    A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=0.05), rnd(N, seed=3, std=0.1), rnd(M, N, seed=4)
+    before = dispatch_counts(ctx)
+    if epi == 4:
+        g, u = W[: N // 2].contiguous(), rnd(N // 2, K, seed=5, std=0.05)
+        out = ctx.gemm(A.cuda(), interleave_gate_up(g.cuda(), u.cuda()), None, None, 4).cpu()
+        ref = F.silu(F.linear(A, g)) * F.linear(A, u)
+        lin = None
+    else:
+        out = ctx.gemm(A.cuda(), W.cuda(), b.cuda(), r.cuda() if epi == 1 else None, epi).cpu()
+        ref = ref_linear(A, W, b, r, epi)
+        lin = F.linear(A, W, b) if epi else None
+    after = dispatch_counts(ctx)
+    which = L.DISPATCH_GEMM_BIG_PERSIST if epi == 3 else L.DISPATCH_GEMM_BIG
+    assert [x - y for x, y in zip(after, before)] == [1 if k == which else 0 for k in range(6)], (before, after)
+    assert_bf16_close(out, ref, f"big gemm {M}x{N}x{K} epi{epi}", inter=lin, ulps=2 if epi == 4 else 1)
+    assert rel_err(out, ref) < 1e-3
+
+
+def test_esm_layer_256x256_fused_rotary_vs_oracle(ctx):
+    """gemm_kernel_big<STORE + fused rotary> (the ESM qkv projection: q pre-scaled, q and k rotated in the epilogue) is only
+    reachable through pcy_esm_encode: one full-width ESM2-650M layer over 2150 packed tokens against the oracle, asserting that
+    all four GEMMs of the layer went to the 256x256 kernels (qkv + rotary, o + residual, fc2 + residual: big; fc1 + GELU:
+    persistent) and none to the smaller tilings."""
+    from oracle import esm_ref as ER
+    from procyon_amd import _lib as L
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig, EsmEngine
+    kw = dict(d=1280, n_layers=1, n_heads=20, ffn=5120)
+    sd = synth.esm_state_dict(**kw)
+    eng = EsmEngine(sd, EsmConfig(**kw))
+    toks = synth.protein_tokens([1000, 700, 444], seed=21)
+    before = dispatch_counts(ctx)
+    out = eng.hidden_states(toks).cpu()
+    d = [x - y for x, y in zip(dispatch_counts(ctx), before)]
+    assert d[L.DISPATCH_GEMM_BIG] == 3 and d[L.DISPATCH_GEMM_BIG_PERSIST] == 1 and d[L.DISPATCH_GEMM_128] == 0 and d[L.DISPATCH_GEMM_64] == 0, d
+    ref = ER.esm_forward(sd, ER.EsmGeom(**kw), toks)
+    keep = toks != 1
+    err = rel_err(out[keep], ref[keep])
+    print(f"one ESM2-650M layer through the 256x256 kernels vs oracle: {err:.2e} (CPU-vs-CPU floor of this layer 1.7e-3)")
+    assert err < 2.5e-3
 
 
 @pytest.mark.parametrize("B,beam,g,V,steps,eos", [(1, 4, 2, 300, 7, 299), (2, 6, 2, 481, 6, 5), (1, 5, 5, 300, 6, 299), (3, 8, 4, 260, 5, 7),
@@ -423,7 +484,10 @@ def test_gemm_swiglu_epilogue_every_bf16_gate_value(ctx, M):
     up = torch.ones(2048, 64, dtype=BF)
     A = torch.zeros(M, 64, dtype=BF)
     A[torch.arange(M), torch.arange(M) % 64] = 1.0
+    before = dispatch_counts(ctx)
     out = ctx.gemm(A.cuda(), interleave_gate_up(gate.cuda(), up.cuda()), None, None, L.EPI_SWIGLU).cpu()[:64]   # [64, F]: silu(gate[f][m])
+    which = L.DISPATCH_GEMM_BIG if M == 2048 else L.DISPATCH_GEMM_128     # SwiGLU has no 64x64 variant
+    assert [a - b for a, b in zip(dispatch_counts(ctx), before)] == [1 if k == which else 0 for k in range(6)]
     x = gate.t().contiguous()
     ok = torch.isfinite(x.float()) & (x.view(torch.int16) != -32768)           # inf / NaN become NaN in the MFMA, -0 arrives as +0
     ref = F.silu(x)
