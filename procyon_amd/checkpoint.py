@@ -51,6 +51,7 @@ def split_state_dict(sd):
     llama = {k[len("text_encoder.model."):]: v for k, v in sd.items() if k.startswith("text_encoder.model.")}
     esm_raw = {k[len("protein_seq_encoder.model."):]: v for k, v in sd.items() if k.startswith("protein_seq_encoder.model.")}
     esm = fair_esm_to_hf(esm_raw) if esm_raw else None
+    esm_fair = any(not k.startswith("esm.") for k in esm_raw)      # fair-esm parameter names: the fair-esm ESM2 class produced them
 
     def mlp(prefix):
         idx = sorted({int(m.group(1)) for k in sd for m in [re.match(re.escape(prefix) + r"\.(\d+)\.weight$", k)] if m})
@@ -66,10 +67,41 @@ def split_state_dict(sd):
         if layers:
             projectors[name] = layers
     tables = {k[:-len(".weight")]: v for k, v in sd.items() if re.match(r"^(protein_seq|domain|peptide|protein_struct|drug_structure)_embeddings\.weight$", k)}
-    return dict(llama=llama, esm=esm, projectors=projectors, tables=tables)
+    return dict(llama=llama, esm=esm, esm_fair=esm_fair, projectors=projectors, tables=tables)
+
+
+def merge_lora(sd, lora_alpha=None):
+    """Checkpoints trained with `use_lora` carry PEFT names (peft 0.5.0): `<prefix>.base_model.model.<hf key>` for the frozen
+    weights (a Linear that holds an adapter: `...<name>.weight` stays under that name in 0.5.0, `base_layer.weight` in later
+    versions) and `...<name>.lora_A.<adapter>.weight` [r, in], `...lora_B.<adapter>.weight` [out, r].  The reference loads them
+    into a PEFT-wrapped module; the engine packs plain matrices, so the delta is folded in: W += (alpha / r) * B @ A.
+    `lora_alpha` defaults to r (scale 1) when the checkpoint does not say; pass the training value."""
+    if not any(".lora_A." in k or ".base_model.model." in k for k in sd):
+        return sd
+    out, lora = {}, {}
+    for k, v in sd.items():
+        k2 = k.replace(".base_model.model.", ".").replace(".base_layer.", ".")
+        m = re.match(r"^(.*)\.lora_([AB])\.([^.]+)\.weight$", k2)
+        if m:
+            lora.setdefault((m.group(1), m.group(3)), {})[m.group(2)] = v
+        elif ".lora_" not in k2:
+            out[k2] = v
+    for (base, _adapter), ab in lora.items():
+        if "A" not in ab or "B" not in ab:
+            raise KeyError(f"incomplete LoRA pair for {base}")
+        wkey = base + ".weight"
+        if wkey not in out:
+            raise KeyError(f"LoRA adapter for {base} but no base weight {wkey} in the checkpoint")
+        r = ab["A"].shape[0]
+        scale = (lora_alpha if lora_alpha is not None else r) / r
+        out[wkey] = (out[wkey].float() + scale * (ab["B"].float() @ ab["A"].float())).to(out[wkey].dtype)
+    return out
 
 
 def infer_llama_config(llama_sd, **over):
+    if "model.embed_tokens.weight" not in llama_sd:
+        raise KeyError("text_encoder.model.model.embed_tokens.weight is not in the checkpoint: frozen tensors are missing (the reference "
+                       "fills them from the pretrained Llama under pretrained_weights_dir; merge them into the state dict first)")
     from .engine import LlamaConfig
     emb = llama_sd["model.embed_tokens.weight"]
     n_layers = 1 + max(int(m.group(1)) for k in llama_sd for m in [re.match(r"model\.layers\.(\d+)\.", k)] if m)
@@ -91,7 +123,7 @@ def infer_esm_config(esm_sd, n_heads=None, **over):
     return EsmConfig(d=d, n_layers=n_layers, n_heads=n_heads, ffn=ffn, vocab=emb.shape[0], **over)
 
 
-def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_heads=None, **llama_over):
+def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_heads=None, esm_rope_math=None, **llama_over):
     """state dict + `ProCyonConfig` + tokenizer -> engine-backed `UnifiedProCyon` (the tail of `from_pretrained`,
     model_unified.py:1370-1382 `load_state_dict(strict=False)`)."""
     from .engine import BF16, MlpEngine
@@ -101,7 +133,10 @@ def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_he
     text_encoder = LlamaPostTokenization(parts["llama"], infer_llama_config(parts["llama"], **llama_over), dev, max_new_tokens)
     plm = None
     if parts["esm"] and not config.use_aaseq_embeddings:
-        plm = ESM_PLM(parts["esm"], infer_esm_config(parts["esm"], n_heads=esm_heads), pooling_method=config.protein_pooling_opt,
+        # fair-esm's rotary embedding rounds every product in model dtype, HF's computes in fp32 and rounds once:
+        # the encoder a checkpoint was trained with is recognisable by its parameter names
+        rope_math = esm_rope_math or ("model_dtype" if parts["esm_fair"] else "fp32_once")
+        plm = ESM_PLM(parts["esm"], infer_esm_config(parts["esm"], n_heads=esm_heads, rope_math=rope_math), pooling_method=config.protein_pooling_opt,
                       protein_pooling_correction_option=config.protein_pooling_correction_option,
                       max_protein_len=config.max_protein_len, device=dev)
     mk = lambda layers: MlpEngine([(w.to(dev, BF16), None if b is None else b.to(dev, BF16)) for w, b in layers])
@@ -187,14 +222,89 @@ def hf_tokenizer(path):
     return tok
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# DeepSpeed ZeRO stage-1/2 checkpoint -> one fp32 state dict
+def get_fp32_state_dict_from_zero_checkpoint(checkpoint_dir, tag=None):
+    """What `deepspeed.utils.zero_to_fp32.get_fp32_state_dict_from_zero_checkpoint` returns for a ZeRO stage 1 / 2 checkpoint
+    (the reference's fallback when `txllm_model_ckpt.pt` is absent, model_unified.py:1336,1380-1382; ProCyon-Full ships as
+    ZeRO-2, world 32, `global_step59469`).  DeepSpeed itself (pyproject pin 0.12.4) is not a dependency of this engine; the
+    published algorithm is restated:
+
+      <dir>/latest                                       text file holding the tag (e.g. "global_step59469") unless `tag` given
+      <dir>/<tag>/mp_rank_00_model_states.pt             'module' (16-bit weights + buffers), 'buffer_names', 'param_shapes'
+                                                         (one ordered name -> shape map per optimizer param group),
+                                                         'shared_params', optional 'frozen_param_shapes' / '_fragments'
+      <dir>/<tag>/[bf16_]zero_pp_rank_<r>_mp_rank_00_optim_states.pt   'optimizer_state_dict': 'zero_stage', 'partition_count',
+                                                         'single_partition_of_fp32_groups' (rank r's slice of every group)
+
+    Stage <= 2 keeps, per param group, ONE flat fp32 buffer holding the group's parameters back to back in `param_shapes`
+    order, padded to a multiple of 2 x world size and cut into `world` equal slices.  Merge = concatenate the slices in rank
+    order and cut the parameters back out.  Frozen parameters are stored whole; buffers come from 'module'; tied parameters
+    are re-tied through 'shared_params'."""
+    import glob
+    import math
+    import os
+    if tag is None:
+        latest = os.path.join(checkpoint_dir, "latest")
+        if not os.path.isfile(latest):
+            raise ValueError(f"Unable to find 'latest' file at {latest}")
+        tag = open(latest).read().strip()
+    d = os.path.join(checkpoint_dir, tag)
+    if not os.path.isdir(d):
+        raise FileNotFoundError(f"Directory '{d}' doesn't exist")
+    load = lambda f: torch.load(f, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
+    rank_of = lambda f: int(re.search(r"zero_pp_rank_(\d+)_", os.path.basename(f)).group(1))
+    optim_files = sorted(glob.glob(os.path.join(d, "*_optim_states.pt")), key=rank_of)
+    if not optim_files:
+        raise FileNotFoundError(f"can't find '*_optim_states.pt' files in directory '{d}'")
+    model_files = sorted(glob.glob(os.path.join(d, "*_model_states.pt")))
+    if not model_files:
+        raise FileNotFoundError(f"can't find '*_model_states.pt' files in directory '{d}'")
+    ms = load(model_files[0])
+    flat_groups, stage, world = [], None, None
+    for f in optim_files:
+        osd = load(f)["optimizer_state_dict"]
+        stage = osd["zero_stage"] if stage is None else stage
+        pc = osd["partition_count"]
+        world = max(pc) if isinstance(pc, (list, tuple)) else pc
+        flat_groups.append(osd["single_partition_of_fp32_groups"])
+    if stage > 2:
+        raise NotImplementedError(f"ZeRO stage {stage} checkpoints are not supported (ProCyon checkpoints are stage 2)")
+    if world != len(optim_files):
+        raise ValueError(f"Expected {world} of '*_optim_states.pt' under '{d}' but found {len(optim_files)} files")
+    out = {}
+    for name in ms.get("buffer_names", []):                                   # buffers, as fp32
+        out[name] = ms["module"][name].float()
+    for name in (ms.get("frozen_param_shapes") or {}):                        # stage <= 2: frozen parameters are stored whole
+        out[name] = ms["frozen_param_fragments"][name]
+    align = 2 * world
+    up = lambda n: align * math.ceil(n / align)
+    param_shapes = ms["param_shapes"]
+    if isinstance(param_shapes, dict):
+        param_shapes = [param_shapes]
+    for gi, shapes in enumerate(param_shapes):
+        full = torch.cat([fg[gi] for fg in flat_groups], 0)
+        offset = 0
+        for name, shape in shapes.items():
+            numel = int(math.prod(shape))
+            out[name] = full.narrow(0, offset, numel).view(tuple(shape))
+            offset += numel
+        if up(offset) != up(full.numel()):
+            raise ValueError(f"consumed {offset} numels out of {full.numel()} - something is wrong")
+    for pair in ms.get("shared_params", []) or []:
+        if pair[1] in out:
+            out[pair[0]] = out[pair[1]]
+    return out
+
+
 def from_pretrained(*, pretrained_weights_dir=None, checkpoint_dir=None, model=None, config_only=False, config=None,
                     state_dict_relative_path="txllm_model_ckpt.pt", strict_load=False, load_plm_directly=False,
                     protein_pooling_correction_option=False, tokenizer=None, device="cuda", max_new_tokens=256, **engine_kw):
     """`UnifiedProCyon.from_pretrained` (model_unified.py:1296-1394) -> (model, config).
 
     Same keyword contract for what inference uses.  Differences: `model=` (update an existing module in place) is not
-    supported -- the engine packs weights at construction; a checkpoint that only holds DeepSpeed ZeRO shards must be
-    consolidated first (`zero_to_fp32.py`, shipped inside every DeepSpeed checkpoint directory); `tokenizer=` may supply
+    supported -- the engine packs weights at construction; a checkpoint that only holds DeepSpeed ZeRO stage-2 shards is merged
+    by `get_fp32_state_dict_from_zero_checkpoint` above; `tokenizer=` may supply
     the tokenizer object when the Llama tokenizer files are not at $LLAMA3_PATH / pretrained_weights_dir."""
     import os
     if model is not None:
@@ -227,9 +337,11 @@ def from_pretrained(*, pretrained_weights_dir=None, checkpoint_dir=None, model=N
         config.protein_enc_batch_limit = None
         config.protein_pooling_correction_option = protein_pooling_correction_option
     sd_path = os.path.join(checkpoint_dir, state_dict_relative_path)
-    if not os.path.exists(sd_path):
-        raise NotImplementedError(f"{sd_path} not found: consolidate the DeepSpeed ZeRO shards with the checkpoint's zero_to_fp32.py first")
-    sd = torch.load(sd_path, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
+    if os.path.exists(sd_path):                                  # consolidated locally (model_unified.py:1376-1379)
+        sd = torch.load(sd_path, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
+    else:                                                        # DeepSpeed ZeRO shards (:1380-1382)
+        sd = get_fp32_state_dict_from_zero_checkpoint(checkpoint_dir)
+    sd = merge_lora(sd)
     if not any(k.startswith("protein_seq_encoder.model.") for k in sd) and not getattr(config, "use_aaseq_embeddings", False):
         # frozen encoder loaded from the fair-esm release file next to the other pretrained weights (esm.py:378-398)
         name = {"650m": "esm2_t33_650M_UR50D.pt", "3b": "esm2_t36_3B_UR50D.pt", "35m": "esm2_t12_35M_UR50D.pt",

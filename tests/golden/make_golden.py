@@ -406,7 +406,39 @@ def g10(ns):
     save("g10_text_prep", **out)
 
 
+def g11():
+    """Reference `get_prompt` / `get_prompt_open_def` (instruct_constructor.py:111-365, imported from the file -- it only needs
+    torch / numpy) on seven of the reference's task templates (data files): every category, PPI and non-PPI, the three
+    sequence types.  The fixture holds the task dicts (inputs) and the returned tuples (expected outputs)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ref_ic", os.path.join(REF, "procyon/data/instruct_tune/instruct_constructor.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cases = []
+    tasks = {}
+    for name in ("uniprot_all_caption", "disgenet_all_retrieval", "omim_all_qa", "protein_homology_qa", "protein_homology_retrieval",
+                 "domain_pfam_all_qa", "peptide_all_retrieval"):
+        task = json.load(open(os.path.join(REF, "procyon/data/instruct_tune/tasks", name + ".json")))
+        tasks[name] = task
+        ppi = "aaseq_1" in task["Positive Examples"][0]
+        for aa in ("protein", "domain", "peptide", None):
+            for ne in (None, 0, 1, 2):
+                for samp in (False, True):
+                    cases.append(dict(task=name, fn="get_prompt", aaseq_type=aa, num_examples=ne, sample_examples=samp, is_ppi=ppi,
+                                      out=list(ref.get_prompt(task, ne, False, ppi, samp, aa))))
+                cases.append(dict(task=name, fn="get_prompt_open_def", aaseq_type=aa, num_examples=ne, sample_examples=False, is_ppi=ppi,
+                                  out=list(ref.get_prompt_open_def(task, ne, False, ppi, False, aa))))
+    import gzip
+    with gzip.open(os.path.join(HERE, "g11_prompts.json.gz"), "wt") as f:
+        json.dump(dict(tasks=tasks, cases=cases), f)
+    print("wrote g11_prompts.json.gz", len(cases), "cases")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["g11"]:
+        g11()
+        sys.exit(0)
     ns = ref_ns()
-    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns)
+    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns); g11()

@@ -209,7 +209,8 @@ def test_checkpoint_ingest_builds_identical_model(env):
     for name, key in (("token_projectors.aaseq", "aaseq"), ("aaseq_shared_projector", "shared"), ("aaseq_lm_projector", "lm")):
         for j, (wt, b) in zip((0, 3, 6), w["projs"][key]):
             sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = wt, b
-    m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, esm_heads=2, head_dim=64, max_pos=4096)
+    m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, esm_heads=2, head_dim=64, max_pos=4096,
+                     esm_rope_math="fp32_once")      # (fair-esm names select the fair-esm rotary arithmetic by default)
     a, b = m.forward_sequences(env["prot"], get_soft_tokens=True), m2.forward_sequences(env["prot"], get_soft_tokens=True)
     for k in ("original", "shared", "token"):
         assert torch.equal(a[k], b[k]), k
@@ -229,7 +230,7 @@ def test_checkpoint_ingest_builds_identical_model(env):
         torch.save(SimpleNamespace(data_dir="/x"), os.path.join(d, "data_args.pt"))
         torch.save(sd, os.path.join(d, "txllm_model_ckpt.pt"))
         m3, cfg = UnifiedProCyon.from_pretrained(pretrained_weights_dir=d, checkpoint_dir=d, tokenizer=m.tokenizer, max_new_tokens=16,
-                                                 esm_heads=2, head_dim=64, max_pos=4096)
+                                                 esm_heads=2, head_dim=64, max_pos=4096, esm_rope_math="fp32_once")
     assert cfg.protein_pooling_opt == "mean" and cfg.n_model_pieces == 1
     c = m3.forward_sequences(env["prot"], get_soft_tokens=True)
     for k in ("original", "shared", "token"):
