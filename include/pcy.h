@@ -86,6 +86,11 @@ int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int3
  * fp32-accumulating matmul rounded once).  D must be a multiple of 64. */
 int pcy_retrieval_scores(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, void* sims_out);
 
+/* Retrieval ranking (data/inference_utils.py:921-978 `get_proteins_from_embedding`): the same similarities, then per query the
+ * k best targets in stable descending order (ties: the lower index first; torch.argsort leaves them open) -> idx_out [Q,k]
+ * int32, score_out [Q,k] bf16.  1 <= k <= N; k == N is the full ranking (top_k=None). */
+int pcy_retrieval_topk(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, int k, int32_t* idx_out, void* score_out);
+
 /* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path"; the reference has no fp8 counterpart) ----
  * Per-row symmetric OCP e4m3 quantisation of a bf16 matrix x[rows,K] (ldx elements between rows, K % 8 == 0):
  * scale_out[r] = the smallest power of two >= 2^-126 with amax|x[r,:]| / scale <= 448 (1 for an all-zero row),

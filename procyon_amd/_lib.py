@@ -82,6 +82,7 @@ SIGNATURES = {
     "pcy_attn_decode": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "pcy_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
     "pcy_retrieval_scores": (ci, [vp, vp, ci, vp, ci, ci, vp]),
+    "pcy_retrieval_topk": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp]),
     "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),

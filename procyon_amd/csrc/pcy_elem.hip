@@ -461,6 +461,43 @@ __global__ __launch_bounds__(NT) void l2norm_rows_kernel(const bf16_t* __restric
   }
 }
 
+// ------------------------------------------------------------------ retrieval ranking (row f3): top-k of a similarity row
+// `get_proteins_from_embedding` (data/inference_utils.py:955-978) argsorts the whole similarity row to keep 20 entries.  Here
+// every entry computes its own RANK -- the number of entries that sort in front of it: a larger score, or an equal score at a
+// lower index (a stable descending order, deterministic where torch.argsort leaves ties open) -- and writes itself to slot
+// `rank` if rank < k.  N^2 comparisons of 16-bit keys from LDS tiles: 18174 targets (the reference's cached matrix) = 3.3e8,
+// 100k targets = 1e10 (< 1 ms of VALU), no sort, no atomics, k up to N (top_k=None: the full ranking).
+// Order-preserving key of a bf16: flip all bits of negatives, the sign bit of positives; NaNs land at the extremes like in torch.
+__device__ __forceinline__ uint32_t bf16_order_key(bf16_t b) { return (b & 0x8000u) ? (uint32_t)(b ^ 0xffffu) & 0xffffu : (uint32_t)(b | 0x8000u); }
+constexpr int RANK_TILE = 4096;
+__global__ __launch_bounds__(NT) void retrieval_rank_kernel(const bf16_t* __restrict__ sims, int N, int k, int32_t* __restrict__ idx_out,
+                                                            bf16_t* __restrict__ score_out) {
+  __shared__ uint16_t keys[RANK_TILE];
+  const int q = blockIdx.y;
+  const bf16_t* row = sims + (size_t)q * N;
+  const int i0 = blockIdx.x * NT, i = i0 + threadIdx.x;
+  const bf16_t mine = i < N ? row[i] : (bf16_t)0;
+  const uint32_t ki = bf16_order_key(mine);
+  int rank = 0;
+  for (int t0 = 0; t0 < N; t0 += RANK_TILE) {
+    const int tn = (N - t0) < RANK_TILE ? (N - t0) : RANK_TILE;
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += NT) keys[j] = (uint16_t)bf16_order_key(row[t0 + j]);
+    __syncthreads();
+    if (t0 + tn <= i0) {                       // every j of the tile lies before every i of this block: ties count
+      for (int j = 0; j < tn; ++j) rank += keys[j] >= ki;
+    } else if (t0 >= i0 + NT) {                // every j lies behind: ties do not count
+      for (int j = 0; j < tn; ++j) rank += keys[j] > ki;
+    } else {
+      for (int j = 0; j < tn; ++j) rank += (keys[j] > ki) | ((keys[j] == ki) & (t0 + j < i));
+    }
+  }
+  if (i < N && rank < k) {
+    idx_out[(size_t)q * k + rank] = i;
+    score_out[(size_t)q * k + rank] = mine;
+  }
+}
+
 __global__ __launch_bounds__(NT) void copy_rows_kernel(const bf16_t* __restrict__ src, int lds_, bf16_t* __restrict__ dst,
                                                        int ldd, const int32_t* __restrict__ rows, int d) {
   const int r = blockIdx.x;
@@ -905,6 +942,10 @@ void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* ds
 }
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps) {
   if (rows > 0) hipLaunchKernelGGL(l2norm_rows_kernel, dim3(rows), dim3(NT), 0, s, x, y, d, eps);
+}
+void pcy_launch_retrieval_rank(hipStream_t s, const bf16_t* sims, int Q, int N, int k, int32_t* idx_out, bf16_t* score_out) {
+  if (Q > 0 && N > 0 && k > 0)
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((N + NT - 1) / NT, Q), dim3(NT), 0, s, sims, N, k, idx_out, score_out);
 }
 size_t pcy_beam_ws_bytes(int B, int beam) {
   return (size_t)B * beam * BEAM_NCH * sizeof(float2) + 256 + (size_t)B * beam * BEAM_NCH * beam * sizeof(BeamCand);

@@ -438,6 +438,20 @@ int pcy_gemm_fp8(pcy_ctx* c, const void* A8, const float* sa, const void* W8, co
   pcy_launch_gemm(c->stream, a);
   return check_launch("pcy_gemm_fp8");
 }
+int pcy_retrieval_topk(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, int k, int32_t* idx_out, void* score_out) {
+  if (D % 64) return fail(1, "pcy_retrieval_topk: D=%d must be a multiple of 64", D);
+  if (k < 1 || k > N) return fail(1, "pcy_retrieval_topk: k=%d must be in [1, N=%d]", k, N);
+  const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256), sb = align_up((size_t)Q * N * 2, 256);
+  if (int r = c->reserve(qb + tb + sb + 4096)) return r;
+  bf16_t* qn = reinterpret_cast<bf16_t*>(c->ws);
+  bf16_t* tn = reinterpret_cast<bf16_t*>(c->ws + qb);
+  bf16_t* sims = reinterpret_cast<bf16_t*>(c->ws + qb + tb);
+  pcy_launch_l2norm_rows(c->stream, (const bf16_t*)query, qn, Q, D, 1e-12f);
+  pcy_launch_l2norm_rows(c->stream, (const bf16_t*)targets, tn, N, D, 1e-12f);
+  linear(c->stream, qn, D, tn, nullptr, nullptr, 0, sims, N, Q, N, D, EPI_STORE);
+  pcy_launch_retrieval_rank(c->stream, sims, Q, N, k, idx_out, (bf16_t*)score_out);
+  return check_launch("pcy_retrieval_topk");
+}
 int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, void* sims_out) {
   if (D % 64) return fail(1, "pcy_retrieval_scores: D=%d must be a multiple of 64", D);
   const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256);

@@ -136,6 +136,8 @@ void pcy_launch_beam_step(hipStream_t s, const bf16_t* logits, int V, int B, int
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds, bf16_t* dst, int ldd, const int32_t* rows,
                           int nrows, int d);
 void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows, int d, float eps);
+// per row of sims [Q,N]: the k best entries in stable descending order (ties: lower index first) -> idx_out / score_out [Q,k]
+void pcy_launch_retrieval_rank(hipStream_t s, const bf16_t* sims, int Q, int N, int k, int32_t* idx_out, bf16_t* score_out);
 // acc[r][:] (fp32) = / += src[rows[r]][:]; out = bf16(acc)
 void pcy_launch_acc_rows(hipStream_t s, const bf16_t* src, int lds, const int32_t* rows, float* acc, int nrows, int d, int first);
 void pcy_launch_acc_finish(hipStream_t s, const float* acc, bf16_t* out, size_t n);

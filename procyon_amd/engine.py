@@ -162,6 +162,18 @@ class Context:
         L.check(self.lib.pcy_retrieval_scores(self.h, _p(query), Q, _p(targets), N, D, _p(out)), "pcy_retrieval_scores")
         return out
 
+    def retrieval_topk(self, query, targets, k=None):
+        """(indices int64 [Q,k], scores bf16 [Q,k]) of the k most similar targets per query, best first, ties by lower index
+        (`get_proteins_from_embedding`, data/inference_utils.py:921-978); k=None ranks all N targets."""
+        _chk_bf16(query, targets)
+        Q, D = query.shape
+        N = targets.shape[0]
+        k = N if k is None else min(int(k), N)
+        idx = torch.empty(Q, k, dtype=torch.int32, device=query.device)
+        sc = torch.empty(Q, k, dtype=BF16, device=query.device)
+        L.check(self.lib.pcy_retrieval_topk(self.h, _p(query), Q, _p(targets), N, D, k, _p(idx), _p(sc)), "pcy_retrieval_topk")
+        return idx.long(), sc
+
     def pool(self, hidden, seg, rng, nprot, mode):
         _chk_bf16(hidden)
         d = hidden.shape[-1]

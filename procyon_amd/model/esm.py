@@ -27,8 +27,9 @@ class ESM_PLM:
 
     def __init__(self, state_dict, cfg: EsmConfig, pooling_method="max", protein_pooling_correction_option=False,
                  long_protein_strategy="split", max_protein_len=1024, official=False, device=None):
-        if long_protein_strategy != "split":
-            raise NotImplementedError("only long_protein_strategy='split' is on the hot path (llama3-full.yml)")
+        if long_protein_strategy not in ("split", "truncate"):
+            raise NotImplementedError(f"long_protein_strategy={long_protein_strategy!r} (train_utils.py:1497-1596 knows 'split' and 'truncate')")
+        self.long_protein_strategy = long_protein_strategy
         self.engine = EsmEngine(state_dict, cfg, device)
         self.embedding_size = cfg.d
         self.repr_layer = cfg.n_layers
@@ -46,6 +47,9 @@ class ESM_PLM:
     def forward(self, tokens, aggregate=True):
         if not aggregate:
             raise NotImplementedError("aggregate=False (MLM / per-residue) is outside the north-star path")
+        if self.long_protein_strategy == "truncate":       # cut to max_protein_len residues, re-terminate (train_utils.py:1575-1588)
+            from ..sequences import split_or_truncate_long_seq
+            tokens, _, _ = split_or_truncate_long_seq(tokens.cpu().long(), self.padding_idx, self.eos_idx, "truncate", self.max_protein_len)
         z = self.engine.forward(tokens, pooling=self.pooling_method, correction=self.correction,
                                 mask_pads=not self.official, max_protein_len=self.max_protein_len)
         return z, None

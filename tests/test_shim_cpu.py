@@ -1,0 +1,233 @@
+"""CPU: the `procyon` import surface -- the import lines of the reference's entry points resolve against
+the shim with no dataset, checkpoint or environment variable present; the host-side helpers match the reference's own
+functions (golden g11: prompts produced by the reference's `get_prompt` / `get_prompt_open_def` on its task files) and build the
+`inputs` dictionaries of SURVEY App. D from a synthetic ProCyon-Instruct directory; checkpoint ingest merges DeepSpeed ZeRO-2
+shards."""
+import gzip
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pandas as pd
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the import statements of the reference's entry points, verbatim (they are the interface under test):
+ENTRY_POINT_IMPORTS = {
+    "scripts/caption_bulk.py:11-20": """
+from procyon.model.model_unified import UnifiedProCyon
+from procyon.training.train_utils import (
+    set_seed,
+)
+from procyon.data.data_utils import DATA_DIR
+from procyon.data.inference_utils import (
+    create_caption_input_simple,
+    uniprot_id_to_index,
+)
+""",
+    "procyon/app/main.py:9": "from procyon.inference.retrieval_utils import startup_retrieval, do_retrieval",
+    "procyon/inference/retrieval_utils.py:9-15": """
+from procyon.data.inference_utils import (
+    create_input_retrieval,
+    get_proteins_from_embedding,
+)
+from procyon.evaluate.framework.utils import move_inputs_to_device
+from procyon.inference.settings import logger
+from procyon.model.model_unified import UnifiedProCyon
+from procyon.training.train_utils import DataArgs
+""",
+    "examples/*.ipynb cell 0/1, scripts/qa_filter_captions.py": """
+from procyon.data.inference_utils import create_qa_input_simple, ProCyonQAInference, get_proteins_from_embedding, desc_perturbation
+from procyon.evaluate.framework.procyon import ProcyonCaptionEval, ProcyonQAEval, ProcyonRetrievalEval
+from procyon.training.training_args_IT import ModelArgs, DataArgs
+from procyon.model.model_utils import create_mlp, left_pad_tensors
+from procyon.model.esm import ESM_PLM
+from procyon.model.pmc_llama import LlamaPostTokenization
+""",
+}
+
+
+@pytest.mark.parametrize("where", sorted(ENTRY_POINT_IMPORTS))
+def test_entry_point_import_lines_resolve_without_data(where):
+    """fresh interpreter, DATA_DIR / HOME_DIR / CHECKPOINT_PATH unset: nothing may be read at import"""
+    env = {k: v for k, v in os.environ.items() if k not in ("DATA_DIR", "HOME_DIR", "CHECKPOINT_PATH", "HF_TOKEN", "LLAMA3_PATH")}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", ENTRY_POINT_IMPORTS[where] + "\nprint('IMPORTS_OK')"], env=env, capture_output=True, text=True, cwd="/")
+    assert r.returncode == 0 and "IMPORTS_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_fastapi_app_module_imports_and_declares_the_route():
+    from procyon.app.main import RetrievalRequest, app
+    assert any(getattr(r, "path", None) == "/retrieve" for r in app.routes)
+    assert RetrievalRequest(task_desc="a", disease_desc="b", instruction_source_dataset="omim").k is None
+
+
+@pytest.fixture(scope="module")
+def g11():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "g11_prompts.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def test_prompts_match_the_reference_constructor(g11):
+    from procyon.data.instruct_tune import instruct_constructor as IC
+    assert len(g11["cases"]) > 300
+    for c in g11["cases"]:
+        task = g11["tasks"][c["task"]]
+        fn = getattr(IC, c["fn"])
+        out = fn(task, num_examples=c["num_examples"], is_special_definition=False, is_ppi=c["is_ppi"],
+                 sample_examples=c["sample_examples"], aaseq_type=c["aaseq_type"])
+        assert list(out) == c["out"], (c["task"], c["fn"], c["aaseq_type"], c["num_examples"], c["sample_examples"])
+
+
+@pytest.fixture()
+def instruct_dir(tmp_path, g11, monkeypatch):
+    """a miniature ProCyon-Instruct tree + task templates: DATA_DIR / HOME_DIR for the input builders"""
+    home, data = tmp_path / "home", tmp_path / "data"
+    tasks = home / "procyon" / "data" / "instruct_tune" / "tasks"
+    tasks.mkdir(parents=True)
+    for name, t in g11["tasks"].items():
+        (tasks / f"{name}.json").write_text(json.dumps(t))
+    prot = data / "integrated_data" / "v1" / "protein"
+    prot.mkdir(parents=True)
+    n = 20000
+    pd.DataFrame({"index": range(n), "protein_id": [f"P{i:05d}" for i in range(n)], "name": [f"GENE{i}" for i in range(n)]}).to_pickle(
+        prot / "protein_info_filtered.pkl")
+    pd.DataFrame({"index": range(n), "function": [f"function of protein {i}" for i in range(n)]}).to_pickle(prot / "uniprot_functional_descriptions.pkl")
+    for ds, rows in (("uniprot", 20000), ("omim", 5000), ("disgenet", 240000)):
+        d = data / "integrated_data" / "v1" / ds
+        d.mkdir(parents=True)
+        pd.DataFrame({"index": range(rows), "description_a": [None if i % 3 == 0 else f"{ds} text A {i}" for i in range(rows)],
+                      "description_b": [f"{ds} text B {i}" for i in range(rows)], "other": 0}).to_pickle(d / f"{ds}_info_filtered_composed.pkl")
+    monkeypatch.setenv("DATA_DIR", str(data))
+    monkeypatch.setenv("HOME_DIR", str(home))
+    import procyon.data.constants as C
+    import procyon.data.inference_utils as IU
+    C._cache = None
+    IU._LAZY.clear()
+    return data
+
+
+def test_input_builders_produce_the_documented_dicts(instruct_dir, g11):
+    from procyon.data import inference_utils as IU
+    from procyon.training.training_args_IT import DataArgs
+    da = DataArgs()
+    assert IU.uniprot_id_to_index("P00530") == 530 and IU.index_to_uniprot_id(5) == "P00005"
+    with pytest.raises(AssertionError):
+        IU.uniprot_id_to_index("nope")
+    # caption (phenotype_generation.ipynb cell 9 -> 10): one in-context example (protein 5) + the query protein
+    cap = IU.create_caption_input_simple(input_aaseq_ids=[530], data_args=da, instruction_source_dataset="uniprot", icl_example_number=1)
+    assert cap["data"]["seq"].tolist() == [5, 530] and cap["input"]["seq"] == [[0, 1]] and cap["input"]["text"] == [[0]]
+    assert cap["data"]["text"] == ["uniprot text A 5"] and cap["target"] == {"seq": None, "text": None, "drug": None}
+    ins = cap["instructions"][0]
+    assert ins.startswith("Definition: You will be shown a protein.") and ins.endswith("Protein: <|protein|>\nOutput: [ANSWER] ")
+    assert ins.count("<|protein|>") == 2 and ins.count("[EXT]") == 1 and "[CONTEXT]" not in ins
+    # QA: positive + negative example, first non-missing description column, answer slot "null"
+    qa = IU.create_qa_input_simple(input_aaseq_ids=[77], data_args=da, input_description="query text", instruction_source_dataset="omim")
+    assert qa["data"]["seq"].tolist() == [13207, 16671, 77] and qa["data"]["text"] == ["omim text A 464", "omim text B 2715", "query text"]
+    assert qa["instructions"][0].endswith("Output: [ANSWER] null") and qa["instructions"][0].count("[EXT]") == 3
+    # retrieval with an open task definition: prompt ends in [PROT]
+    ret = IU.create_input_retrieval(input_description="a disease", data_args=da, instruction_source_dataset="disgenet",
+                                    task_definition="Find the proteins.", icl_example_number=1)
+    assert ret["data"]["seq"].tolist() == [6549] and ret["data"]["text"][-1] == "a disease" and ret["input"]["drug"] is None
+    assert ret["instructions"][0].startswith("Definition: Find the proteins.\n") and ret["instructions"][0].endswith("Protein: [PROT]")
+    # batching shifts the slot lists of the later prompts
+    b = IU.create_batched_input_retrieval(["d1", "d2"], da, instruction_source_dataset="disgenet")
+    assert b["input"]["seq"] == [[0], [1]] and b["input"]["text"] == [[0, 1], [2, 3]] and len(b["instructions"]) == 2
+    # context augmentation interleaves the proteins' functional descriptions
+    cap2 = IU.create_caption_input_simple([530], da, instruction_source_dataset="uniprot", disease_context_augmentation=True)
+    assert cap2["data"]["text"] == ["Context: function of protein 5", "uniprot text A 5", "Context: function of protein 530"]
+    assert cap2["instructions"][0].count("[EXT]") == 3
+
+
+def test_perturbation_and_seed_helpers():
+    import numpy as np
+    from procyon.data.inference_utils import desc_perturbation, perturb_by_words
+    from procyon.training.train_utils import set_seed
+    s = " ".join(f"w{i}" for i in range(40))
+    out = perturb_by_words(s, np.random.default_rng(0), 0.25).split()
+    assert len(out) == 30 and out == sorted(out, key=lambda w: int(w[1:]))
+    d = desc_perturbation(s, lambda x: len(x.split()), num_perturbations=3, perturbation_pct=0.1, seed=1)
+    assert d == {"perturb_0": 36, "perturb_1": 36, "perturb_2": 36}
+    set_seed(7); a = torch.rand(3); set_seed(7); b = torch.rand(3)
+    assert torch.equal(a, b)
+
+
+def test_argument_classes_unpickle_under_the_reference_paths(tmp_path):
+    """model_args.pt / data_args.pt hold pickled instances of procyon.training.training_args_IT.{ModelArgs,DataArgs}"""
+    from procyon.training.training_args_IT import DataArgs, ModelArgs
+    m = ModelArgs(protein_pooling_opt="mean", ret_token_access="last")
+    m.some_training_only_field = 3          # instances carry every field of the run, declared here or not
+    torch.save(m, tmp_path / "model_args.pt")
+    torch.save(DataArgs(data_dir="/x"), tmp_path / "data_args.pt")
+    back = torch.load(tmp_path / "model_args.pt", weights_only=False)
+    assert isinstance(back, ModelArgs) and back.protein_pooling_opt == "mean" and back.some_training_only_field == 3
+    assert torch.load(tmp_path / "data_args.pt", weights_only=False).data_dir == "/x"
+
+
+def test_residue_tokeniser_matches_the_oracle_and_truncate_strategy():
+    from oracle import procyon_ref as PR
+    from procyon.data.data_utils import ESM_ALPHABET, convert_batch_protein
+    from procyon_amd.sequences import split_or_truncate_long_seq, tokenize_proteins
+    seqs = ["MKTAYIAKQR", "ACDEFGHIKLMNPQRSTVWYXBUZO.-", "J", ""]
+    assert torch.equal(tokenize_proteins(seqs), PR.convert_batch_protein(seqs))
+    bc = ESM_ALPHABET.get_batch_converter()
+    toks = convert_batch_protein([1, 0], False, bc, seqs, None, ESM_ALPHABET)
+    assert torch.equal(toks, PR.convert_batch_protein([seqs[1], seqs[0]]))
+    pre = [tokenize_proteins([s])[0] for s in seqs[:2]]
+    assert convert_batch_protein([0, 1], True, None, None, pre, ESM_ALPHABET, max_protein_len=8).shape == (2, 8)
+    t = tokenize_proteins(["A" * 30, "C" * 5])
+    new, keys, eos = split_or_truncate_long_seq(t, 1, 2, "truncate", 10)
+    assert new.shape == (2, 12) and new[0, -1] == 2 and new[1, 6] == 2 and keys is None and eos is None
+    new, keys, eos = split_or_truncate_long_seq(t, 1, 2, "split", 10)
+    ref_new, ref_keys, ref_eos = PR.batched_split_long_seq(t, max_protein_len=10)
+    assert torch.equal(new, ref_new) and torch.equal(keys, ref_keys) and eos == ref_eos
+
+
+def test_zero2_shard_merge_and_lora_fold(tmp_path):
+    """a DeepSpeed ZeRO-2 checkpoint directory written by an independent sharder (flat fp32 groups, padded to 2 x world, cut
+    into equal slices; frozen parameters whole; a buffer; tied weights) merges back to the original tensors"""
+    from collections import OrderedDict
+    from procyon_amd.checkpoint import get_fp32_state_dict_from_zero_checkpoint, merge_lora
+    g = torch.Generator().manual_seed(0)
+    world = 4
+    groups = [OrderedDict(a=torch.randn(7, 3, generator=g), b=torch.randn(5, generator=g)),
+              OrderedDict(c=torch.randn(2, 2, 2, generator=g), tied_src=torch.randn(6, generator=g))]
+    frozen = {"frozen.w": torch.randn(3, 3, generator=g)}
+    tag = "global_step12"
+    d = tmp_path / tag
+    d.mkdir()
+    (tmp_path / "latest").write_text(tag)
+    flats = []
+    for grp in groups:
+        flat = torch.cat([t.reshape(-1) for t in grp.values()])
+        pad = (-flat.numel()) % (2 * world)
+        flats.append(torch.cat([flat, torch.zeros(pad)]).chunk(world))
+    for r in range(world):
+        torch.save({"optimizer_state_dict": {"zero_stage": 2, "partition_count": [world, world],
+                                             "single_partition_of_fp32_groups": [f[r].clone() for f in flats]}},
+                   d / f"bf16_zero_pp_rank_{r}_mp_rank_00_optim_states.pt")
+    torch.save({"module": {"buf": torch.arange(4).to(torch.bfloat16)}, "buffer_names": ["buf"],
+                "param_shapes": [OrderedDict((k, v.shape) for k, v in grp.items()) for grp in groups],
+                "shared_params": [["tied_dst", "tied_src"]], "frozen_param_shapes": {k: v.shape for k, v in frozen.items()},
+                "frozen_param_fragments": frozen, "ds_version": "0.12.4"}, d / "mp_rank_00_model_states.pt")
+    sd = get_fp32_state_dict_from_zero_checkpoint(str(tmp_path))
+    for grp in groups:
+        for k, v in grp.items():
+            assert torch.equal(sd[k], v), k
+    assert torch.equal(sd["frozen.w"], frozen["frozen.w"]) and torch.equal(sd["tied_dst"], sd["tied_src"])
+    assert sd["buf"].dtype == torch.float32 and sd["buf"].tolist() == [0, 1, 2, 3]
+    os.remove(d / "bf16_zero_pp_rank_3_mp_rank_00_optim_states.pt")
+    with pytest.raises(ValueError):
+        get_fp32_state_dict_from_zero_checkpoint(str(tmp_path))
+    # PEFT-named checkpoint: W += (alpha / r) B A, adapter tensors removed, names restored
+    W, A, B = torch.randn(6, 4, generator=g), torch.randn(2, 4, generator=g), torch.randn(6, 2, generator=g)
+    out = merge_lora({"text_encoder.model.base_model.model.model.layers.0.self_attn.q_proj.weight": W,
+                      "text_encoder.model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight": A,
+                      "text_encoder.model.base_model.model.model.layers.0.self_attn.q_proj.lora_B.default.weight": B,
+                      "text_encoder.model.base_model.model.model.norm.weight": torch.ones(4)}, lora_alpha=4)
+    assert set(out) == {"text_encoder.model.model.layers.0.self_attn.q_proj.weight", "text_encoder.model.model.norm.weight"}
+    assert torch.allclose(out["text_encoder.model.model.layers.0.self_attn.q_proj.weight"], W + 2.0 * (B @ A))
