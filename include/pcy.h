@@ -41,6 +41,9 @@ int pcy_abi_version(void);
  * (0: 128x128 tiles, 1: 64x64, 2: 256x256, 3: 256x256 persistent (ESM fc1 + GELU), 4: split-K, 5: fp8 256x256).  Parity
  * tests use it to assert that they reach the kernel they claim to test. */
 unsigned long long pcy_debug_dispatch_count(int kind);
+/* Test / profiling instrumentation (PCY_PIPE_TRACE=1 in the environment): 100 MHz wall-clock stamps {entry, input ready, compute done,
+ * flag raised} of workgroup 0 of every stage of the last pipelined decode step; returns the number of words copied to `out`. */
+int pcy_debug_pipe_trace(pcy_ctx*, unsigned long long* out, int max_words);
 const char* pcy_last_error(void);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream */
 int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out);
@@ -85,6 +88,16 @@ int pcy_pool(pcy_ctx*, const void* hidden, int d, const int32_t* seg, const int3
  * sims[Q,N] = F.normalize(query) @ F.normalize(targets)^T in bf16 (norm rounded to bf16, then the division, then an
  * fp32-accumulating matmul rounded once).  D must be a multiple of 64. */
 int pcy_retrieval_scores(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, void* sims_out);
+
+/* ---- the one collective of the path: all-gather of the per-rank embedding blocks over RCCL / xGMI --------------------------
+ * (reference pattern: training/trainIT.py:1594-1610, torch.distributed.all_gather of the shards of SequentialDistributedSampler).
+ * One rank calls pcy_comm_unique_id (128 bytes) and distributes the id by any host channel (torch.distributed's store, MPI,
+ * a file); every rank then calls pcy_comm_init.  pcy_allgather: recvbuf [nranks * bytes] = every rank's sendbuf [bytes] in
+ * rank order, enqueued on the context's stream.  RCCL is dlopen'ed at first use (no link-time dependency). */
+int pcy_comm_unique_id(void* id128);
+int pcy_comm_init(pcy_ctx*, int nranks, int rank, const void* id128, void** comm_out);
+void pcy_comm_destroy(void* comm);
+int pcy_allgather(pcy_ctx*, void* comm, const void* sendbuf, void* recvbuf, size_t bytes);
 
 /* Retrieval ranking (data/inference_utils.py:921-978 `get_proteins_from_embedding`): the same similarities, then per query the
  * k best targets in stable descending order (ties: the lower index first; torch.argsort leaves them open) -> idx_out [Q,k]

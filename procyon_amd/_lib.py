@@ -66,6 +66,7 @@ class BeamState(C.Structure):
 SIGNATURES = {
     "pcy_abi_version": (ci, []),
     "pcy_debug_dispatch_count": (C.c_ulonglong, [ci]),
+    "pcy_debug_pipe_trace": (ci, [vp, C.POINTER(C.c_ulonglong), ci]),
     "pcy_last_error": (C.c_char_p, []),
     "pcy_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "pcy_ctx_destroy": (None, [vp]),
@@ -82,6 +83,10 @@ SIGNATURES = {
     "pcy_attn_decode": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci]),
     "pcy_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
     "pcy_retrieval_scores": (ci, [vp, vp, ci, vp, ci, ci, vp]),
+    "pcy_comm_unique_id": (ci, [vp]),
+    "pcy_comm_init": (ci, [vp, ci, ci, vp, C.POINTER(vp)]),
+    "pcy_comm_destroy": (None, [vp]),
+    "pcy_allgather": (ci, [vp, vp, vp, vp, C.c_size_t]),
     "pcy_retrieval_topk": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp]),
     "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),

@@ -182,11 +182,18 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int K
 //     w, w + n_waves, ...; the host sizes the grid so that every wave gets the same number of units
 //   * the first batch of weight loads is issued BEFORE the x-staging / RMSNorm prologue, and each later batch
 //     (16 x 16 B per lane) is issued before the previous one is consumed (two register sets, static indexing)
-template <int NB, int EPI, bool RMS, int R>
-__global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int units) {
+// PIPE: a stage of the software-pipelined decode step (PcyPipe, pcy_common.h): the first two weight batches are requested, THEN
+// the workgroup waits for the producer stage's flags, reads x (and the residual) with L1-bypassing loads and runs as usual;
+// outputs are written through and the workgroup's flag follows.  Two such launches share every CU (the next stage prefetches
+// while this one streams), so a PIPE instantiation is capped at 128 VGPRs (four waves per SIMD): batches of 8 instead of 16
+// loads per lane.  Per output row the k order of the accumulation, the reduction tree and the rounding points are unchanged:
+// bit-identical to the unpipelined launch.
+template <int NB, int EPI, bool RMS, int R, bool PIPE = false>
+__global__ __launch_bounds__(512, PIPE ? 4 : 2) void gemv_stream_kernel(PcyGemvArgs a, int units) {
   constexpr bool DIRECTX = PCY_GEMV_DIRECTX && !RMS;
   constexpr int RW = (EPI == EPI_SWIGLU) ? 2 * R : R;
-  constexpr int UN = 16 / RW;
+  constexpr int UN = (PIPE ? 8 : 16) / RW;
+  static_assert(!PIPE || NB == 1, "the pipelined step is batch 1");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                          // [NB][K]
   float* red = reinterpret_cast<float*>(smem + (size_t)NB * a.K * 2);    // [waves per block]
@@ -262,11 +269,12 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
             v = rbf(silu_f(g)) * up;
           } else {
             v = rbf(acc[i][b] + (a.bias ? bf2f(a.bias[n]) : 0.f));
-            if (EPI == EPI_RESID) v = rbf(v + bf2f(a.resid[(size_t)b * a.ldy + n]));
+            if (EPI == EPI_RESID) v = rbf(v + bf2f(PIPE ? ld_bf16_agent(a.resid + (size_t)b * a.ldy + n) : a.resid[(size_t)b * a.ldy + n]));
             if (EPI == EPI_GELU_ERF) v = rbf(gelu_erf_f(v));
             if (EPI == EPI_GELU_ESM) v = gelu_esm_chain(v);
           }
-          a.y[(size_t)b * a.ldy + n] = f2bf(v);
+          if (PIPE && !a.pipe_out_plain) st_bf16_agent(a.y + (size_t)b * a.ldy + n, f2bf(v));
+          else a.y[(size_t)b * a.ldy + n] = f2bf(v);
         }
       }
     }
@@ -287,37 +295,64 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
   // waits for.  x (and the norm weight) go out FIRST -- a few KiB, back after one round trip -- then TWO weight batches
   // (32 x 16 B per lane); the RMSNorm / LDS staging then runs while the weights stream, instead of waiting behind the first
   // batch and leaving the second one to be requested only after it (qkv 12.46 -> 12.22 us, down 21.8 -> 21.0 us, decode step 3.27 -> 3.25 ms).
-  constexpr int MAXX = RMS ? 4 : 8;
-  const bool xfirst = NB == 1 && !DIRECTX && K <= MAXX * nthr * 8 && a.plain_loads != 2;
+  constexpr int MAXX = PIPE ? (RMS ? 2 : 4) : (RMS ? 4 : 8);
+  const bool xfirst = PIPE || (NB == 1 && !DIRECTX && K <= MAXX * nthr * 8 && a.plain_loads != 2);   // (PIPE: the launcher checks K)
   uint4 xr[MAXX], gr[RMS ? MAXX : 1];
   int u1 = u, it1 = 0;
   bool have1 = false;
   if (xfirst) {
+    unsigned epoch = 0;
+    if (PIPE) {
+      // weights first: they depend on nothing.  x exists only once the producer stage has published.
+      epoch = pipe_epoch(a.pipe);
+      if (have) issue(u, 0, wa);
+      next_pos(u, 0, u1, it1);
+      have1 = have && u1 < units;
+      if (have1) issue(u1, it1, wb);
+      pipe_wait(a.pipe, epoch);
 #pragma unroll
-    for (int i = 0; i < MAXX; ++i) {
-      const int k = (threadIdx.x + i * nthr) * 8;
-      if (k < K) {
-        xr[i] = *reinterpret_cast<const uint4*>(a.x + k);
-        if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
+      for (int i = 0; i < MAXX; ++i) {
+        const int k = (threadIdx.x + i * nthr) * 8;
+        if (k < K) {
+          xr[i] = ld16_agent(a.x + k);
+          if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
+        }
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXX; ++i) {
+        const int k = (threadIdx.x + i * nthr) * 8;
+        if (k < K) {
+          xr[i] = *reinterpret_cast<const uint4*>(a.x + k);
+          if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
+        }
+      }
+      if (have) issue(u, 0, wa);
+      next_pos(u, 0, u1, it1);
+      have1 = have && u1 < units;
+      if (have1) issue(u1, it1, wb);
     }
-    if (have) issue(u, 0, wa);
-    next_pos(u, 0, u1, it1);
-    have1 = have && u1 < units;
-    if (have1) issue(u1, it1, wb);
     float rs = 1.f;
     if (RMS) {
-      float ss = 0.f;
+      // Sum of squares in an order that does not depend on the workgroup size (the pipelined and the plain launch use
+      // different ones and must agree to the bit): per 8-element chunk in element order into LDS, then every wave adds the
+      // chunk sums l, l + 64, ... per lane and folds the 64 lanes -- the same value in every wave, one barrier.
+      float* csum = red + 16;                                   // [K / 8]
 #pragma unroll
       for (int i = 0; i < MAXX; ++i) {
         const int k = (threadIdx.x + i * nthr) * 8;
         if (k < K) {
           const uint32_t w4[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+          float ss = 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
+          csum[k >> 3] = ss;
         }
       }
-      ss = block_sum_rt(ss, red, wpb);
+      __syncthreads();
+      float ss = 0.f;
+      for (int c = lane; c < (K >> 3); c += 64) ss += csum[c];
+      ss = wave_sum(ss);
       rs = rsqrtf(ss / (float)K + a.rms_eps);
     }
 #pragma unroll
@@ -360,6 +395,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
       PCY_GEMV_STEP2(wb, wa)
     }
 #undef PCY_GEMV_STEP2
+    if (PIPE) pipe_done(a.pipe, epoch);
     return;
   }
   if (have) issue(u, 0, wa);
@@ -446,9 +482,32 @@ void launch_stream(hipStream_t s, const PcyGemvArgs& a) {
   const int units = (a.N + R - 1) / R;
   int blocks, wpb;
   pick_grid(units, blocks, wpb);
-  const size_t smem = (size_t)NB * a.K * 2 + 64;
+  const size_t smem = (size_t)NB * a.K * 2 + 64 + (size_t)(a.K / 8) * 4;
   hipLaunchKernelGGL((gemv_stream_kernel<NB, EPI, RMS, R>), dim3(blocks), dim3(wpb * 64), smem, s, a, units);
 }
+
+// pipelined stage: one workgroup per CU of `pipe_waves` waves (a second launch shares every CU), rows dealt out so that every
+// wave gets the same number of units where the row count allows
+inline void pipe_grid(const PcyGemvArgs& a, int R, int& blocks, int& wpb, int& units) {
+  units = (a.N + R - 1) / R;
+  wpb = a.pipe_waves;
+  if (units <= GEMV_CUS * wpb) { blocks = (units + wpb - 1) / wpb; return; }
+  blocks = GEMV_CUS;
+  double best = 1e30;
+  for (int w = a.pipe_waves < 4 ? a.pipe_waves : 4; w <= a.pipe_waves; ++w) {   // e.g. gate/up: 3584 units = 256 x 7 waves x 2
+    const int waves = GEMV_CUS * w;
+    const double cost = (double)((units + waves - 1) / waves) * waves / units - 1e-4 * w;
+    if (cost < best) { best = cost; wpb = w; }
+  }
+}
+template <int EPI, bool RMS, int R>
+void launch_stream_pipe(hipStream_t s, const PcyGemvArgs& a) {
+  int blocks, wpb, units;
+  pipe_grid(a, R, blocks, wpb, units);
+  const size_t smem = (size_t)a.K * 2 + 64 + (size_t)(a.K / 8) * 4;
+  hipLaunchKernelGGL((gemv_stream_kernel<1, EPI, RMS, R, true>), dim3(blocks), dim3(wpb * 64), smem, s, a, units);
+}
+inline int pipe_R(const PcyGemvArgs& a) { return a.epi == EPI_SWIGLU ? 4 : 2; }
 
 template <int NB, int EPI, bool RMS>
 void launch_nb(hipStream_t s, const PcyGemvArgs& a) {
@@ -480,136 +539,8 @@ void launch_epi(hipStream_t s, const PcyGemvArgs& a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Batched decode (4 < B <= 32, e.g. beam 20): skinny MFMA GEMV.  Weights are still read exactly once; the batch rides
-// on the MFMA N dimension instead of re-streaming W per group of 4 rows.
-//   * workgroup = 16 output rows (32 weight rows for SwiGLU: its gate tile + up tile); the 4 waves split K in quarters
-//   * per 128-k super-step a lane loads 64 contiguous bytes of its weight row (A fragments, k-slots remapped so that the
-//     4 MFMA k-steps of the super-step are the lane's 4 consecutive 16-B pieces) and the matching pieces of x[b] straight
-//     from L2 in B-fragment layout -- no LDS on the operand path
-//   * the four K-quarter partial tiles are summed through LDS in fixed order by wave 0, which runs the fused epilogue
-template <int EPI, int BT>
-__global__ __launch_bounds__(256) void gemv_mfma_kernel(PcyGemvArgs a) {
-  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
-  __shared__ float part[3][RT][BT][64][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int K = a.K;
-  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
-  const int r0 = blockIdx.x * 16 * RT;
-  const int kq = K >> 2;                    // K % 512 == 0
-  const int kbeg = wave * kq, kend = kbeg + kq;
-  const bf16_t* wp[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    int r = r0 + rt * 16 + fr;
-    r = r < nrows ? r : nrows - 1;
-    wp[rt] = a.W + (size_t)r * K + fq * 32;
-  }
-  const bf16_t* xp[BT];
-#pragma unroll
-  for (int bt = 0; bt < BT; ++bt) {
-    int b = bt * 16 + fr;
-    b = b < a.B ? b : a.B - 1;
-    xp[bt] = a.x + (size_t)b * a.ldx + fq * 32;
-  }
-  f32x4 acc[RT][BT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // Software pipeline over 128-k super-steps with two register sets: the loads of step i+1 (and i+2) are in flight while
-  // step i's MFMAs run.  Without it every iteration exposed a full memory round trip (the K quarter of `down` is 28
-  // super-steps: 35 us for 117 MB).
-  auto load_set = [&](int k, bf16x8 (&wf)[RT][4], bf16x8 (&xf)[BT][4]) {
-    const bool ok = k < kend;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (ok) { const uint4 v = ldg_nt(wp[rt] + k + j * 8); wf[rt][j] = __builtin_bit_cast(bf16x8, v); }
-        else wf[rt][j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      }
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        xf[bt][j] = ok ? *reinterpret_cast<const bf16x8*>(xp[bt] + k + j * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  };
-  auto mma_set = [&](const bf16x8 (&wf)[RT][4], const bf16x8 (&xf)[BT][4]) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[bt][j], acc[rt][bt], 0, 0, 0);
-  };
-  {
-    bf16x8 wa[RT][4], xa[BT][4], wb[RT][4], xb[BT][4];
-    load_set(kbeg, wa, xa);
-    load_set(kbeg + 128, wb, xb);
-    for (int k0 = kbeg; k0 < kend; k0 += 256) {
-      mma_set(wa, xa);
-      load_set(k0 + 256, wa, xa);
-      mma_set(wb, xb);
-      load_set(k0 + 384, wb, xb);
-    }
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[wave - 1][rt][bt][lane][r] = acc[rt][bt][r];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[rt][bt][r] = ((acc[rt][bt][r] + part[0][rt][bt][lane][r]) + part[1][rt][bt][lane][r]) + part[2][rt][bt][lane][r];
-  // D[n = fq*4 + r][b = fr]
-#pragma unroll
-  for (int bt = 0; bt < BT; ++bt) {
-    const int b = bt * 16 + fr;
-    if (b >= a.B) continue;
-    if (EPI == EPI_SWIGLU) {
-      const int f = (r0 >> 5) * 16 + fq * 4;
-      if (f >= a.N) continue;
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = rbf(silu_f(rbf(acc[0][bt][r]))) * rbf(acc[RT - 1][bt][r]);
-      *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
-    } else {
-      const int n = r0 + fq * 4;
-      if (n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = (n + r) < a.N ? n + r : a.N - 1;
-        v[r] = rbf(acc[0][bt][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
-        if (EPI == EPI_RESID) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)b * a.ldy + nn]));
-        if (EPI == EPI_GELU_ERF) v[r] = rbf(gelu_erf_f(v[r]));
-        if (EPI == EPI_GELU_ESM) v[r] = gelu_esm_chain(v[r]);
-      }
-      if (n + 3 < a.N && (a.ldy & 3) == 0) {
-        *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.N) a.y[(size_t)b * a.ldy + n + r] = f2bf(v[r]);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Batched decode, second generation (B = 5..32 rows): the activations are the expensive operand of gemv_mfma_kernel --
-// every 16-row workgroup re-reads all of x from L2 (x : W traffic = 2 : 1, half of a wave's loads).  Here a workgroup is
+// Batched decode (B = 5..32 rows; e.g. beam 20): skinny MFMA GEMV.  Weights are read exactly once; the batch rides on the
+// MFMA N dimension.  Were every 16-row workgroup to re-read all of x from L2, x : W traffic would be 2 : 1; here a workgroup is
 // 4 waves x 16 output rows (32 weight rows for SwiGLU) over the SAME K range: x travels global -> LDS once per
 // workgroup in 512-k chunks (LDS-DMA, double buffered) and is shared by the four waves (x : W = 1 : 2), the vector
 // loads carry weights only.  K is split over gridDim.y workgroups when N/64 alone cannot fill the chip (o, down, qkv);
@@ -836,8 +767,7 @@ __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int kspl
 template <int EPI>
 void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
   const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
-  static const int gen = [] { const char* e = getenv("PCY_GEMV_MFMA_GEN"); return e ? atoi(e) : 2; }();
-  if (gen == 2 && (a.ldx % 8) == 0) {
+  {
     const int rpw = (EPI == EPI_SWIGLU) ? 32 : 16;          // weight rows per wave
     const int bx = (nrows + 4 * rpw - 1) / (4 * rpw);
     // K split: enough workgroups for two per CU; only with a plain / residual epilogue and a workspace
@@ -861,18 +791,28 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     }
     return;
   }
-  const int rpb = (EPI == EPI_SWIGLU) ? 32 : 16;
-  const int blocks = (nrows + rpb - 1) / rpb;
-  if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma_kernel<EPI, 1>), dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemv_mfma_kernel<EPI, 2>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 }  // namespace
 
+int pcy_gemv_pipe_blocks(const PcyGemvArgs& a) {
+  int blocks, wpb, units;
+  pipe_grid(a, pipe_R(a), blocks, wpb, units);
+  return blocks;
+}
+
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
-  static const int plain = [] { const char* e = getenv("PCY_GEMV_PLAIN"); return e ? atoi(e) : 0; }();
   PcyGemvArgs a0 = a00;
-  a0.plain_loads = plain;
+  a0.plain_loads = 0;
+  if (a0.pipe.my_flags != nullptr) {   // stage of the pipelined decode step: batch 1, x fits the per-thread staging registers
+    const bool rms = a0.rms_w != nullptr;
+    switch (a0.epi) {
+      case EPI_STORE: rms ? launch_stream_pipe<EPI_STORE, true, 2>(s, a0) : launch_stream_pipe<EPI_STORE, false, 2>(s, a0); break;
+      case EPI_RESID: launch_stream_pipe<EPI_RESID, false, 2>(s, a0); break;
+      default: launch_stream_pipe<EPI_SWIGLU, true, 4>(s, a0); break;
+    }
+    return;
+  }
   // B > 4 on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused RMSNorm prologue is a
   // B <= 4 feature)
   if (a0.B > 4 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {

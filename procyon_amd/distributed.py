@@ -10,9 +10,54 @@ the evident intent -- W distinct slots in rank order -- is what is built).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
+
+
+class PcyComm:
+    """RCCL communicator behind the C ABI (`pcy_comm_init` / `pcy_allgather`, include/pcy.h), bootstrapped over an existing
+    torch.distributed group: rank 0 draws the unique id, the group's host channel broadcasts it."""
+
+    def __init__(self, group=None):
+        import torch.distributed as td
+        from . import _lib as L
+        from .engine import Context
+        self.ctx = Context.get()
+        self.lib = self.ctx.lib
+        self.rank, self.world = td.get_rank(group), td.get_world_size(group)
+        idbuf = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(self.lib.pcy_comm_unique_id(idbuf), "pcy_comm_unique_id")
+        box = [idbuf.raw]
+        td.broadcast_object_list(box, src=td.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.h = C.c_void_p()
+        L.check(self.lib.pcy_comm_init(self.ctx.h, self.world, self.rank, C.create_string_buffer(box[0], 128), C.byref(self.h)), "pcy_comm_init")
+
+    def all_gather(self, local):
+        """[n, D] on this rank -> [world * n, D] in rank order (one ncclAllGather on the engine's stream)"""
+        from . import _lib as L
+        local = local.contiguous()
+        full = torch.empty(self.world * local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
+        L.check(self.lib.pcy_allgather(self.ctx.h, self.h, C.c_void_p(local.data_ptr()), C.c_void_p(full.data_ptr()),
+                                       local.numel() * local.element_size()), "pcy_allgather")
+        return full
+
+    def close(self):
+        if self.h:
+            self.lib.pcy_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+_comms = {}
+
+
+def _comm_for(group):
+    key = id(group)
+    if key not in _comms:
+        _comms[key] = PcyComm(group)
+    return _comms[key]
 
 
 def shard_indices(n_total: int, rank: int, world: int):
@@ -50,8 +95,11 @@ def embed_sharded(model_or_fn, token_fn, n_total, batch_size=None, rank=None, wo
         idx = mine[s:s + batch_size]
         outs.append(fn(token_fn(idx)))
     local = torch.cat(outs, 0).contiguous()
-    if world == 1:
+    if world == 1 and not dist:
         return local[:n_total]
+    if local.is_cuda and td.get_backend(group) == "nccl":
+        # the one collective of the path, through the C ABI (RCCL over xGMI) on the engine's stream
+        return _comm_for(group).all_gather(local)[:n_total]
     full = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
-    td.all_gather_into_tensor(full, local, group=group)   # the one collective of the path
+    td.all_gather_into_tensor(full, local, group=group)   # host tensors (gloo): torch's collective
     return full[:n_total]

@@ -1,0 +1,113 @@
+"""Synthetic workloads of BASELINE.json configs[3] and configs[4] through the model-level API (`UnifiedProCyon.generate` /
+`.forward`), shared by bench.py's `configs` block, tools/run_configs.py and the full-size GPU tests.
+
+config 4  batch 32, residue lengths uniform-int in [256, 2048] (seed 7; proteins > 1024 residues are split into chunks and
+          pooled jointly), 512 greedy tokens; (4a) every prompt 512 tokens, (4b) ragged prompts, T uniform-int in [128, 512],
+          left-padded (reference quirks Q1 / Q2 apply: SURVEY App. B)
+config 5  256 (protein, peptide) pairs as six-slot QA prompts (one positive + one negative in-context pair + the query pair,
+          T ~ 450): P(yes), P(no) at the last [ANSWER]; bf16 weights and the fp8 (e4m3, MX MFMA) weight path
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import synth
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _words(n, salt):
+    return [f"w{(salt + 31 * i) % 50000}" for i in range(n)]
+
+
+def config4_inputs(ragged=False, rows=32, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(256, 2049, (rows,), generator=g).tolist()
+    prot = synth.protein_tokens(lens, seed=seed)
+    plen = torch.randint(128, 513, (rows,), generator=g).tolist() if ragged else [512] * rows
+    instr = []
+    for b in range(rows):
+        n = plen[b] - 2                      # words + <|protein|> + [ANSWER]
+        instr.append(" ".join(_words(n // 2, 17 * b) + ["<|protein|>"] + _words(n - n // 2, 13 * b + 5)) + " [ANSWER]")
+
+    def make():
+        return {"data": {"seq": prot.clone(), "seq_idx": torch.arange(rows), "text": [], "drug": None},
+                "input": {"seq": [[b] for b in range(rows)], "text": [[] for _ in range(rows)], "drug": None},
+                "target": {"seq": None, "text": None, "drug": None}, "instructions": list(instr)}
+    return make, lens, plen
+
+
+def run_config4(model, new_tokens=512, ragged=False, rows=32):
+    make, lens, plen = config4_inputs(ragged, rows)
+    model.generate(make(), max_len=8, method="greedy")
+    _sync()
+    t0 = time.perf_counter()
+    toks, *_ = model.generate(make(), max_len=new_tokens, method="greedy")
+    _sync()
+    dt = time.perf_counter() - t0
+    assert toks.shape == (rows, 1, new_tokens)
+    return {"rows": rows, "residues_min_max": [min(lens), max(lens)], "protein_chunks": int(sum((n + 1023) // 1024 for n in lens)),
+            "prompt_tokens": "ragged %d-%d, left-padded" % (min(plen), max(plen)) if ragged else 512, "new_tokens": new_tokens,
+            "seconds": round(dt, 3), "tokens_per_s": round(rows * new_tokens / dt, 1)}
+
+
+def config5_inputs(pairs=256, chunk=64, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    plen = [805] + [int(x) for x in torch.randint(8, 41, (pairs + 2,), generator=g)]   # receptor + peptides
+    prot = synth.protein_tokens(plen, seed=11)
+    tmpl = (" ".join(_words(140, 1)) + " <|protein|> binds <|protein|> ? [ANSWER] yes " + " ".join(_words(140, 2)) +
+            " <|protein|> binds <|protein|> ? [ANSWER] no " + " ".join(_words(140, 3)) + " <|protein|> binds <|protein|> ? [ANSWER]")
+
+    def make(lo):
+        return {"data": {"seq": prot.clone(), "seq_idx": torch.arange(prot.shape[0]), "text": [], "drug": None},
+                "input": {"seq": [[0, 1, 0, 2, 0, 3 + lo + i] for i in range(chunk)], "text": [[] for _ in range(chunk)], "drug": None},
+                "target": {"seq": None, "text": None, "drug": None}, "instructions": [tmpl] * chunk}
+    return make, len(tmpl.split())
+
+
+def score_pairs(model, pairs=256, chunk=64):
+    """-> (P(yes), P(no)) [pairs, 2] fp32 and a 1/61 sample of every answer-row logit vector"""
+    make, _ = config5_inputs(pairs, chunk)
+    ys, ls = [], []
+    for lo in range(0, pairs, chunk):
+        lg = model.forward(make(lo), retrieval=False)["outputs"].logits[:, 0].float()
+        p = lg.softmax(-1)
+        ys.append(torch.stack([p[:, model.yes_token], p[:, model.no_token]], 1))
+        ls.append(lg[:, ::61].clone())
+    return torch.cat(ys), torch.cat(ls)
+
+
+def run_config5(model, pairs=256, chunk=64, fp8=True):
+    """pairs/s with bf16 weights and on the fp8 weight path, algorithmic TFLOP/s of the Llama prefill part (2 * params * tokens
+    + attention), and how far the fp8 path's answers are from the bf16 path's"""
+    eng = model.text_encoder.engine
+    cfg = eng.cfg
+    _, T = config5_inputs(pairs, chunk)
+    out = {}
+    for mode in (("bf16", "fp8") if fp8 else ("bf16",)):
+        if mode == "fp8":
+            eng.quantize_fp8()
+        score_pairs(model, chunk, chunk)
+        _sync()
+        t0 = time.perf_counter()
+        y, lg = score_pairs(model, pairs, chunk)
+        _sync()
+        out[mode] = (y.cpu(), time.perf_counter() - t0, lg.cpu())
+    if fp8:
+        eng.set_fp8(False)
+    per_tok = 2 * cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d + 3 * cfg.d * cfg.ffn)
+    flop = pairs * (per_tok * T + 4 * cfg.n_layers * cfg.n_heads * cfg.head_dim * T * T / 2)
+    res = {"pairs": pairs, "slots_per_prompt": 6, "prompt_tokens": T, "bf16_pairs_per_s": round(pairs / out["bf16"][1], 1),
+           "bf16_prefill_TFLOPs": round(flop / out["bf16"][1] / 1e12, 1), "bf16_mfma_frac_of_2.5PF": round(flop / out["bf16"][1] / 2.5e15, 3)}
+    if fp8:
+        y16, y8, l16, l8 = out["bf16"][0], out["fp8"][0], out["bf16"][2], out["fp8"][2]
+        res.update({"fp8_pairs_per_s": round(pairs / out["fp8"][1], 1), "fp8_prefill_TFLOPs": round(flop / out["fp8"][1] / 1e12, 1),
+                    "fp8_mfma_frac_of_5PF": round(flop / out["fp8"][1] / 5e15, 3),
+                    "answer_logits_rel_err_fp8_vs_bf16": round(float((l8 - l16).norm() / l16.norm()), 4),
+                    "yes_no_agreement_fp8_vs_bf16": round(float(((y16[:, 0] > y16[:, 1]) == (y8[:, 0] > y8[:, 1])).float().mean()), 4),
+                    "mean_abs_dP_yes": float((y8[:, 0] - y16[:, 0]).abs().mean())})
+    return res
