@@ -41,9 +41,6 @@ int pcy_abi_version(void);
  * (0: 128x128 tiles, 1: 64x64, 2: 256x256, 3: 256x256 persistent (ESM fc1 + GELU), 4: split-K, 5: fp8 256x256).  Parity
  * tests use it to assert that they reach the kernel they claim to test. */
 unsigned long long pcy_debug_dispatch_count(int kind);
-/* Test / profiling instrumentation (PCY_PIPE_TRACE=1 in the environment): 100 MHz wall-clock stamps {entry, input ready, compute done,
- * flag raised} of workgroup 0 of every stage of the last pipelined decode step; returns the number of words copied to `out`. */
-int pcy_debug_pipe_trace(pcy_ctx*, unsigned long long* out, int max_words);
 const char* pcy_last_error(void);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream */
 int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out);

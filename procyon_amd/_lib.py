@@ -66,7 +66,6 @@ class BeamState(C.Structure):
 SIGNATURES = {
     "pcy_abi_version": (ci, []),
     "pcy_debug_dispatch_count": (C.c_ulonglong, [ci]),
-    "pcy_debug_pipe_trace": (ci, [vp, C.POINTER(C.c_ulonglong), ci]),
     "pcy_last_error": (C.c_char_p, []),
     "pcy_ctx_create": (ci, [ci, vp, C.POINTER(vp)]),
     "pcy_ctx_destroy": (None, [vp]),

@@ -638,34 +638,6 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
   }
 }
 
-// Decode attention as a stage of the software-pipelined step (PcyPipe): the key tiles and V rows of the cache are requested,
-// then the workgroup waits for the qkv projection's flags; output written through, one flag per workgroup.  Same body, same
-// arithmetic as attn_dec_kernel<DH, G, 16>.
-template <int DH, int G>
-__global__ __launch_bounds__(512) void attn_pipe_kernel(PcyDecAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int slices = DH / 16;
-  const unsigned epoch = pipe_epoch(a.pipe);
-  a.xepoch = epoch;
-  a.xerr = a.pipe.err;
-  a.t_plus1 = a.pipe_pos[0] + a.pipe_pos[1] * (int)epoch + 1;   // cache length of THIS step (not *pos_dev: see PcyDecAttnArgs)
-  const int unit = blockIdx.x;
-  AttnPipeHook hook{a.pipe, epoch};
-  attn_dec_body<DH, G, 16, AttnPipeHook>(a, smem, (unit / a.Hkv) % slices, unit % a.Hkv, unit / (slices * a.Hkv), hook);
-  pipe_done(a.pipe, epoch);
-}
-template <int DH, int G>
-void launch_attn_pipe(hipStream_t s, PcyDecAttnArgs a) {
-  a.o_sc1 = 1;
-  const size_t smem = attn_dec_smem_bytes(G, 16, DH, a.Tmax);
-  static size_t configured = 0;
-  if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pipe_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured = smem;
-  }
-  hipLaunchKernelGGL((attn_pipe_kernel<DH, G>), dim3((DH / 16) * a.Hkv * a.B), dim3(512), smem, s, a);
-}
-
 template <int DH, int G>
 bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch, unsigned* flags, unsigned* err,
                       unsigned* xflags) {
@@ -787,19 +759,6 @@ void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a) {
   if (a.dh == 128) launch_dec_g<128>(s, a);
   else if (a.dh == 64) launch_dec_g<64>(s, a);
   else launch_dec_g<32>(s, a);
-}
-
-int pcy_attn_pipe_blocks(const PcyDecAttnArgs& a) { return (a.dh / 16) * a.Hkv * a.B; }
-bool pcy_launch_attn_decode_pipe(hipStream_t s, const PcyDecAttnArgs& a) {
-  // half a CU's LDS at most: a second launch shares the CU
-  if (a.B != 1 || a.dh != 128 || a.pipe.my_flags == nullptr || attn_dec_smem_bytes(a.H / a.Hkv, 16, 128, a.Tmax) > 80 * 1024) return false;
-  switch (a.H / a.Hkv) {
-    case 1: launch_attn_pipe<128, 1>(s, a); return true;
-    case 2: launch_attn_pipe<128, 2>(s, a); return true;
-    case 4: launch_attn_pipe<128, 4>(s, a); return true;
-    case 8: launch_attn_pipe<128, 8>(s, a); return true;
-  }
-  return false;
 }
 
 // Fused decode attention + o projection (see attn_o_kernel).  Returns false (nothing launched) when the shape is not

@@ -18,14 +18,13 @@ namespace {
 //       key groups by DPP + LDS, rounded once -> no cross-workgroup reduction.
 struct Rope8In { uint4 a, b, c, s; };
 // elements e0..e0+7 of one head and their rotate_half partners e +- DH/2, with the cos / sin rows of the position
-// AGENT: x was written by another launch of the same (pipelined) decode step -> L1-bypassing loads
-template <int DH, bool AGENT = false>
+template <int DH>
 __device__ __forceinline__ Rope8In rope8_load(const bf16_t* __restrict__ x, const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn, int e0) {
   constexpr int HALF = DH / 2;
   const int p0 = e0 < HALF ? e0 + HALF : e0 - HALF;
   Rope8In r;
-  r.a = AGENT ? ld16_agent(x + e0) : *reinterpret_cast<const uint4*>(x + e0);
-  r.b = AGENT ? ld16_agent(x + p0) : *reinterpret_cast<const uint4*>(x + p0);
+  r.a = *reinterpret_cast<const uint4*>(x + e0);
+  r.b = *reinterpret_cast<const uint4*>(x + p0);
   r.c = *reinterpret_cast<const uint4*>(cs + e0);
   r.s = *reinterpret_cast<const uint4*>(sn + e0);
   return r;
@@ -99,16 +98,10 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // from HBM (measured: 6.8 us from the position load to the first barrier) and the prefetch overlaps nothing.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct AttnDecNoHook { static constexpr bool kAgent = false; __device__ __forceinline__ void operator()() const {} };
-// stage of the pipelined decode step: wait for the qkv projection's flags, then read q/k/v with L1-bypassing loads
-struct AttnPipeHook {
-  static constexpr bool kAgent = true;
-  PcyPipe pipe; unsigned epoch;
-  __device__ __forceinline__ void operator()() const { pipe_wait(pipe, epoch); }
-};
+struct AttnDecNoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `inputs_ready` runs after the cache rows of the first passes have been requested and before anything of the new
-// token's q/k/v is read: the pipelined decode step waits there for the projections of this layer.
+// token's q/k/v is read: the persistent decode kernel waits there for the projections of this layer.
 template <int DH, int G, int DS, typename Hook = AttnDecNoHook>
 __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* smem, const int bx, const int kvh, const int b,
                                               Hook inputs_ready = Hook()) {
@@ -141,7 +134,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
   // Vector loads return in order: the (L2-resident) q / k_new / cos / sin operands of the rope are requested BEFORE the
   // V rows and key tiles that come from HBM, otherwise the rope -- the head of the whole dependent chain -- waits for
   // every cache row first (measured: 6.8 us to the first barrier; the persistent kernel's hook has to keep its order)
-  constexpr bool kPlainInputs = !Hook::kAgent;
+  constexpr bool kPlainInputs = std::is_same<Hook, AttnDecNoHook>::value;
   static_assert((G + 1) * (DH / 8) <= NT, "one rope item per thread");
   const bool roper = tid < (G + 1) * (DH / 8);
   const int rh = tid / (DH / 8), rch = tid % (DH / 8);
@@ -185,7 +178,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     };
     // the key tiles of the first NP passes (NP x 256 keys) are all requested up front: each pass that fetched its own
     // tiles paid a full memory round trip inside the dependent chain rope -> scores -> softmax -> P.V
-    constexpr int NP = DS == 16 ? (Hook::kAgent ? 3 : 4) : 2;   // (pipelined stage: 192-VGPR budget, 768 keys up front)
+    constexpr int NP = DS == 16 ? 4 : 2;
     bf16x8 kt[NP][2][KB];
     auto load_group = [&](int j0) {
 #pragma unroll
@@ -198,7 +191,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     load_group(0);
     inputs_ready();
     // rope q (G heads) and the new key ONCE per block into LDS (bf16), then pick fragments from there
-    if (!kPlainInputs && roper) rin = rope8_load<DH, true>(rsrc, cs, sn, rch * 8);
+    if (!kPlainInputs && roper) rin = rope8_load<DH>(rsrc, cs, sn, rch * 8);
     if (roper) {
       const int hh = rh, ch = rch;
       float tmp[8];
@@ -210,8 +203,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     }
     if (bx == 0 && tid >= NT - DH / 8) {  // ... and its V
       const int ch = tid - (NT - DH / 8);
-      const bf16_t* vsrc = row + (a.H + a.Hkv + kvh) * DH + ch * 8;
-      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + ch * 8) = kPlainInputs ? *reinterpret_cast<const uint4*>(vsrc) : ld16_agent(vsrc);
+      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + ch * 8) = *reinterpret_cast<const uint4*>(row + (a.H + a.Hkv + kvh) * DH + ch * 8);
     }
     lds_barrier();
     // A operand: roped q of head `fr` (zero rows for fr >= G); new key in B-fragment layout
@@ -348,12 +340,12 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     for (int u = 0; u < UV; ++u) {
       if (j0 == 0) {   // first pass: rows fetched at kernel start; slot t comes straight from the projection
         vv[u] = vpre[u];
-        if (grp + u * NGV == t) vv[u] = kPlainInputs ? *reinterpret_cast<const uint4*>(vnew) : ld16_agent(vnew);
+        if (grp + u * NGV == t) vv[u] = *reinterpret_cast<const uint4*>(vnew);
         continue;
       }
       const int j = j0 + grp + u * NGV;
       const bf16_t* src = (j < t) ? vsl + (size_t)j * DH : vnew;   // slot t comes straight from the projection
-      vv[u] = (kPlainInputs || j < t) ? *reinterpret_cast<const uint4*>(src) : ld16_agent(src);
+      vv[u] = *reinterpret_cast<const uint4*>(src);
     }
 #pragma unroll
     for (int u = 0; u < UV; ++u) {

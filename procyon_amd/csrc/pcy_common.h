@@ -133,69 +133,6 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined decode step (batch 1): consecutive kernels of the step run on two HIP streams, so kernel n+1 is resident
-// and streams its first weight batches while kernel n is still running; the DATA dependency n -> n+1 is a per-workgroup flag
-// hand-over inside the launches (placement-independent: write-through stores + drained flag on the producer, relaxed polls +
-// L1-bypassing loads on the consumer; CDNA4 guide, Guideline 16 R1).
-//   my_flags[wg]   one word per workgroup of THIS stage = number of steps it has completed.  A workgroup derives the step's
-//                  epoch from its own word (epoch = value + 1): no shared epoch word, nothing to reset between steps, and the
-//                  two streams need no other ordering.
-//   wait_flags     the wait_n words of the producer stage; the stage may touch its input once they all read `epoch`.
-// The first and the last launches of a step run on the same stream, so consecutive steps are ordered by the stream.
-// Every spin is bounded; a time-out sets *err (checked by pcy_ctx_sync: results invalid) and lets the kernel finish.
-struct PcyPipe {
-  unsigned* my_flags;
-  const unsigned* wait_flags;
-  int wait_n;
-  unsigned* err;
-  unsigned long long* trace;   // optional (PCY_PIPE_TRACE): 100 MHz wall-clock stamps of workgroup 0: entry, input ready, done
-};
-__device__ __forceinline__ void pipe_stamp(const PcyPipe& p, int slot) {
-  if (p.trace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) p.trace[slot] = wall_clock64();
-}
-__device__ __forceinline__ unsigned pipe_epoch(const PcyPipe& p) {
-  pipe_stamp(p, 0);
-  return __hip_atomic_load(p.my_flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-}
-// all threads of the workgroup call it; returns once the producer stage has published (wave 0 polls, the others wait at the barrier)
-__device__ __forceinline__ void pipe_wait(const PcyPipe& p, unsigned epoch) {
-  if (p.wait_flags != nullptr && threadIdx.x < 64) {
-    const unsigned want = epoch;
-    unsigned spins = 0;
-    for (;;) {
-      bool ok = true;
-      for (int i = threadIdx.x; i < p.wait_n; i += 64)
-        ok = ok && (__hip_atomic_load(p.wait_flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want);
-      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 20)) {
-        if (threadIdx.x == 0 && p.err) __hip_atomic_store(p.err, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  pipe_stamp(p, 1);
-}
-// all threads: every wave's (write-through) output stores have left the CU, then ONE flag store per workgroup
-__device__ __forceinline__ void pipe_done(const PcyPipe& p, unsigned epoch) {
-  pipe_stamp(p, 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(p.my_flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  pipe_stamp(p, 3);
-}
-// 16 bytes / one bf16 written by another workgroup of the SAME step: L1-bypassing (agent-scope) loads
-__device__ __forceinline__ uint4 ld16_agent(const void* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-}
-__device__ __forceinline__ bf16_t ld_bf16_agent(const bf16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_bf16_agent(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Epilogue selectors shared by the GEMM (prefill / encoder) and GEMV (decode) kernels.
 enum PcyEpi : int {
   EPI_STORE = 0,      // y = bf16(acc [+ bias])

@@ -128,17 +128,8 @@ __global__ __launch_bounds__(NT) void layernorm_wave_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------ embedding lookup + soft-token splice (A5)
 __global__ __launch_bounds__(NT) void embed_gather_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
                                                           const bf16_t* __restrict__ soft, const int32_t* __restrict__ soft_map,
-                                                          bf16_t* __restrict__ out, int d, unsigned* __restrict__ epoch, PcyPipe pipe) {
+                                                          bf16_t* __restrict__ out, int d, unsigned* __restrict__ epoch) {
   const int r = blockIdx.x;
-  if (pipe.my_flags != nullptr) {   // first stage of the pipelined decode step: row written through, then this workgroup's flag
-    const unsigned ep = pipe_epoch(pipe);
-    const bf16_t* srow = table + (size_t)ids[r] * d;
-    for (int k = threadIdx.x * 4; k < d; k += NT * 4)
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + (size_t)r * d + k), *reinterpret_cast<const unsigned long long*>(srow + k),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pipe_done(pipe, ep);
-    return;
-  }
   // first launch of a decode step: also advances the epoch word of the step's in-launch hand-overs (was a launch of its own)
   if (epoch && r == 0 && threadIdx.x == 0) *epoch += 1;
   const int sm = soft_map ? soft_map[r] : -1;
@@ -905,11 +896,10 @@ void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const
 }
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
-  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr, PcyPipe{});
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr);
 }
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch,
-                                 const PcyPipe* pipe) {
-  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch, pipe ? *pipe : PcyPipe{});
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch) {
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch);
 }
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads) {

@@ -52,16 +52,6 @@ struct pcy_ctx {
   unsigned* ao_sync = nullptr;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
   size_t beam_ws_bytes = 0;
-  // software-pipelined decode step (batch 1): second stream, its graph, per-workgroup flags of every stage
-  hipStream_t stream_b = nullptr;
-  hipGraphExec_t graph_b = nullptr;
-  hipEvent_t ev_pipe = nullptr;
-  unsigned* pipe_flags = nullptr;
-  unsigned long long* pipe_trace = nullptr;   // PCY_PIPE_TRACE: [stages][4] wall-clock stamps of the last step
-  int pipe_trace_stages = 0;
-  int32_t* pipe_pos = nullptr;        // {base, advance}: cache length of the step with epoch e = base + advance * e
-  size_t pipe_flag_words = 0;
-  const void* pipe_sig[3] = {nullptr, nullptr, nullptr};
 
   int reserve(size_t bytes) {
     if (bytes <= ws_bytes) return 0;
@@ -78,7 +68,6 @@ struct pcy_ctx {
   }
   void drop_graph() {
     if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
-    if (graph_b) { hipGraphExecDestroy(graph_b); graph_b = nullptr; }
   }
 };
 
@@ -126,24 +115,8 @@ bool attn_o_enabled() {
   const char* e = getenv("PCY_ATTN_O");
   return !e || atoi(e) != 0;
 }
-// PCY_DECODE_PIPE=0 switches the software-pipelined batch-1 decode step off (default on): consecutive launches of the step
-// alternate between two streams and hand their vectors over through per-workgroup flags, so that the next launch streams its
-// first weight batches while the current one is still running (two independent GEMV streams sustain 6.9 TB/s on MI355X, one
-// 5.6).  Read on every call: tests compare both paths in one process (bit-identical).
-bool pipe_enabled() {
-  const char* e = getenv("PCY_DECODE_PIPE");
-  return !e || atoi(e) != 0;
-}
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (pipe_enabled() ? 4 : 0); }
+int decode_mode() { return attn_o_enabled() ? 2 : 0; }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
-constexpr int PIPE_WG = 256;   // flag words per stage (workgroups per launch <= CUs)
-inline int pipe_stages(int L) { return 5 * L + 2; }                      // embed, L x (qkv, attention, o, gate/up, down), lm_head
-inline size_t pipe_words(int L) { return (size_t)pipe_stages(L) * PIPE_WG + (size_t)L * AO_FLAGS; }   // + score-exchange flags per layer
-bool pipe_geometry_ok(const pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, int B) {
-  // batch 1; x of every RMS-fused stage fits 2 x 16 B per thread of a 4-wave workgroup; the attention stage's LDS <= half a CU
-  return B == 1 && m->head_dim == 128 && m->d <= 4096 && m->d % 8 == 0 && m->ffn <= 16384 && m->n_heads * m->head_dim <= 8192 &&
-         m->n_layers <= AO_MAX_LAYERS && c->n_cu >= 64 && kv->Tmax <= 4096;
-}
 
 // device words of the in-launch hand-overs; must run outside stream capture
 int ensure_decode_state(pcy_ctx* c) {
@@ -161,36 +134,6 @@ int ensure_decode_state(pcy_ctx* c) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ao_sync), bytes));
     HIP_TRY(hipMemset(c->ao_sync, 0, bytes));
   }
-  if (!c->stream_b) {
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_pipe, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_pos), 64));
-    HIP_TRY(hipMemset(c->pipe_pos, 0, 64));
-  }
-  return 0;
-}
-// Flags of the pipelined step: every workgroup counts its own completed steps, so all words must start equal.  They are
-// zeroed whenever the set of launches can change (another model / layer count / device) and after a watchdog time-out.
-int ensure_pipe_flags(pcy_ctx* c, const pcy_llama_desc* m, bool force_reset = false) {
-  const size_t words = pipe_words(m->n_layers);
-  const void* sig[3] = {m->layers, (const void*)(intptr_t)m->n_layers, (const void*)(intptr_t)c->n_cu};
-  if (!force_reset && c->pipe_flags && words <= c->pipe_flag_words && memcmp(sig, c->pipe_sig, sizeof(sig)) == 0) return 0;
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream_b));
-  c->drop_graph();
-  if (words > c->pipe_flag_words) {
-    if (c->pipe_flags) HIP_TRY(hipFree(c->pipe_flags));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_flags), words * sizeof(unsigned)));
-    c->pipe_flag_words = words;
-  }
-  HIP_TRY(hipMemset(c->pipe_flags, 0, c->pipe_flag_words * sizeof(unsigned)));
-  if (getenv("PCY_PIPE_TRACE")) {
-    if (c->pipe_trace) HIP_TRY(hipFree(c->pipe_trace));
-    c->pipe_trace_stages = pipe_stages(m->n_layers);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_trace), (size_t)c->pipe_trace_stages * 32));
-    HIP_TRY(hipMemset(c->pipe_trace, 0, (size_t)c->pipe_trace_stages * 32));
-  }
-  memcpy(c->pipe_sig, sig, sizeof(sig));
   return 0;
 }
 
@@ -200,83 +143,6 @@ size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
          align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) +
          align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) +
          align_up((size_t)B * m->d * 2, 256) + (B > 4 ? align_up((size_t)8 * B * qkvw * 4, 256) : 0) + 4096;
-}
-
-// Software-pipelined decode step, batch 1.  Stage k waits for the flags of stage k-1 (PcyPipe); stages alternate between the
-// streams `sa` (the caller's: embed, ..., lm_head and the pick) and `sb`, so stage k+1 is resident and prefetching while stage k
-// streams.  Resource budget that makes any two consecutive launches fit one CU together whatever the dispatch order (a waiting
-// launch can therefore never lock its producer out): GEMV stages <= 128 VGPRs, 8 waves per workgroup -- 4 for the two
-// neighbours of the attention stage (qkv, o), which takes 8 waves of <= 192 VGPRs -- one workgroup per CU and stage, LDS <= 80 KiB.
-// only_chain: -1 = launch everything (eager, two real streams); 0 / 1 = only the launches of stream a / b (graph capture).
-void enqueue_decode_pipe(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, hipStream_t sa,
-                         hipStream_t sb, int only_chain) {
-  const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn, L = m->n_layers;
-  const int qkvw = (H + 2 * Hkv) * dh;
-  Carver cv(c->ws);
-  bf16_t* x = cv.take<bf16_t>((size_t)d);
-  bf16_t* qkv = cv.take<bf16_t>((size_t)qkvw);
-  bf16_t* ao = cv.take<bf16_t>((size_t)H * dh);
-  bf16_t* act = cv.take<bf16_t>((size_t)F);
-  float* scores = cv.take<float>((size_t)H * (kv->Tmax + 1));
-  const int S_lm = 5 * L + 1;                                   // stage index of lm_head; it must run on stream a
-  auto chain_of = [&](int stage) { return stage == 0 ? 0 : (S_lm - stage) & 1; };
-  auto flags_of = [&](int stage) { return c->pipe_flags + (size_t)stage * PIPE_WG; };
-  auto on = [&](int stage) { return only_chain < 0 || only_chain == chain_of(stage); };
-  auto stream_of = [&](int stage) { return chain_of(stage) ? sb : sa; };
-  int prev_n = 1;                                               // workgroups of the previous stage
-  auto pipe_of = [&](int stage) {
-    PcyPipe p{};
-    p.my_flags = flags_of(stage);
-    p.wait_flags = stage > 0 ? flags_of(stage - 1) : nullptr;
-    p.wait_n = prev_n;
-    p.err = c->xwg_err;
-    p.trace = c->pipe_trace ? c->pipe_trace + (size_t)stage * 4 : nullptr;
-    return p;
-  };
-  {
-    PcyPipe p = pipe_of(0);
-    if (on(0)) pcy_launch_embed_tokens_dev(stream_of(0), (const bf16_t*)m->embed, st->next_tok, x, 1, d, nullptr, &p);
-    prev_n = 1;
-  }
-  const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
-  auto gemv_stage = [&](int stage, PcyGemvArgs& g, int waves, int plain_out) {
-    g.B = 1; g.pipe = pipe_of(stage); g.pipe_waves = waves; g.pipe_out_plain = plain_out;
-    if (on(stage)) pcy_launch_gemv(stream_of(stage), g);
-    prev_n = pcy_gemv_pipe_blocks(g);
-  };
-  for (int l = 0; l < L; ++l) {
-    const pcy_llama_layer& Lw = m->layers[l];
-    const int s0 = 1 + 5 * l;
-    PcyGemvArgs g{};
-    g.W = (const bf16_t*)Lw.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)Lw.ln1; g.rms_eps = m->rms_eps; g.rms_cast = m->rms_cast;
-    g.N = qkvw; g.K = d; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
-    gemv_stage(s0, g, 4, 0);
-    PcyDecAttnArgs t{};
-    t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
-    t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
-    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = 1; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
-    t.scale = 1.0f / sqrtf((float)dh);
-    t.pipe = pipe_of(s0 + 1);
-    t.pipe_pos = c->pipe_pos;
-    { const char* xe = getenv("PCY_AO_XMIN"); t.xmin = xe ? atoi(xe) : 768; }
-    t.xflags = t.xmin > 0 ? c->pipe_flags + (size_t)pipe_stages(L) * PIPE_WG + (size_t)l * AO_FLAGS : nullptr;
-    if (on(s0 + 1)) pcy_launch_attn_decode_pipe(stream_of(s0 + 1), t);
-    prev_n = pcy_attn_pipe_blocks(t);
-    PcyGemvArgs o{};
-    o.W = (const bf16_t*)Lw.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
-    gemv_stage(s0 + 2, o, 4, 0);
-    PcyGemvArgs u{};
-    u.W = (const bf16_t*)Lw.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)Lw.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
-    u.N = F; u.K = d; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
-    gemv_stage(s0 + 3, u, 8, 0);
-    PcyGemvArgs w{};
-    w.W = (const bf16_t*)Lw.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
-    gemv_stage(s0 + 4, w, 8, 0);
-  }
-  PcyGemvArgs h{};
-  h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
-  h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
-  gemv_stage(S_lm, h, 8, 1);   // the logits are read by later launches on stream a (pick / the caller): ordinary stores
 }
 
 void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
@@ -421,12 +287,6 @@ __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict_
 extern "C" {
 
 int pcy_abi_version(void) { return PCY_ABI_VERSION; }
-int pcy_debug_pipe_trace(pcy_ctx* c, unsigned long long* out, int max_words) {
-  if (!c->pipe_trace) return 0;
-  const int n = c->pipe_trace_stages * 4 < max_words ? c->pipe_trace_stages * 4 : max_words;
-  if (hipMemcpy(out, c->pipe_trace, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return n;
-}
 unsigned long long pcy_debug_dispatch_count(int kind) { return (kind >= 0 && kind < PCY_DISPATCH_N) ? g_pcy_dispatch[kind] : 0; }
 const char* pcy_last_error(void) { return g_err; }
 
@@ -453,11 +313,6 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->beam_ws) hipFree(c->beam_ws);
-  if (c->stream_b) { hipStreamSynchronize(c->stream_b); hipStreamDestroy(c->stream_b); }
-  if (c->ev_pipe) hipEventDestroy(c->ev_pipe);
-  if (c->pipe_flags) hipFree(c->pipe_flags);
-  if (c->pipe_pos) hipFree(c->pipe_pos);
-  if (c->pipe_trace) hipFree(c->pipe_trace);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
@@ -470,8 +325,6 @@ int pcy_ctx_sync(pcy_ctx* c) {
     HIP_TRY(hipMemcpy(&err, c->xwg_err, sizeof(err), hipMemcpyDeviceToHost));
     if (err) {
       HIP_TRY(hipMemset(c->xwg_err, 0, sizeof(err)));
-      if (c->stream_b) HIP_TRY(hipStreamSynchronize(c->stream_b));
-      if (c->pipe_flags) HIP_TRY(hipMemset(c->pipe_flags, 0, c->pipe_flag_words * sizeof(unsigned)));   // the stages' step counts no longer agree
       return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (results invalid)");
     }
   }
@@ -858,19 +711,10 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   return check_launch("pcy_llama_prefill");
 }
 
-namespace {
-bool use_pipe(const pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, int B);
-int pipe_begin_call(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int advance);
-}
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c)) return r;
-  if (use_pipe(c, m, kv, B)) {
-    if (int r = pipe_begin_call(c, m, st, 0)) return r;
-    enqueue_decode_pipe(c, m, kv, st, c->stream, c->stream_b, -1);
-    return check_launch("pcy_llama_decode");
-  }
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
@@ -882,22 +726,6 @@ int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
 }
 
 namespace {
-bool use_pipe(const pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, int B) { return pipe_enabled() && pipe_geometry_ok(c, m, kv, B); }
-// per call of a pipelined decode: flags consistent with this model, and stream b ordered behind everything the caller has
-// queued on stream a so far (prefill, the previous pick, ...).  The step's last launch runs on stream a, so the caller's stream
-// alone orders whatever follows.
-__global__ void pipe_pos_kernel(int32_t* pipe_pos, const int32_t* pos_dev, const unsigned* flag0, int advance) {
-  // the next step has epoch *flag0 + 1 and runs at cache length *pos_dev
-  pipe_pos[0] = *pos_dev - advance * (int)(*flag0 + 1u);
-  pipe_pos[1] = advance;
-}
-int pipe_begin_call(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int advance) {
-  if (int r = ensure_pipe_flags(c, m)) return r;
-  hipLaunchKernelGGL(pipe_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->pipe_pos, st->pos, c->pipe_flags, advance);
-  HIP_TRY(hipEventRecord(c->ev_pipe, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->stream_b, c->ev_pipe, 0));
-  return 0;
-}
 // capture (once per model / cache / state / batch) and replay the decode step; kind 0 = decode + greedy pick, 1 = decode only
 int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps, int kind) {
   // EVERYTHING a captured kernel argument was derived from: every pointer of the state / cache / model the enqueue functions
@@ -907,43 +735,26 @@ int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache*
                                            st->logits, st->logits_all, st->keep, c->ws,
                                            (const void*)(intptr_t)(((int64_t)st->logits_all_ld << 32) ^ kv->Tmax),
                                            (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ st->max_steps)};
-  const bool pipe = use_pipe(c, m, kv, B);
-  if (pipe) { if (int r = ensure_pipe_flags(c, m)) return r; }   // (may drop the graphs: before the cache check)
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 ||
       c->graph_B != B || c->graph_mode != decode_mode() || c->graph_kind != kind) {
     c->drop_graph();
+    hipGraph_t g = nullptr;
     hipStream_t user = c->stream;
     c->stream = c->cap_stream;
-    // pipelined step: TWO linear graphs, one per stream (chain 0: the caller's stream, incl. the pick; chain 1: stream b);
-    // their launches overlap because they are replayed on two real streams -- nothing depends on how a graph executor
-    // schedules parallel branches
-    for (int chain = 0; chain < (pipe ? 2 : 1); ++chain) {
-      hipGraph_t g = nullptr;
-      hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
-      if (e0 == hipSuccess) {
-        if (pipe) enqueue_decode_pipe(c, m, kv, st, c->cap_stream, c->cap_stream, chain);
-        else enqueue_decode(c, m, kv, st, B);
-        if (kind == 0 && chain == 0) enqueue_pick(c, m, st, B, 1, kv->Tmax);
-        e0 = hipStreamEndCapture(c->cap_stream, &g);
-      }
-      if (e0 != hipSuccess) { c->stream = user; return fail(2, "decode-step graph capture failed: %s", hipGetErrorString(e0)); }
-      hipError_t e1 = hipGraphInstantiate(chain ? &c->graph_b : &c->graph, g, nullptr, nullptr, 0);
-      hipGraphDestroy(g);
-      if (e1 != hipSuccess) { c->stream = user; return fail(2, "hipGraphInstantiate failed: %s", hipGetErrorString(e1)); }
+    hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e0 == hipSuccess) {
+      enqueue_decode(c, m, kv, st, B);
+      if (kind == 0) enqueue_pick(c, m, st, B, 1, kv->Tmax);
+      e0 = hipStreamEndCapture(c->cap_stream, &g);
     }
     c->stream = user;
+    if (e0 != hipSuccess) return fail(2, "decode-step graph capture failed: %s", hipGetErrorString(e0));
+    HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
     memcpy(c->graph_key, key, sizeof(key));
     c->graph_B = B;
     c->graph_mode = decode_mode();
     c->graph_kind = kind;
-  }
-  if (pipe) {
-    if (int r = pipe_begin_call(c, m, st, kind == 0 ? 1 : 0)) return r;
-    for (int i = 0; i < n_steps; ++i) {
-      HIP_TRY(hipGraphLaunch(c->graph, c->stream));
-      HIP_TRY(hipGraphLaunch(c->graph_b, c->stream_b));
-    }
-    return 0;
   }
   for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
   return 0;
@@ -956,11 +767,8 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c)) return r;
   if (!use_graph) {
-    const bool pipe = use_pipe(c, m, kv, B);
-    if (pipe) { if (int r = pipe_begin_call(c, m, st, 1)) return r; }
     for (int i = 0; i < n_steps; ++i) {
-      if (pipe) enqueue_decode_pipe(c, m, kv, st, c->stream, c->stream_b, -1);
-      else enqueue_decode(c, m, kv, st, B);
+      enqueue_decode(c, m, kv, st, B);
       enqueue_pick(c, m, st, B, 1, kv->Tmax);
     }
     return check_launch("pcy_llama_greedy");

@@ -182,18 +182,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(PcyGemvArgs a, int K
 //     w, w + n_waves, ...; the host sizes the grid so that every wave gets the same number of units
 //   * the first batch of weight loads is issued BEFORE the x-staging / RMSNorm prologue, and each later batch
 //     (16 x 16 B per lane) is issued before the previous one is consumed (two register sets, static indexing)
-// PIPE: a stage of the software-pipelined decode step (PcyPipe, pcy_common.h): the first two weight batches are requested, THEN
-// the workgroup waits for the producer stage's flags, reads x (and the residual) with L1-bypassing loads and runs as usual;
-// outputs are written through and the workgroup's flag follows.  Two such launches share every CU (the next stage prefetches
-// while this one streams), so a PIPE instantiation is capped at 128 VGPRs (four waves per SIMD): batches of 8 instead of 16
-// loads per lane.  Per output row the k order of the accumulation, the reduction tree and the rounding points are unchanged:
-// bit-identical to the unpipelined launch.
-template <int NB, int EPI, bool RMS, int R, bool PIPE = false>
-__global__ __launch_bounds__(512, PIPE ? 4 : 2) void gemv_stream_kernel(PcyGemvArgs a, int units) {
+template <int NB, int EPI, bool RMS, int R>
+__global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int units) {
   constexpr bool DIRECTX = PCY_GEMV_DIRECTX && !RMS;
   constexpr int RW = (EPI == EPI_SWIGLU) ? 2 * R : R;
-  constexpr int UN = (PIPE ? 8 : 16) / RW;
-  static_assert(!PIPE || NB == 1, "the pipelined step is batch 1");
+  constexpr int UN = 16 / RW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                          // [NB][K]
   float* red = reinterpret_cast<float*>(smem + (size_t)NB * a.K * 2);    // [waves per block]
@@ -269,12 +262,11 @@ __global__ __launch_bounds__(512, PIPE ? 4 : 2) void gemv_stream_kernel(PcyGemvA
             v = rbf(silu_f(g)) * up;
           } else {
             v = rbf(acc[i][b] + (a.bias ? bf2f(a.bias[n]) : 0.f));
-            if (EPI == EPI_RESID) v = rbf(v + bf2f(PIPE ? ld_bf16_agent(a.resid + (size_t)b * a.ldy + n) : a.resid[(size_t)b * a.ldy + n]));
+            if (EPI == EPI_RESID) v = rbf(v + bf2f(a.resid[(size_t)b * a.ldy + n]));
             if (EPI == EPI_GELU_ERF) v = rbf(gelu_erf_f(v));
             if (EPI == EPI_GELU_ESM) v = gelu_esm_chain(v);
           }
-          if (PIPE && !a.pipe_out_plain) st_bf16_agent(a.y + (size_t)b * a.ldy + n, f2bf(v));
-          else a.y[(size_t)b * a.ldy + n] = f2bf(v);
+          a.y[(size_t)b * a.ldy + n] = f2bf(v);
         }
       }
     }
@@ -295,64 +287,37 @@ __global__ __launch_bounds__(512, PIPE ? 4 : 2) void gemv_stream_kernel(PcyGemvA
   // waits for.  x (and the norm weight) go out FIRST -- a few KiB, back after one round trip -- then TWO weight batches
   // (32 x 16 B per lane); the RMSNorm / LDS staging then runs while the weights stream, instead of waiting behind the first
   // batch and leaving the second one to be requested only after it (qkv 12.46 -> 12.22 us, down 21.8 -> 21.0 us, decode step 3.27 -> 3.25 ms).
-  constexpr int MAXX = PIPE ? (RMS ? 2 : 4) : (RMS ? 4 : 8);
-  const bool xfirst = PIPE || (NB == 1 && !DIRECTX && K <= MAXX * nthr * 8 && a.plain_loads != 2);   // (PIPE: the launcher checks K)
+  constexpr int MAXX = RMS ? 4 : 8;
+  const bool xfirst = NB == 1 && !DIRECTX && K <= MAXX * nthr * 8 && a.plain_loads != 2;
   uint4 xr[MAXX], gr[RMS ? MAXX : 1];
   int u1 = u, it1 = 0;
   bool have1 = false;
   if (xfirst) {
-    unsigned epoch = 0;
-    if (PIPE) {
-      // weights first: they depend on nothing.  x exists only once the producer stage has published.
-      epoch = pipe_epoch(a.pipe);
-      if (have) issue(u, 0, wa);
-      next_pos(u, 0, u1, it1);
-      have1 = have && u1 < units;
-      if (have1) issue(u1, it1, wb);
-      pipe_wait(a.pipe, epoch);
 #pragma unroll
-      for (int i = 0; i < MAXX; ++i) {
-        const int k = (threadIdx.x + i * nthr) * 8;
-        if (k < K) {
-          xr[i] = ld16_agent(a.x + k);
-          if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
-        }
+    for (int i = 0; i < MAXX; ++i) {
+      const int k = (threadIdx.x + i * nthr) * 8;
+      if (k < K) {
+        xr[i] = *reinterpret_cast<const uint4*>(a.x + k);
+        if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < MAXX; ++i) {
-        const int k = (threadIdx.x + i * nthr) * 8;
-        if (k < K) {
-          xr[i] = *reinterpret_cast<const uint4*>(a.x + k);
-          if (RMS) gr[i] = *reinterpret_cast<const uint4*>(a.rms_w + k);
-        }
-      }
-      if (have) issue(u, 0, wa);
-      next_pos(u, 0, u1, it1);
-      have1 = have && u1 < units;
-      if (have1) issue(u1, it1, wb);
     }
+    if (have) issue(u, 0, wa);
+    next_pos(u, 0, u1, it1);
+    have1 = have && u1 < units;
+    if (have1) issue(u1, it1, wb);
     float rs = 1.f;
     if (RMS) {
-      // Sum of squares in an order that does not depend on the workgroup size (the pipelined and the plain launch use
-      // different ones and must agree to the bit): per 8-element chunk in element order into LDS, then every wave adds the
-      // chunk sums l, l + 64, ... per lane and folds the 64 lanes -- the same value in every wave, one barrier.
-      float* csum = red + 16;                                   // [K / 8]
+      float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXX; ++i) {
         const int k = (threadIdx.x + i * nthr) * 8;
         if (k < K) {
           const uint32_t w4[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-          float ss = 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
-          csum[k >> 3] = ss;
         }
       }
-      __syncthreads();
-      float ss = 0.f;
-      for (int c = lane; c < (K >> 3); c += 64) ss += csum[c];
-      ss = wave_sum(ss);
+      ss = block_sum_rt(ss, red, wpb);
       rs = rsqrtf(ss / (float)K + a.rms_eps);
     }
 #pragma unroll
@@ -395,7 +360,6 @@ __global__ __launch_bounds__(512, PIPE ? 4 : 2) void gemv_stream_kernel(PcyGemvA
       PCY_GEMV_STEP2(wb, wa)
     }
 #undef PCY_GEMV_STEP2
-    if (PIPE) pipe_done(a.pipe, epoch);
     return;
   }
   if (have) issue(u, 0, wa);
@@ -482,32 +446,9 @@ void launch_stream(hipStream_t s, const PcyGemvArgs& a) {
   const int units = (a.N + R - 1) / R;
   int blocks, wpb;
   pick_grid(units, blocks, wpb);
-  const size_t smem = (size_t)NB * a.K * 2 + 64 + (size_t)(a.K / 8) * 4;
+  const size_t smem = (size_t)NB * a.K * 2 + 64;
   hipLaunchKernelGGL((gemv_stream_kernel<NB, EPI, RMS, R>), dim3(blocks), dim3(wpb * 64), smem, s, a, units);
 }
-
-// pipelined stage: one workgroup per CU of `pipe_waves` waves (a second launch shares every CU), rows dealt out so that every
-// wave gets the same number of units where the row count allows
-inline void pipe_grid(const PcyGemvArgs& a, int R, int& blocks, int& wpb, int& units) {
-  units = (a.N + R - 1) / R;
-  wpb = a.pipe_waves;
-  if (units <= GEMV_CUS * wpb) { blocks = (units + wpb - 1) / wpb; return; }
-  blocks = GEMV_CUS;
-  double best = 1e30;
-  for (int w = a.pipe_waves < 4 ? a.pipe_waves : 4; w <= a.pipe_waves; ++w) {   // e.g. gate/up: 3584 units = 256 x 7 waves x 2
-    const int waves = GEMV_CUS * w;
-    const double cost = (double)((units + waves - 1) / waves) * waves / units - 1e-4 * w;
-    if (cost < best) { best = cost; wpb = w; }
-  }
-}
-template <int EPI, bool RMS, int R>
-void launch_stream_pipe(hipStream_t s, const PcyGemvArgs& a) {
-  int blocks, wpb, units;
-  pipe_grid(a, R, blocks, wpb, units);
-  const size_t smem = (size_t)a.K * 2 + 64 + (size_t)(a.K / 8) * 4;
-  hipLaunchKernelGGL((gemv_stream_kernel<1, EPI, RMS, R, true>), dim3(blocks), dim3(wpb * 64), smem, s, a, units);
-}
-inline int pipe_R(const PcyGemvArgs& a) { return a.epi == EPI_SWIGLU ? 4 : 2; }
 
 template <int NB, int EPI, bool RMS>
 void launch_nb(hipStream_t s, const PcyGemvArgs& a) {
@@ -795,24 +736,9 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
 
 }  // namespace
 
-int pcy_gemv_pipe_blocks(const PcyGemvArgs& a) {
-  int blocks, wpb, units;
-  pipe_grid(a, pipe_R(a), blocks, wpb, units);
-  return blocks;
-}
-
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   PcyGemvArgs a0 = a00;
   a0.plain_loads = 0;
-  if (a0.pipe.my_flags != nullptr) {   // stage of the pipelined decode step: batch 1, x fits the per-thread staging registers
-    const bool rms = a0.rms_w != nullptr;
-    switch (a0.epi) {
-      case EPI_STORE: rms ? launch_stream_pipe<EPI_STORE, true, 2>(s, a0) : launch_stream_pipe<EPI_STORE, false, 2>(s, a0); break;
-      case EPI_RESID: launch_stream_pipe<EPI_RESID, false, 2>(s, a0); break;
-      default: launch_stream_pipe<EPI_SWIGLU, true, 4>(s, a0); break;
-    }
-    return;
-  }
   // B > 4 on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused RMSNorm prologue is a
   // B <= 4 feature)
   if (a0.B > 4 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {

@@ -19,13 +19,7 @@ struct PcyGemvArgs {
   // next_xn = RMSNorm(y) * next_rms_w (rms_eps / rms_cast above) and sets *fused_next = 1; otherwise *fused_next stays 0 and
   // the caller launches the norm itself.  Same summation order as rmsnorm_kernel -> identical bits.
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
-  // pipelined decode step (batch 1 only; pipe.my_flags == nullptr otherwise): x / resid come from, y goes to, other launches
-  // of the same step -- see PcyPipe.  pipe_waves = waves per workgroup (4 next to the attention launch, else 8)
-  PcyPipe pipe; int pipe_waves;
-  int pipe_out_plain;   // y is consumed by a later launch on the SAME stream (kernel boundary): ordinary stores
 };
-// workgroups a pipelined GEMV launch will use (= flag words of its stage)
-int pcy_gemv_pipe_blocks(const PcyGemvArgs& a);
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
 struct PcyGemmArgs {
@@ -63,8 +57,7 @@ void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d);
 // epoch (optional): device word incremented by the launch (decode step: epoch of the in-launch hand-overs)
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch = nullptr,
-                                 const PcyPipe* pipe = nullptr);   // pipe: first stage of the pipelined decode step (rows == 1)
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch = nullptr);
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads);
 // rope on heads [0,nh) located at column col0 of a token-major buffer; pos[tok] = rotary position.
@@ -107,15 +100,7 @@ struct PcyDecAttnArgs {
   // `scratch` ([B*H*(Tmax+1)] fp32) carries the exchanged scores
   unsigned* xflags; unsigned xepoch; int xmin; unsigned* xerr;
   int unit_map;                   // fused launch: 1 = kv head in the low digits of the workgroup index (slices of a head share an XCD)
-  PcyPipe pipe;                   // pipelined decode step (pcy_launch_attn_decode_pipe)
-  // pipelined step: {base, advance} -- cache length of the step with epoch e = base + advance * e.  A stage of step k+1 may
-  // start (and prefetch cache rows) before the pick of step k has advanced *pos_dev, so the position comes from the stage's
-  // own step count instead (set once per call on the caller's stream, pcy_engine.hip pipe_begin_call)
-  const int32_t* pipe_pos;
 };
-// decode attention as a stage of the pipelined step: grid = (dh/16) * Hkv workgroups (batch 1, head_dim 128); false = not covered
-bool pcy_launch_attn_decode_pipe(hipStream_t s, const PcyDecAttnArgs& a);
-int pcy_attn_pipe_blocks(const PcyDecAttnArgs& a);
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;
 // decode attention + o projection (EPI_RESID GEMV over the attention output) in one launch; false = shape not covered,

@@ -218,7 +218,6 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
     monkeypatch.setenv("PCY_AO_XMIN", "384")   # key split + score exchange between the slice workgroups from 384 keys on (default 1024)
-    monkeypatch.setenv("PCY_DECODE_PIPE", "0")  # the launch-per-stage step (the pipelined step has no fused attention + o launch)
 
     def run(ao, use_graph):
         monkeypatch.setenv("PCY_ATTN_O", "1" if ao else "0")
@@ -239,60 +238,6 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
         got = run(True, use_graph)
         for x, y in zip(got, ref):
             assert torch.equal(x, y), use_graph
-
-
-@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (600, 10, 2), (1100, 6, 2), (40, 12, 5)])   # 600 / 1100: key split on; 3 / 5 layers: lm_head parity
-def test_decode_pipelined_step_bit_identical(monkeypatch, T, N, n_layers):
-    """PCY_DECODE_PIPE (default on): the batch-1 decode step as a software pipeline over two streams -- every launch requests its
-    first weight batches, then waits for the per-workgroup flags of the launch before it, reads its input vector with
-    L1-bypassing loads, writes its output through and raises its own flags.  Per output row the arithmetic is that of the
-    launch-per-stage step, so logits, tokens, log-probabilities and the appended K/V must be BIT-identical to PCY_DECODE_PIPE=0:
-    eager (two real streams) and as two replayed hipGraphs, over enough steps that a stale flag, a missed hand-over or a read
-    of a vector that is not there yet would show; the watchdog must stay silent."""
-    from procyon_amd import synth
-    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
-    kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
-    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))
-    torch.manual_seed(4)
-    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
-    monkeypatch.setenv("PCY_AO_XMIN", "384")
-
-    def run(pipe, use_graph):
-        monkeypatch.setenv("PCY_DECODE_PIPE", "1" if pipe else "0")
-        cache = eng.new_cache(1, T + N + 2)
-        st = GenState(1, kw["vocab"], N + 2, "cuda")
-        logits, _ = eng.prefill(emb, None, cache, "last")
-        st.logits.copy_(logits); st.pos.fill_(T)
-        eng.pick(cache, st, 1, advance_pos=False)
-        out = []
-        for i in range(N):
-            if i % 3 == 2:      # several steps per call: the two graphs are launched back to back without the host in between
-                continue
-            eng.greedy_steps(cache, st, 1, 2 if i % 3 == 1 else 1, use_graph=use_graph)
-            out.append(st.logits[0].clone())
-        Context.get().sync()    # raises if a hand-over timed out
-        return (torch.stack(out).cpu(), st.tokens_out[0, :N + 1].cpu(), st.logprob.cpu().clone(), cache.k[:, 0, :, T:T + N].cpu(),
-                cache.v[:, 0, :, T:T + N].cpu())
-
-    ref = run(False, False)
-    for use_graph in (False, True, True, False):   # flags keep counting across calls, states, eager and graph launches
-        got = run(True, use_graph)
-        for x, y in zip(got, ref):
-            assert torch.equal(x, y), use_graph
-    # a decode-only step (no pick: the sampling / beam drivers) in both modes
-    def one(pipe):
-        monkeypatch.setenv("PCY_DECODE_PIPE", "1" if pipe else "0")
-        cache = eng.new_cache(1, T + 4)
-        st = GenState(1, kw["vocab"], 2, "cuda")
-        eng.prefill(emb, None, cache, "last")
-        st.pos.fill_(T); st.next_tok.fill_(17)
-        eng.decode(cache, st, 1)
-        a = st.logits.clone()
-        st.pos.fill_(T + 1); st.next_tok.fill_(99)
-        eng.decode_graph(cache, st, 1)
-        return a.cpu(), st.logits.cpu()
-    for x, y in zip(one(True), one(False)):
-        assert torch.equal(x, y)
 
 
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):

@@ -24,16 +24,3 @@ for rep in range(3):
     ms = ctx.timer_stop() / 60
     print(f"decode {ms:.3f} ms/token  {1e3/ms:.1f} tok/s  {15.09/ms:.2f} TB/s   host enqueue {host*1e3:.3f} ms/step", flush=True)
 ctx.sync()
-if os.environ.get("PCY_PIPE_TRACE"):
-    import ctypes as C
-    buf = (C.c_ulonglong * 4096)()
-    n = ctx.lib.pcy_debug_pipe_trace(ctx.h, buf, 4096)
-    t = [buf[i] for i in range(n)]
-    t0 = t[0]
-    names = ["embed"] + ["qkv", "attn", "o", "gateup", "down"] * 32 + ["lm_head"]
-    print("stage           entry    ready     done     flag   (us from the step's first stamp; workgroup 0)")
-    for s_ in list(range(0, 12)) + list(range(n // 4 - 7, n // 4)):
-        e, r, d, f = [(x - t0) / 100.0 for x in t[4 * s_:4 * s_ + 4]]
-        print(f"{s_:4d} {names[s_]:8s} {e:8.2f} {r:8.2f} {d:8.2f} {f:8.2f}   wait {r - e:6.2f}  work {d - r:6.2f}  publish {f - d:5.2f}")
-    L5 = [t[4 * (1 + 5 * l) + 0] for l in range(32)]
-    print("layer period (us):", [round((L5[i + 1] - L5[i]) / 100.0, 1) for i in range(0, 31, 5)])
