@@ -35,7 +35,23 @@ def parse():
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--retrieval-proteins", type=int, default=125, help="proteins per rank in the retrieval leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] block (batch-32 generation, pair scoring)")
     return ap.parse_args()
+
+
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) under torch.distributed.run and pass
+    every argument on; the child ranks find WORLD_SIZE set and run the bench."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def cpu_baseline(tokens, residues, prompt):
@@ -88,8 +104,12 @@ def cpu_baseline(tokens, residues, prompt):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(a.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1 or bool(os.environ.get("PCY_BENCH_FORCE_DIST"))   # the env switch exercises the RCCL path on one GPU
     torch.cuda.set_device(local)
@@ -155,6 +175,20 @@ def main():
     logits, _ = eng.prefill(emb, mask, cache, "last")
     st.logits.copy_(logits); st.pos.fill_(a.prompt)
     eng.pick(cache, st, 1, advance_pos=False)
+    prefill_flop = 2 * cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d
+                                       + 3 * cfg.d * cfg.ffn) * a.prompt + 4 * cfg.n_layers * cfg.n_heads * cfg.head_dim * a.prompt * a.prompt / 2 \
+        + 2 * cfg.vocab * cfg.d
+    # prefill alone, HIP events (the wall-clock phase above includes the host side of the call)
+    eng.prefill(emb, mask, cache, "last")
+    ctx.timer_start()
+    for _ in range(5):
+        eng.prefill(emb, mask, cache, "last")
+    pre_ms = ctx.timer_stop() / 5
+    phases.update(prefill_kernels_ms=pre_ms, prefill_TFLOPs=prefill_flop / 1e12 / (pre_ms / 1e3),
+                  prefill_mfma_frac_of_2500TF=prefill_flop / 1e12 / (pre_ms / 1e3) / 2500.0)
+    logits, _ = eng.prefill(emb, mask, cache, "last")
+    st.logits.copy_(logits); st.pos.fill_(a.prompt)
+    eng.pick(cache, st, 1, advance_pos=False)
     eng.greedy_steps(cache, st, 1, 8)          # warm the graph
     ctx.timer_start()
     nsteps = a.tokens - 16
@@ -181,15 +215,21 @@ def main():
             ctx.gemv(wl[i], x, epi=4, rms_w=ln[i], out=outb)
     k_ms = ctx.timer_stop() / (reps * len(wl))
     k_bytes = 2 * cfg.ffn * cfg.d * 2
-    traffic = None
-    try:  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with tools/bench_gemv.py)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")))["kernels"]
-        traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "<1, 4, true" in k][0] if a.geometry == "full" else None
-    except Exception:
-        pass
+    traffic, traffic_source = None, None
+    # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
+    # `--pmc WRITE_SIZE` passes over tools/bench_gemv.py (the same kernel, the same shapes), committed under profiles/
+    for name in ("r02_pmc_gemv.json", "r01_pmc_gemv.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            if a.geometry == "full":
+                traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "<1, 4, true" in k][0]
+                traffic_source = f"profiles/{name} (rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+            break
+        except Exception:
+            continue
     roofline = {"bound": "hbm", "kernel": "gemv_stream_kernel<1,EPI_SWIGLU,RMS,4> (Llama gate/up, 32 launches/token)",
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic,
+                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
 
     # ---- retrieval leg (config 3 shape): DP-sharded forward_sequences + ONE all-gather --------------
@@ -204,7 +244,26 @@ def main():
     allz = embed_sharded(model, tok_fn, nprot, batch_size=rb)
     barrier(); rt = time.perf_counter() - t0
     assert allz.shape[0] == nprot
-    retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": rb}
+    # the gathered [N_total, D] matrix against single-rank embeddings of a sample of its rows (first / middle / last protein:
+    # the last one lives on the last rank): a protein's embedding does not depend on its batch mates, so the rows must be EQUAL
+    per = -(-nprot // world)                                   # shard size (distributed.shard_indices)
+    for i in sorted({0, nprot // 2, nprot - 1}):
+        b0 = (i // per) * per + ((i % per) // rb) * rb           # first protein of the engine call that embedded protein i
+        idx = list(range(b0, min(b0 + rb, (i // per + 1) * per, nprot)))
+        ref_row = model.forward_sequences(tok_fn(idx))["shared"][i - b0]
+        assert torch.equal(ref_row, allz[i]), f"gathered embedding of protein {i} differs from the single-rank result"
+    retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": rb,
+                 "mfma_frac_of_2500TF": round(nprot / rt * (2 * 648806400 * (plen + 2) + 168960 * (plen + 2) ** 2) / 2.5e15, 4) if a.geometry == "full" else None,
+                 "collective": "one RCCL all-gather through pcy_allgather" if dist else "none (single rank)", "gather_checked_rows": 3}
+
+    # ---- BASELINE configs[3] (batch-32 mixed-length generation, 4a equal and 4b ragged prompts) and configs[4] (pair scoring) ----
+    configs = None
+    if not a.no_configs and a.geometry == "full" and world == 1:
+        from procyon_amd import workloads as WL
+        model.text_encoder.max_new_tokens = 512
+        configs = {"config3_4a_batch32_mixed_residues_T512": WL.run_config4(model, new_tokens=512, ragged=False),
+                   "config3_4b_batch32_ragged_prompts": WL.run_config4(model, new_tokens=512, ragged=True),
+                   "config4_pair_scoring_256": WL.run_config5(model, pairs=256, chunk=64, fp8=True)}
 
     if rank == 0:
         out = {"metric": "phenotype-gen tokens/sec (ProCyon-Full greedy generation, end to end)", "value": round(value, 2),
@@ -214,6 +273,8 @@ def main():
                                       f"{a.residues}-residue protein, {a.prompt}-token prompt, {a.tokens}-token greedy generation",
                           "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
                "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
+        if configs is not None:
+            out["configs"] = configs
         if not a.no_cpu_baseline and a.geometry == "full" and world == 1:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.tokens, a.residues, a.prompt)
         print(json.dumps(out))
