@@ -388,11 +388,14 @@ def test_esm_layer_256x256_fused_rotary_vs_oracle(ctx):
     out = eng.hidden_states(toks).cpu()
     d = [x - y for x, y in zip(dispatch_counts(ctx), before)]
     assert d[L.DISPATCH_GEMM_BIG] == 3 and d[L.DISPATCH_GEMM_BIG_PERSIST] == 1 and d[L.DISPATCH_GEMM_128] == 0 and d[L.DISPATCH_GEMM_64] == 0, d
+    from conftest import alt_accumulation
     ref = ER.esm_forward(sd, ER.EsmGeom(**kw), toks)
+    with alt_accumulation():     # the oracle with another fp32 accumulation order: the reproducibility floor of this layer
+        twin = ER.esm_forward(sd, ER.EsmGeom(**kw), toks)
     keep = toks != 1
-    err = rel_err(out[keep], ref[keep])
-    print(f"one ESM2-650M layer through the 256x256 kernels vs oracle: {err:.2e} (CPU-vs-CPU floor of this layer 1.7e-3)")
-    assert err < 2.5e-3
+    err, floor = rel_err(out[keep], ref[keep]), rel_err(twin[keep], ref[keep])
+    print(f"one ESM2-650M layer through the 256x256 kernels vs oracle: {err:.2e} (CPU-vs-CPU floor of this layer {floor:.2e})")
+    assert err < max(2.5e-3, 2 * floor)
 
 
 @pytest.mark.parametrize("B,beam,g,V,steps,eos", [(1, 4, 2, 300, 7, 299), (2, 6, 2, 481, 6, 5), (1, 5, 5, 300, 6, 299), (3, 8, 4, 260, 5, 7),
