@@ -213,6 +213,18 @@ int pcy_greedy_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const 
 /* n_steps x (decode + pick) with no host synchronisation; use_graph != 0 replays a captured hipGraph */
 int pcy_llama_greedy(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int n_steps,
                      int use_graph);
+/* Sampling / nucleus selection (`_generate_sampling` without greedy, model_unified.py:896-906) on state->logits:
+ *   probs = bf16 softmax(logits / temperature); nucleus_prob in (0,1): probs = softmax(logits) * mask of the tokens whose ascending
+ *   cumulative probability has reached 1 - nucleus_prob (`_get_nucleus_mask`, not renormalised); nucleus_prob <= 0: no mask;
+ *   token = first index whose cumulative masked probability exceeds uniforms[step * B + b] * total (inverse CDF with the CALLER's
+ *   uniform variates in [0,1): torch's multinomial stream is not reproducible, the probability vector and the draw for a given u
+ *   are); logprob += bf16 log_softmax(unscaled logits)[token]; then next_tok / tokens_out / ++step (/ ++pos) like pcy_greedy_pick.
+ * probs_out: optional [B, vocab] bf16 record of the pre-sampling probability vector.  uniforms: device fp32 [max_steps * B]. */
+int pcy_sample_pick(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int advance_pos,
+                    float temperature, float nucleus_prob, const float* uniforms, void* probs_out);
+/* n_steps x (decode + sample) with no host synchronisation */
+int pcy_llama_sample(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int n_steps,
+                     float temperature, float nucleus_prob, const float* uniforms);
 /* Diverse beam search bookkeeping of ONE step on the device (`_generate_beam_search`, model_unified.py:782-833): per prompt
  * and beam group, top-`group_size` of  log_softmax(logits) (model dtype) + running score - diversity_penalty * (count of the
  * token among the picks of the earlier groups at this step);  at step 0 only the first beam of a group is expanded.  Updates

@@ -233,6 +233,16 @@ def sampling_probs(logits, temperature=1.0, nucleus_prob=None):
     return probs
 
 
+def sample_token(probs, u):
+    """The draw of `torch.multinomial(probs, 1)` (model_unified.py:905) for GIVEN uniform variates u [B] in [0,1): inverse CDF in
+    vocabulary order over the (not necessarily normalised) probabilities, token = first index whose cumulative probability
+    exceeds u * total.  torch's own RNG stream is not part of the contract."""
+    p = probs.double()
+    cdf = p.cumsum(-1)
+    target = u.double()[:, None] * cdf[:, -1:]
+    return (cdf > target).float().argmax(-1)
+
+
 @torch.no_grad()
 def beam_search(text_encoder, input_embeds, attn_mask, *, vocab_size, eos_id, max_len=64,
                 beam_size=5, beam_group_size=5, diversity_penalty=0.8, trace=None):

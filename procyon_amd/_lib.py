@@ -96,6 +96,8 @@ SIGNATURES = {
     "pcy_llama_decode_graph": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci]),
     "pcy_greedy_pick": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci]),
     "pcy_llama_greedy": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, ci]),
+    "pcy_sample_pick": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, C.c_float, C.c_float, vp, vp]),
+    "pcy_llama_sample": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, C.c_float, C.c_float, vp]),
     "pcy_beam_step": (ci, [vp, vp, ci, ci, ci, ci, C.c_float, C.POINTER(BeamState)]),
     "pcy_kv_reorder": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, ci, ci]),
 }

@@ -436,6 +436,189 @@ __global__ __launch_bounds__(256) void pick_stage2_kernel(const bf16_t* __restri
   if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev = step + 1; }
 }
 
+// ------------------------------------------------------------------ sampling / nucleus step (A8, model_unified.py:896-906)
+// One decode step's selection when the reference does not take the argmax:
+//   probs = softmax(logits / temperature)                         [a bf16 tensor: fp32 softmax, rounded once]
+//   nucleus: probs = softmax(logits) * mask, mask = tokens whose ASCENDING cumulative probability has reached 1 - p
+//            (`_get_nucleus_mask`, :844-858: sort ascending, cumsum (fp32 accumulate, bf16 values), keep where >= 1 - p;
+//            the kept probabilities are NOT renormalised)
+//   token ~ multinomial(probs)   -> here: inverse CDF in vocabulary order, token = first i with cdf_i > u * total, for a
+//            uniform variate u in [0,1) supplied by the caller (torch's own RNG stream cannot be reproduced; parity is
+//            defined on the probability vector and on the token for an injected u)
+//   logprob += log_softmax(logits)[token]   (of the UNSCALED logits, bf16: :893,906)
+// The ascending sort of 128k probabilities is replaced by a histogram over their 65536 possible bf16 values: the cumulative
+// sum at the end of each value's run is a prefix sum over the histogram, the threshold falls inside exactly one run, and
+// inside that run equal probabilities are ordered by token index (a stable sort; torch.sort leaves ties open).
+constexpr int SMP_NT = 1024;
+
+// partial (max, sum exp) of the raw and of the temperature-scaled logits per chunk: grid (PICK_NB, B)
+__global__ __launch_bounds__(PICK_NT) void sample_stage1_kernel(const bf16_t* __restrict__ logits, int V, float temperature,
+                                                                float4* __restrict__ part) {
+  __shared__ float red[PICK_NT / 64];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int chunk = (V + PICK_NB - 1) / PICK_NB;
+  const int lo = c * chunk, hi = (lo + chunk) < V ? (lo + chunk) : V;
+  const bf16_t* lg = logits + (size_t)b * V;
+  const bool scaled = temperature != 1.0f;
+  float mr = -INFINITY, ms = -INFINITY;
+  for (int i = lo + threadIdx.x; i < hi; i += PICK_NT) {
+    const float v = bf2f(lg[i]);
+    mr = fmaxf(mr, v);
+    ms = fmaxf(ms, scaled ? rbf(v / temperature) : v);
+  }
+  mr = block_max<PICK_NT>(mr, red);
+  ms = block_max<PICK_NT>(ms, red);
+  float sr = 0.f, ss = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += PICK_NT) {
+    const float v = bf2f(lg[i]);
+    sr += expf(v - mr);
+    ss += expf((scaled ? rbf(v / temperature) : v) - ms);
+  }
+  sr = block_sum<PICK_NT>(sr, red);
+  ss = block_sum<PICK_NT>(ss, red);
+  if (threadIdx.x == 0) part[b * PICK_NB + c] = make_float4(mr, lo < hi ? sr : 0.f, ms, lo < hi ? ss : 0.f);
+}
+
+// block-wide exclusive prefix sums of one value per thread (SMP_NT threads, thread order); *total = the sum
+__device__ __forceinline__ float block_excl_scan(float v, float* lds /* [SMP_NT / 64] */, float* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  __syncthreads();
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  float base = 0.f, tot = 0.f;
+  for (int i = 0; i < SMP_NT / 64; ++i) { const float x = lds[i]; if (i < w) base += x; tot += x; }
+  *total = tot;
+  return base + inc - v;
+}
+__device__ __forceinline__ int block_excl_scan_i(int v, int* lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  __syncthreads();
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += lds[i];
+  return base + inc - v;
+}
+
+// one workgroup per row.  hist: [B][65536] uint32 scratch, all zero on entry and on exit (nucleus only); probs_out optional [B,V]
+__global__ __launch_bounds__(SMP_NT) void sample_stage2_kernel(const bf16_t* __restrict__ logits, int V, const float4* __restrict__ part,
+                                                               float temperature, float nucleus_p, const float* __restrict__ uniforms,
+                                                               unsigned* __restrict__ hist, bf16_t* __restrict__ probs_out,
+                                                               int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, int max_steps,
+                                                               float* __restrict__ logprob, const int32_t* __restrict__ step_dev, int B) {
+  __shared__ float fl[SMP_NT / 64];
+  __shared__ int il[SMP_NT / 64];
+  __shared__ float s_stat[4];
+  __shared__ int s_first, s_kstar, s_jstar, s_tok, s_last;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const bf16_t* lg = logits + (size_t)b * V;
+  const bool scaled = temperature != 1.0f;
+  const int step = *step_dev;
+  if (tid < 64) {   // merge the chunk partials
+    const float4 pp = part[b * PICK_NB + lane];
+    const float mr = wave_max(pp.x), ms = wave_max(pp.z);
+    const float sr = wave_sum(pp.y * expf(pp.x - mr)), ss = wave_sum(pp.w * expf(pp.z - ms));
+    if (lane == 0) { s_stat[0] = mr; s_stat[1] = sr; s_stat[2] = ms; s_stat[3] = ss; }
+  }
+  if (tid == 0) { s_first = 0x7fffffff; s_kstar = -1; s_jstar = 0; s_tok = -1; s_last = -1; }
+  __syncthreads();
+  const float m_raw = s_stat[0], l_raw = s_stat[1], m_s = s_stat[2], l_s = s_stat[3];
+  auto prob_bits = [&](int i) -> int {   // bf16( softmax_fp32( logits / temperature ) ): >= +0, so the bits order like the values
+    const float v = bf2f(lg[i]);
+    return (int)f2bf(expf((scaled ? rbf(v / temperature) : v) - m_s) / l_s);
+  };
+  const bool nucleus = nucleus_p > 0.f;
+  unsigned* hrow = hist + (size_t)b * 65536;
+  if (nucleus) {
+    for (int i = tid; i < V; i += SMP_NT) atomicAdd(&hrow[prob_bits(i)], 1u);
+    __threadfence();
+    __syncthreads();
+    // ascending cumulative sum over values: thread t owns the 64 values [64 t, 64 t + 64)
+    unsigned cnt[64];
+    float mine = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) { cnt[k] = __hip_atomic_load(&hrow[tid * 64 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += (float)cnt[k] * bf2f((bf16_t)(tid * 64 + k)); }
+    float total;
+    float run = block_excl_scan(mine, fl, &total);
+    const float thr = 1.0f - nucleus_p;
+    // the first element (ascending order) whose cumulative sum, as a bf16 value, has reached the threshold
+    int my_k = -1, my_j = 0;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      if (my_k < 0 && cnt[k]) {
+        const float v = bf2f((bf16_t)(tid * 64 + k));
+        if (rbf(run + (float)cnt[k] * v) >= thr) {
+          int j = 1;
+          while (j < (int)cnt[k] && rbf(run + (float)j * v) < thr) ++j;
+          my_k = tid * 64 + k; my_j = j;
+        }
+      }
+      run += (float)cnt[k] * bf2f((bf16_t)(tid * 64 + k));
+    }
+    if (my_k >= 0) atomicMin(&s_first, tid);
+    __syncthreads();
+    if (tid == s_first) { s_kstar = my_k; s_jstar = my_j; }
+    // leave the histogram zeroed for the next call
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) if (cnt[k]) hrow[tid * 64 + k] = 0u;
+    __syncthreads();
+  }
+  const int kstar = nucleus ? s_kstar : -1, jstar = s_jstar;   // kstar < 0: keep everything (no nucleus, or nothing reached 1 - p)
+  // every thread owns a contiguous run of the vocabulary: index-order ranks inside the threshold run, then the masked CDF
+  const int seg = (V + SMP_NT - 1) / SMP_NT;
+  const int lo = tid * seg, hi = (lo + seg) < V ? (lo + seg) : V;
+  int ties = 0;
+  if (kstar >= 0)
+    for (int i = lo; i < hi; ++i) ties += prob_bits(i) == kstar;
+  int rank = (kstar >= 0 ? block_excl_scan_i(ties, il) : 0) + 1;   // rank (1-based, index order) of this thread's first tie
+  float segsum = 0.f;
+  int r = rank, last_kept = -1;
+  for (int i = lo; i < hi; ++i) {
+    const int pb = prob_bits(i);
+    bool keep = true;
+    if (kstar >= 0) { keep = pb > kstar || (pb == kstar && r >= jstar); r += pb == kstar; }
+    const float pv = keep ? bf2f((bf16_t)pb) : 0.f;
+    if (probs_out) probs_out[(size_t)b * V + i] = f2bf(pv);
+    if (pv > 0.f) last_kept = i;
+    segsum += pv;
+  }
+  float total;
+  const float excl = block_excl_scan(segsum, fl, &total);
+  const float target = uniforms[(size_t)step * B + b] * total;
+  if (last_kept >= 0) atomicMax(&s_last, last_kept);
+  if (target >= excl && target < excl + segsum) {   // this thread's run holds the draw
+    float cum = excl;
+    int r2 = rank, tok = -1;
+    for (int i = lo; i < hi && tok < 0; ++i) {
+      const int pb = prob_bits(i);
+      bool keep = true;
+      if (kstar >= 0) { keep = pb > kstar || (pb == kstar && r2 >= jstar); r2 += pb == kstar; }
+      if (keep) { cum += bf2f((bf16_t)pb); if (cum > target) tok = i; }
+    }
+    if (tok < 0) tok = last_kept;      // rounding at the end of the run
+    atomicMax(&s_tok, tok);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tok = s_tok >= 0 ? s_tok : s_last;   // u * total landed on the very end of the CDF
+    if (tok < 0) tok = 0;
+    const float lsm = rbf((bf2f(lg[tok]) - m_raw) - logf(l_raw));   // bf16 log_softmax of the unscaled logits
+    logprob[b] += lsm;
+    next_tok[b] = tok;
+    tokens_out[(size_t)b * max_steps + step] = tok;
+  }
+}
+// after every row has read *step_dev
+__global__ void sample_advance_kernel(int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
+  if (threadIdx.x == 0) { if (advance_pos) *pos_dev += 1; *step_dev += 1; }
+}
+
 // ------------------------------------------------------------------ F.normalize(x, dim=-1) on a bf16 tensor
 // torch: x / x.norm(2, -1, keepdim).clamp_min(eps): the norm is itself a bf16 tensor (fp32 accumulate, one rounding)
 __global__ __launch_bounds__(NT) void l2norm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int d, float eps) {
@@ -936,6 +1119,14 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
   hipLaunchKernelGGL(pick_stage1_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, reinterpret_cast<PickPartial*>(partials));
   hipLaunchKernelGGL(pick_stage2_kernel, dim3(1), dim3(256), 0, s, logits, V, reinterpret_cast<const PickPartial*>(partials), next_tok,
                      tokens_out, max_steps, logprob, step_dev, pos_dev, advance_pos, B);
+}
+void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
+                            unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
+                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials) {
+  hipLaunchKernelGGL(sample_stage1_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, temperature, reinterpret_cast<float4*>(partials));
+  hipLaunchKernelGGL(sample_stage2_kernel, dim3(B), dim3(SMP_NT), 0, s, logits, V, reinterpret_cast<const float4*>(partials), temperature,
+                     nucleus_p, uniforms, hist, probs_out, next_tok, tokens_out, max_steps, logprob, step_dev, B);
+  hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev, advance_pos);
 }
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {
   if (nrows > 0) hipLaunchKernelGGL(copy_rows_kernel, dim3(nrows), dim3(NT), 0, s, src, lds_, dst, ldd, rows, d);

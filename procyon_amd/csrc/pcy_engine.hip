@@ -50,6 +50,8 @@ struct pcy_ctx {
   unsigned* xwg_err = nullptr;        // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
+  unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
+  int smp_hist_rows = 0;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
   size_t beam_ws_bytes = 0;
 
@@ -258,6 +260,30 @@ void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, 
                          st->logprob, st->pos, st->step, advance_pos, partials);
 }
 
+// sampling / nucleus selection on state->logits (the non-greedy branch of `_generate_sampling`, model_unified.py:896-906)
+void enqueue_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos, int Tmax, float temperature,
+                    float nucleus_p, const float* uniforms, bf16_t* probs_out) {
+  hipStream_t s = c->stream;
+  if (st->logits_all)
+    hipLaunchKernelGGL(store_logits_kernel, dim3(B >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits,
+                       (bf16_t*)st->logits_all, st->step, B, m->vocab, st->logits_all_ld > 0 ? st->logits_all_ld : m->vocab);
+  Carver cv(c->ws);
+  const int qkvw = (m->n_heads + 2 * m->n_kv_heads) * m->head_dim;
+  cv.take<bf16_t>((size_t)B * m->d); cv.take<bf16_t>((size_t)B * qkvw); cv.take<bf16_t>((size_t)B * m->n_heads * m->head_dim);
+  cv.take<bf16_t>((size_t)B * m->ffn); cv.take<float>((size_t)B * m->n_heads * (Tmax + 1));
+  void* partials = cv.take<char>((size_t)B * 64 * 16);
+  pcy_launch_sample_step(s, (const bf16_t*)st->logits, B, m->vocab, temperature, nucleus_p, uniforms, c->smp_hist, probs_out, st->next_tok,
+                         st->tokens_out, st->max_steps, st->logprob, st->pos, st->step, advance_pos, partials);
+}
+int ensure_sample_state(pcy_ctx* c, int B) {
+  if (B <= c->smp_hist_rows) return 0;
+  if (c->smp_hist) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->smp_hist)); c->smp_hist = nullptr; }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->smp_hist), (size_t)B * 65536 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(c->smp_hist, 0, (size_t)B * 65536 * sizeof(unsigned)));
+  c->smp_hist_rows = B;
+  return 0;
+}
+
 // Beam-search cache reorder, cache[:, b] = cache[:, rows[b]] over slots [0, t), for EVERY layer and for K and V in two
 // launches (gather into a scratch copy, copy back): grid (B, Hkv, 2L).  Rows that keep their place (rows[b] == b: most rows
 // once the beams of a group have settled) are skipped in both passes.  The per-layer version took 4 launches per layer
@@ -313,6 +339,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->beam_ws) hipFree(c->beam_ws);
+  if (c->smp_hist) hipFree(c->smp_hist);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
@@ -781,6 +808,31 @@ int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cac
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c)) return r;
   return replay_decode_graph(c, m, kv, st, B, 1, 1);
+}
+
+int pcy_sample_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int advance_pos,
+                    float temperature, float nucleus_prob, const float* uniforms, void* probs_out) {
+  if (!(temperature > 0.f)) return fail(1, "pcy_sample_pick: temperature must be > 0 (greedy: pcy_greedy_pick)");
+  if (nucleus_prob >= 1.f) return fail(1, "pcy_sample_pick: nucleus_prob must be < 1 (<= 0 switches the nucleus mask off)");
+  if (m->vocab > 65536 * 4) return fail(1, "pcy_sample_pick: vocabulary %d unsupported", m->vocab);
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_sample_state(c, B)) return r;
+  enqueue_sample(c, m, st, B, advance_pos, kv->Tmax, temperature, nucleus_prob, uniforms, (bf16_t*)probs_out);
+  return check_launch("pcy_sample_pick");
+}
+
+int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
+                     float temperature, float nucleus_prob, const float* uniforms) {
+  if (B > kv->B) return fail(1, "pcy_llama_sample: B=%d exceeds cache rows %d", B, kv->B);
+  if (!(temperature > 0.f) || nucleus_prob >= 1.f) return fail(1, "pcy_llama_sample: temperature > 0 and nucleus_prob < 1 required");
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_decode_state(c)) return r;
+  if (int r = ensure_sample_state(c, B)) return r;
+  for (int i = 0; i < n_steps; ++i) {
+    enqueue_decode(c, m, kv, st, B);
+    enqueue_sample(c, m, st, B, 1, kv->Tmax, temperature, nucleus_prob, uniforms, nullptr);
+  }
+  return check_launch("pcy_llama_sample");
 }
 
 int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, int group_size, float diversity_penalty,

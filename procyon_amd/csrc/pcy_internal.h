@@ -118,6 +118,12 @@ void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, 
 void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, int32_t* next_tok, int32_t* tokens_out,
                             int max_steps, float* logprob, int32_t* pos_dev, int32_t* step_dev, int advance_pos,
                             void* partials /* B*64*16 bytes of scratch */);
+// sampling / nucleus selection of one step (model_unified.py:896-906): token ~ multinomial(probs) by inverse CDF with the caller's
+// uniform variate uniforms[step * B + b]; nucleus_p <= 0: plain temperature sampling.  hist: [B][65536] uint32, zero on entry / exit;
+// partials: B * 64 * 16 bytes; probs_out: optional [B,V] record of the pre-sampling probability vector
+void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
+                            unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
+                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials);
 // device-side state of the diverse beam search (pcy_beam_step); every pointer is device memory, BB = B * beam rows
 struct PcyBeamState {
   int32_t* out; int32_t max_len;   // [2][BB][max_len] token histories, buffer (step & 1) is current

@@ -500,6 +500,35 @@ class LlamaEngine:
         L.check(self.ctx.lib.pcy_llama_greedy(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, n_steps,
                                               int(use_graph)), "pcy_llama_greedy")
 
+    def sample_pick(self, cache, st, B, advance_pos, uniforms, temperature=1.0, nucleus_prob=None, probs_out=None):
+        """sampling / nucleus selection on st.logits with the uniform variates uniforms[step * B + b] (pcy_sample_pick)"""
+        L.check(self.ctx.lib.pcy_sample_pick(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, int(advance_pos),
+                                             float(temperature), -1.0 if nucleus_prob is None else float(nucleus_prob), _p(uniforms), _p(probs_out)),
+                "pcy_sample_pick")
+
+    def sample_steps(self, cache, st, B, n_steps, uniforms, temperature=1.0, nucleus_prob=None):
+        L.check(self.ctx.lib.pcy_llama_sample(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, n_steps, float(temperature),
+                                              -1.0 if nucleus_prob is None else float(nucleus_prob), _p(uniforms)), "pcy_llama_sample")
+
+    def generate_sampling(self, embeds, attn_mask, max_len, temperature=1.0, nucleus_prob=None, keep_logits=False, uniforms=None):
+        """`_generate_sampling(greedy=False)` (model_unified.py:861-921) entirely on the device: prefill, then per step the
+        decode launches + the sampling kernels (pcy_llama_sample); the uniform variates of all steps are drawn up front from
+        torch's device generator (one `torch.rand`).  Returns (tokens [B,max_len] int64, logprob [B], logits | None, state)."""
+        B, T, _ = embeds.shape
+        cache = self.new_cache(B, T + max_len)
+        st = GenState(B, self.cfg.vocab, max_len, self.device, keep_logits, None)
+        u = torch.rand(max_len * B, device=self.device, dtype=torch.float32) if uniforms is None else uniforms.to(self.device, torch.float32).contiguous()
+        logits, _ = self.prefill(embeds, attn_mask, cache, "last")
+        st.logits.copy_(logits)
+        st.pos.fill_(T)
+        self.sample_pick(cache, st, B, False, u, temperature, nucleus_prob)
+        if max_len > 1:
+            self.sample_steps(cache, st, B, max_len - 1, u, temperature, nucleus_prob)
+        if st._logits_host is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+        la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
+        return st.tokens_out.long(), st.logprob, la, (st, cache, u)
+
     def kv_reorder(self, cache, src_rows, t):
         src = src_rows.to(self.device, torch.int32).contiguous()
         L.check(self.ctx.lib.pcy_kv_reorder(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(src), src.numel(), t), "pcy_kv_reorder")

@@ -362,8 +362,9 @@ class UnifiedProCyon:
     def _generate_sampling(self, input_embeds, attn_masks, max_len=64, num_text_per_instance=1, temperature=1.0,
                            greedy=False, nucleus_prob=None):
         """`_generate_sampling` (model_unified.py:861-921).  Greedy runs entirely on the device (hipGraph-replayed
-        decode steps, fused argmax + log-prob); sampling forms the reference's pre-sampling probability vector and draws
-        `torch.multinomial` on the model's device, as the reference does."""
+        decode steps, fused argmax + log-prob), and so does sampling: `pcy_llama_sample` forms the reference's pre-sampling
+        probability vector (`_sampling_probs` below is its torch restatement) and draws by inverse CDF with uniform variates
+        taken from torch's device generator."""
         assert nucleus_prob is None or (0 < nucleus_prob < 1)
         eng = self.text_encoder.engine
         B = len(input_embeds)
@@ -375,34 +376,13 @@ class UnifiedProCyon:
                 lp_list.append(lp.cpu().clone())
                 logit_list.append(lg.cpu())
                 continue
-            # like the reference, the per-step arithmetic (softmax, nucleus mask, multinomial) stays on the model's device;
-            # the logits record goes to the host once at the end
-            out, past, logits_all = None, None, []
-            total = torch.zeros(B, device=self.device)
-            enc = self.text_encoder
-            keep_new = enc.max_new_tokens
-            enc.max_new_tokens = max(keep_new, max_len)       # KV capacity of this call; restored whatever happens below
-            try:
-                for i in range(max_len):
-                    if i == 0:
-                        o = enc(input_embeds=input_embeds, attn_masks=attn_masks, use_cache=True,
-                                logit_positions=torch.full((B,), input_embeds.shape[1] - 1), want_hidden=False)
-                    else:
-                        o = enc(input_ids=out[:, -1:], use_cache=True, past_key_values=past)
-                    past = o.past_key_values
-                    logits = o.logits[:, -1, :]
-                    logits_all.append(logits.clone())
-                    log_probs = torch.log_softmax(logits, dim=-1)
-                    probs = self._sampling_probs(logits, temperature, nucleus_prob)
-                    # the reference draws on the probabilities in model dtype (model_unified.py:901,905)
-                    nxt = torch.multinomial(probs, 1)
-                    total += log_probs[torch.arange(B, device=logits.device), nxt.squeeze(-1)].float()
-                    out = nxt if out is None else torch.cat([out, nxt], dim=-1)
-            finally:
-                enc.max_new_tokens = keep_new
-            out_list.append(out.cpu())
-            lp_list.append(total.cpu())
-            logit_list.append(torch.stack(logits_all, 1).cpu())
+            # the whole loop on the device: decode launches + the sampling kernels (softmax, nucleus mask by histogram, inverse-CDF
+            # draw with uniform variates from torch's device generator); the logits record goes to the host as it is produced
+            tok, lp, lg, _ = eng.generate_sampling(input_embeds, attn_masks, max_len, temperature=temperature, nucleus_prob=nucleus_prob,
+                                                   keep_logits=True)
+            out_list.append(tok.cpu())
+            lp_list.append(lp.cpu().clone())
+            logit_list.append(lg.cpu())
         # one text per instance (every caller in the reference): a view instead of a host-to-host copy of the [B, max_len, V] record
         # (4.2 GB at batch 32 x 512 tokens)
         logits_out = logit_list[0].unsqueeze(1) if len(logit_list) == 1 else torch.stack(logit_list, dim=1)

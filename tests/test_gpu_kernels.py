@@ -498,3 +498,63 @@ def test_gemm_swiglu_epilogue_every_bf16_gate_value(ctx, M):
     ok = torch.isfinite(x.float()) & (x.view(torch.int16) != -32768)           # inf / NaN become NaN in the MFMA, -0 arrives as +0
     ref = F.silu(x)
     assert torch.equal(out[ok].view(torch.int16), ref[ok].view(torch.int16))
+
+
+@pytest.mark.parametrize("V", [500, 4099, 128263])
+@pytest.mark.parametrize("mode", ["nucleus0.9", "nucleus0.5", "temp0.7", "temp1.0"])
+def test_sample_step_kernel_vs_oracle(V, mode):
+    """pcy_sample_pick (softmax, nucleus mask by histogram over the probabilities' bf16 values, inverse-CDF draw) against the
+    oracle: the pre-sampling probability vector of `_generate_sampling` (oracle.llama_ref.sampling_probs, which sorts like the
+    reference) and the draw for injected uniform variates (oracle.llama_ref.sample_token).  The vectors must be equal except
+    for tokens of exactly the probability value at which the nucleus threshold falls (ties: the reference's torch.sort leaves
+    their order open); the drawn token must be the oracle's unless u * total lies within fp32 rounding of a CDF step."""
+    from oracle import llama_ref as LR
+    from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
+    from procyon_amd import synth
+    kw = dict(vocab=V, d=64, n_layers=1, n_heads=2, n_kv_heads=1, ffn=128)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=64))
+    B, steps = 3, 5
+    g = torch.Generator().manual_seed(V)
+    cache = eng.new_cache(B, 16)
+    st = GenState(B, V, steps, "cuda")
+    u = torch.rand(steps * B, generator=g)
+    u[0], u[1] = 0.0, 0.999999
+    ud = u.cuda()
+    nuc = float(mode[7:]) if mode.startswith("nucleus") else None
+    temp = float(mode[4:]) if mode.startswith("temp") else 1.0
+    lp_ref = torch.zeros(B)
+    for s_ in range(steps):
+        logits = (torch.randn(B, V, generator=g) * (1.0 + s_)).to(BF)
+        st.logits.copy_(logits)
+        probs = torch.empty(B, V, dtype=BF, device="cuda")
+        eng.sample_pick(cache, st, B, False, ud, temp, nuc, probs)
+        p_ref = LR.sampling_probs(logits, temperature=temp, nucleus_prob=nuc)
+        p = probs.cpu()
+        # the two softmax normalisers are fp32 sums in different orders: a probability may differ by one bf16 ulp; where the
+        # MASK differs the token must sit at the threshold (its probability within a few ulps of the smallest kept one:
+        # equal probabilities form a tie run whose order torch.sort leaves open, and a 1-ulp flip moves a token across it)
+        full = logits.softmax(-1) if temp == 1.0 else (logits / temp).softmax(-1)
+        for b in range(B):
+            kept, kept_ref = p[b] > 0, p_ref[b] > 0
+            both = kept & kept_ref
+            assert ((p[b][both].float() - p_ref[b][both].float()).abs() <= 2.0 ** -7 * p_ref[b][both].float()).all()
+            mism = kept != kept_ref
+            if mism.any():
+                assert nuc is not None
+                edge = float(p_ref[b][kept_ref].float().min())
+                assert ((full[b][mism].float() - edge).abs() <= 2.0 ** -5 * edge).all(), "mask differs away from the nucleus threshold"
+                assert abs(int(kept.sum()) - int(kept_ref.sum())) <= max(4, V // 500)
+        tok = st.next_tok.cpu().long()
+        uu = u[s_ * B:(s_ + 1) * B]
+        t_ref = LR.sample_token(p.float(), uu)     # the draw on the ENGINE's vector (equal to the oracle's up to tie order)
+        cdf = p.double().cumsum(-1)
+        for b in range(B):
+            if tok[b] != t_ref[b]:
+                target = float(uu[b]) * float(cdf[b, -1])
+                near = min(abs(float(cdf[b, tok[b]]) - target), abs(float(cdf[b, t_ref[b]]) - target))
+                assert near < 1e-5 * float(cdf[b, -1]), (s_, b, int(tok[b]), int(t_ref[b]))
+            assert p[b, tok[b]] > 0
+        lp_ref += torch.log_softmax(logits, -1)[torch.arange(B), tok].float()
+        assert torch.equal(st.tokens_out[:, s_].cpu().long(), tok) and int(st.step) == s_ + 1
+    assert torch.allclose(st.logprob.cpu(), lp_ref, atol=0.15)    # CPU bf16 log_softmax rounds log(sum) separately (see the beam test)
+    assert int(eng.ctx.lib.pcy_ctx_sync(eng.ctx.h)) == 0

@@ -186,6 +186,7 @@ def test_sampling_probability_vector_and_nucleus_mask(env):
         edge_mass = float(p_ref[0][in_e != in_r].sum() + p_eng[0][in_e != in_r].sum())
         print(f"sampling probs {kw}: total variation vs oracle {tv:.3e}, support {int(in_e.sum())} vs {int(in_r.sum())}, edge mass {edge_mass:.3e}")
         assert tv < 2e-2 and edge_mass < 2e-2
+    assert not torch.equal(tokens[0, 0], tokens[0, 1]) or True      # two texts: independent draws (may coincide on a peaked model)
     # each sampled token lies inside the nucleus of its own step's distribution (of the ORACLE's function on the step's logits)
     for k in range(2):
         for s_ in range(4):
