@@ -264,6 +264,13 @@ def main():
         configs = {"config3_4a_batch32_mixed_residues_T512": WL.run_config4(model, new_tokens=512, ragged=False),
                    "config3_4b_batch32_ragged_prompts": WL.run_config4(model, new_tokens=512, ragged=True),
                    "config4_pair_scoring_256": WL.run_config5(model, pairs=256, chunk=64, fp8=True)}
+        # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like
+        # regime instead of the chaotic random-init one), LAST because it rewrites the decoder's weights in place
+        WL.damp_residual_branches(model, 0.25)
+        acc = WL.run_config5(model, pairs=128, chunk=64, fp8=True)
+        configs["config4_fp8_accuracy_damped_model"] = {k: acc[k] for k in ("pairs", "answer_logits_rel_err_fp8_vs_bf16",
+                                                                              "yes_no_agreement_fp8_vs_bf16", "mean_abs_dP_yes")}
+        configs["config4_fp8_accuracy_damped_model"]["residual_branch_scale"] = 0.25
 
     if rank == 0:
         out = {"metric": "phenotype-gen tokens/sec (ProCyon-Full greedy generation, end to end)", "value": round(value, 2),

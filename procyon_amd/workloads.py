@@ -81,6 +81,21 @@ def score_pairs(model, pairs=256, chunk=64):
     return torch.cat(ys), torch.cat(ls)
 
 
+def damp_residual_branches(model, scale):
+    """Multiply the o and down projections of every decoder layer by `scale` IN PLACE (and drop cached fp8 copies).  With
+    N(0, 0.02^2) weights every residual branch is as large as the stream it is added to and 32 layers amplify a 2^-9 rounding
+    into ~8 % of the logits (tests/test_gpu_fulldepth.py) -- any two arithmetics then disagree on a yes/no coin flip.  Trained
+    decoders keep their branches a fraction of the stream; scale ~ 0.25 puts the synthetic model into that regime, where the
+    agreement between the fp8 and the bf16 weight path says something about the fp8 path."""
+    eng = model.text_encoder.engine
+    for ws in eng._keep:
+        ws[1].mul_(scale)       # wo
+        ws[3].mul_(scale)       # wdown
+    eng.set_fp8(False)
+    eng._arr8 = None            # the e4m3 copies are re-made from the scaled matrices on the next quantize_fp8()
+    eng._keep8 = []
+
+
 def run_config5(model, pairs=256, chunk=64, fp8=True):
     """pairs/s with bf16 weights and on the fp8 weight path, algorithmic TFLOP/s of the Llama prefill part (2 * params * tokens
     + attention), and how far the fp8 path's answers are from the bf16 path's"""
