@@ -133,6 +133,17 @@ __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// Vectors handed from one workgroup to another INSIDE a launch (CDNA4 guide, Guideline 16 R1): written through (sc1 stores), the
+// writing waves drain (s_waitcnt vmcnt(0)), ONE flag store per workgroup; the reader polls relaxed and then loads with
+// L1-bypassing (agent-scope) loads.  Placement-independent.
+__device__ __forceinline__ uint4 ld16_agent(const void* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void st_bf16_agent(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Epilogue selectors shared by the GEMM (prefill / encoder) and GEMV (decode) kernels.
 enum PcyEpi : int {
   EPI_STORE = 0,      // y = bf16(acc [+ bias])

@@ -128,10 +128,13 @@ __global__ __launch_bounds__(NT) void layernorm_wave_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------ embedding lookup + soft-token splice (A5)
 __global__ __launch_bounds__(NT) void embed_gather_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
                                                           const bf16_t* __restrict__ soft, const int32_t* __restrict__ soft_map,
-                                                          bf16_t* __restrict__ out, int d, unsigned* __restrict__ epoch) {
+                                                          bf16_t* __restrict__ out, int d, unsigned* __restrict__ epoch, unsigned* __restrict__ epoch2) {
   const int r = blockIdx.x;
-  // first launch of a decode step: also advances the epoch word of the step's in-launch hand-overs (was a launch of its own)
-  if (epoch && r == 0 && threadIdx.x == 0) *epoch += 1;
+  // first launch of a decode step: also advances the epoch words of the step's in-launch hand-overs (was a launch of its own)
+  if (r == 0 && threadIdx.x == 0) {
+    if (epoch) *epoch += 1;
+    if (epoch2) *epoch2 += 1;
+  }
   const int sm = soft_map ? soft_map[r] : -1;
   const bf16_t* src = sm >= 0 ? soft + (size_t)sm * d : table + (size_t)ids[r] * d;
   for (int k = threadIdx.x * 8; k < d; k += NT * 8)
@@ -1079,10 +1082,11 @@ void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const
 }
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
-  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr);
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr, (unsigned*)nullptr);
 }
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch) {
-  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch);
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch,
+                                 unsigned* epoch2) {
+  if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch, epoch2);
 }
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads) {

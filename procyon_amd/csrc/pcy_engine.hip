@@ -50,6 +50,10 @@ struct pcy_ctx {
   unsigned* xwg_err = nullptr;        // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
+  // tagged hand-over vectors of the MLP chain launches: [layer][ffn + d] words, owned by one model geometry at a time
+  uint32_t* mc_tags = nullptr;
+  const void* mc_tags_model = nullptr;
+  size_t mc_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
   int smp_hist_rows = 0;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
@@ -117,11 +121,19 @@ bool attn_o_enabled() {
   const char* e = getenv("PCY_ATTN_O");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return attn_o_enabled() ? 2 : 0; }
+// PCY_MLP_CHAIN=0 switches the fused MLP + next-qkv launch of the batch-1 decode step off (default on): gate/up, down and the
+// next layer's qkv projection as ONE launch whose two all-to-all hand-overs hide behind the next stage's weight prefetch
+// (pcy_gemv.hip, mlp_chain_kernel).  Read on every call: tests compare both paths in one process (bit-identical).
+unsigned long long* g_mc_trace = nullptr;
+bool mlp_chain_enabled() {
+  const char* e = getenv("PCY_MLP_CHAIN");
+  return !e || atoi(e) != 0;
+}
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // device words of the in-launch hand-overs; must run outside stream capture
-int ensure_decode_state(pcy_ctx* c) {
+int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
   if (!c->n_cu) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -132,9 +144,22 @@ int ensure_decode_state(pcy_ctx* c) {
     HIP_TRY(hipMemset(c->xwg_err, 0, 64));
   }
   if (!c->ao_sync) {
-    const size_t bytes = (size_t)(64 + 2 * AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);   // epoch, attention->o flags, score-exchange flags
+    // [0] step epoch, [1] epoch of the MLP chain launches, attention->o flags, score-exchange flags
+    const size_t bytes = (size_t)(64 + 2 * AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ao_sync), bytes));
     HIP_TRY(hipMemset(c->ao_sync, 0, bytes));
+  }
+  // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
+  // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
+  const size_t words = (size_t)m->n_layers * ((size_t)m->ffn + m->d);
+  if (c->mc_tags_model != m || c->mc_tags_words != words) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->mc_tags) hipFree(c->mc_tags);
+    c->mc_tags = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
+    HIP_TRY(hipMemset(c->mc_tags, 0, words * 4));
+    HIP_TRY(hipMemset(c->ao_sync + 1, 0, 4));
+    c->mc_tags_model = m; c->mc_tags_words = words;
   }
   return 0;
 }
@@ -163,7 +188,10 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   const bool batched = B > 4 && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
-  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr);
+  const bool try_mc = mlp_chain_enabled() && B == 1 && c->ao_sync && c->xwg_err && c->mc_tags;
+  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
+                              try_mc ? c->ao_sync + 1 : nullptr);
+  bool qkv_done = false;   // the previous layer's MLP chain launch has already produced this layer's qkv
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
   for (int l = 0; l < m->n_layers; ++l) {
@@ -177,7 +205,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       xn_ready = 0;
       g.x = xn; g.rms_w = nullptr;
     }
-    pcy_launch_gemv(s, g);
+    if (!qkv_done) pcy_launch_gemv(s, g);
+    qkv_done = false;
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
@@ -193,6 +222,21 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
                                        c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
       pcy_launch_attn_decode(s, t);
       pcy_launch_gemv(s, o);
+    }
+    if (try_mc) {   // gate/up + down + the next layer's qkv in one launch
+      PcyMlpChainArgs mc{};
+      mc.x = x; mc.x_out = x; mc.ln2 = (const bf16_t*)L.ln2; mc.wgu = (const bf16_t*)L.wgu; mc.wdown = (const bf16_t*)L.wdown;
+      if (l + 1 < m->n_layers) {
+        mc.ln_next = (const bf16_t*)m->layers[l + 1].ln1; mc.wqkv_next = (const bf16_t*)m->layers[l + 1].wqkv; mc.qkv_next = qkv; mc.Nq = qkvw;
+      }
+      mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast;
+      mc.act_tag = c->mc_tags + (size_t)l * (F + d); mc.x_tag = mc.act_tag + F;
+      mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
+      if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
+        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 128 * 256 * 16 * 8); }
+        mc.trace = g_mc_trace + (size_t)l * 256 * 16;
+      }
+      if (pcy_launch_mlp_chain(s, mc, c->n_cu)) { qkv_done = l + 1 < m->n_layers; continue; }
     }
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
@@ -338,6 +382,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
+  if (c->mc_tags) hipFree(c->mc_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -741,7 +786,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c)) return r;
+  if (int r = ensure_decode_state(c, m)) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
@@ -792,7 +837,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
                      int use_graph) {
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c)) return r;
+  if (int r = ensure_decode_state(c, m)) return r;
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       enqueue_decode(c, m, kv, st, B);
@@ -806,7 +851,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
 int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
   if (B > kv->B) return fail(1, "pcy_llama_decode_graph: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c)) return r;
+  if (int r = ensure_decode_state(c, m)) return r;
   return replay_decode_graph(c, m, kv, st, B, 1, 1);
 }
 
@@ -826,7 +871,7 @@ int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (B > kv->B) return fail(1, "pcy_llama_sample: B=%d exceeds cache rows %d", B, kv->B);
   if (!(temperature > 0.f) || nucleus_prob >= 1.f) return fail(1, "pcy_llama_sample: temperature > 0 and nucleus_prob < 1 required");
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c)) return r;
+  if (int r = ensure_decode_state(c, m)) return r;
   if (int r = ensure_sample_state(c, B)) return r;
   for (int i = 0; i < n_steps; ++i) {
     enqueue_decode(c, m, kv, st, B);
@@ -875,3 +920,10 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
 }
 
 }  // extern "C"
+
+extern "C" int pcy_debug_mc_trace(unsigned long long* out, int n) {
+  if (!g_mc_trace) return 0;
+  hipDeviceSynchronize();
+  hipMemcpy(out, g_mc_trace, (size_t)n * 8, hipMemcpyDeviceToHost);
+  return n;
+}

@@ -734,7 +734,318 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batch-1 decode: gate/up + SwiGLU -> down + residual -> the NEXT layer's qkv projection as ONE launch (PcyMlpChainArgs).
+//
+// As three launches each stage pays a kernel boundary (~1.7 us) and its own ramp (~3.4 us: first bytes after the launch, uneven
+// tail) on 12-42 us of streaming, and HBM idles meanwhile.  Here 256 workgroups (one per CU, 8 waves, all resident) run the
+// three stages back to back.  A stage needs the WHOLE output vector of the one before it, produced by all workgroups.
+//
+// Hand-over without flags: a producer stores every element as ONE 32-bit word {tag : bf16 value}, tag = low half of a device
+// counter that advances once per decode step, written through to memory (agent scope) and never waited for.  A consumer loads
+// the words it wants with L1-bypassing loads and accepts them when every tag is the current one, else asks again: one memory
+// round trip when the data is there, no store drain, no second trip for a flag (in-kernel stamps of the flag version: 5 us from
+// the last flag to the vector in LDS, both trips queued behind the workgroup's own weight prefetch).  Each vector lives in a
+// per-layer slot, so a word with the current tag can only have been written by THIS launch.
+//
+//   gate/up -> down: a wave produces its two units in slot order, so the first half of `act` is complete chip-wide when a wave
+//     is half way through its rows.  A wave that has finished its gate/up rows requests its share of the first half of act and,
+//     right behind it, the first two batches (28 KB) of its down rows; the second half of act is requested next and checked only
+//     two batches later (~9 us), by when the slowest workgroup has delivered it.  Nobody waits for the hop and the spread of
+//     the workgroups' finishing times (34-43 us) is absorbed instead of added.
+//   down -> qkv:  a true barrier (RMSNorm needs every element).  Each wave asks for its share of the tagged residual stream
+//     FIRST, then requests ALL of its qkv rows (24 KB, they depend on nothing) -- loads return in order, so the first answer is not
+//     queued behind the weights; early workgroups stream the 50 MB of Wqkv while the late ones finish.
+//
+// Arithmetic per output row = gemv_stream_kernel's (same k order of the accumulation, same reduction tree, same rounding
+// points); the RMSNorm statistic is summed in the order of the stand-alone launch (`vthr` threads, block_sum_rt): bit-identical.
+constexpr int MC_NT = 512, MC_WV = 8, MC_UNB_D = 7;
+
+__device__ __forceinline__ void st8_agent(void* p, uint32_t lo, uint32_t hi) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// This wave's share of a tagged vector -> LDS as plain bf16: words [w0 + (j*64 + lane)*4, +4), j < NV.  `pre` holds loads issued
+// earlier by mc_fetch_issue (checked first); asks again until every tag matches.
+template <int NV>
+__device__ __forceinline__ void mc_fetch_issue(const uint32_t* src, int w0, int lane, uint4 (&pre)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) pre[j] = ld16_agent(src + w0 + (j * 64 + lane) * 4);
+}
+template <int NV>
+__device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int lane, uint32_t tag, bf16_t* dst, uint4 (&pre)[NV], unsigned* err,
+                                                unsigned code) {
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
+    if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+    if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    __builtin_amdgcn_s_sleep(16);
+    mc_fetch_issue<NV>(src, w0, lane, pre);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    *reinterpret_cast<uint2*>(dst + w0 + (j * 64 + lane) * 4) =
+        make_uint2((pre[j].x & 0xffffu) | (pre[j].y << 16), (pre[j].z & 0xffffu) | (pre[j].w << 16));
+}
+
+// xs[0..K) = bf16( RMSNorm(x) * w ) with the statistic summed like gemv_stream_kernel launched with `vthr` threads.  x: global
+// (written before this launch) or LDS.  K <= 8 * MC_NT.  All threads; ends with a barrier.
+template <typename AfterLoads>
+__device__ __forceinline__ void mc_rms_stage(const bf16_t* x, const bf16_t* __restrict__ w, int K, int vthr, float eps, int cast,
+                                             bf16_t* xs, float* red, AfterLoads after_loads) {
+  const int tid = threadIdx.x;
+  auto ldx = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const uint4*>(x + k); };
+  // vector loads return in order: x (a few KiB, the head of the dependent chain) is requested BEFORE any weight batch
+  uint4 xr[4], xv = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (tid + i * vthr) * 8;
+    xr[i] = (tid < vthr && k < K) ? ldx(k) : make_uint4(0, 0, 0, 0);
+  }
+  const int ks = tid * 8;
+  if (ks < K) { xv = ldx(ks); g = *reinterpret_cast<const uint4*>(w + ks); }
+  after_loads();
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (tid + i * vthr) * 8;
+    if (tid < vthr && k < K) {
+      const uint32_t w4[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
+    }
+  }
+  ss = block_sum_rt(ss, red, vthr >> 6);
+  const float rs = rsqrtf(ss / (float)K + eps);
+  if (ks < K) {
+    const uint32_t xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = lo_bf(xin[j]) * rs, x1 = hi_bf(xin[j]) * rs;
+      if (cast == 0) { x0 = rbf(x0); x1 = rbf(x1); }
+      o[j] = pack_bf(lo_bf(gin[j]) * x0, hi_bf(gin[j]) * x1);
+    }
+    *reinterpret_cast<uint4*>(xs + ks) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  __syncthreads();
+}
+
+// One wave streams its units (RW weight rows each, row i of unit u at W + row_off(u, i)) against xs, UNB k-iterations of 512
+// elements per batch, two batches in flight (wa / wb).  primed: the first two batches of (u0, it 0) are already in wa / wb.
+// before_batch(it0) runs ahead of the arithmetic of every batch (the down stage waits there for the second half of its input).
+template <int RW, int UNB, typename RowOff, typename Finish, typename Before>
+__device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, const bf16_t* xs, int lane, int u0, int ustride, int uend,
+                                          uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch) {
+  static_assert(RW * UNB <= 16, "batch size");
+  const int nit = K >> 9;
+  auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int un = 0; un < UNB; ++un) {
+      const int k = ((it0 + un) * 64 + lane) * 8;
+      const bool ok = (it0 + un) < nit;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  float acc[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+  auto compute = [&](int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int un = 0; un < UNB; ++un) {
+      if ((it0 + un) < nit) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + ((it0 + un) * 64 + lane) * 8);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) acc[i] = dot8(w[un * RW + i], xv, acc[i]);
+      }
+    }
+  };
+  auto next_pos = [&](int cu, int cit, int& nu, int& nit_) __attribute__((always_inline)) { nit_ = cit + UNB; nu = cu; if (nit_ >= nit) { nit_ = 0; nu = cu + ustride; } };
+  int u = u0, it0 = 0, u1, it1;
+  bool have = u < uend;
+  next_pos(u, 0, u1, it1);
+  bool have1 = have && u1 < uend;
+  if (!primed) {
+    if (have) issue(u, 0, wa);
+    if (have1) issue(u1, it1, wb);
+  }
+#define PCY_MC_STEP(CUR)                                   \
+  {                                                        \
+    before_batch(it0);                                     \
+    compute(it0, CUR);                                     \
+    if (it0 + UNB >= nit) {                                \
+      _Pragma("unroll") for (int i = 0; i < RW; ++i) acc[i] = wave_sum(acc[i]); \
+      finish(u, acc);                                      \
+      _Pragma("unroll") for (int i = 0; i < RW; ++i) acc[i] = 0.f; \
+    }                                                      \
+    int u2, it2;                                           \
+    next_pos(u1, it1, u2, it2);                            \
+    const bool have2 = have1 && u2 < uend;                 \
+    if (have2) issue(u2, it2, CUR);                        \
+    u = u1; it0 = it1; have = have1;                       \
+    u1 = u2; it1 = it2; have1 = have2;                     \
+  }
+  while (have) {
+    PCY_MC_STEP(wa)
+    if (!have) break;
+    PCY_MC_STEP(wb)
+  }
+#undef PCY_MC_STEP
+}
+// request the first two batches of unit u0 (what mc_stream(primed = true) expects to find)
+template <int RW, int UNB, typename RowOff>
+__device__ __forceinline__ void mc_prime(const bf16_t* __restrict__ W, int K, int lane, int u0, int ustride, int uend, uint4 (&wa)[16], uint4 (&wb)[16],
+                                         RowOff row_off) {
+  const int nit = K >> 9;
+  auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int un = 0; un < UNB; ++un) {
+      const int k = ((it0 + un) * 64 + lane) * 8;
+      const bool ok = (it0 + un) < nit;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (u0 < uend) {
+    issue(u0, 0, wa);
+    int u1 = u0, it1 = UNB;
+    if (it1 >= nit) { it1 = 0; u1 = u0 + ustride; }
+    if (u1 < uend) issue(u1, it1, wb);
+  }
+}
+
+__global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, int vthr_gu, int vthr_qkv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int d = a.d, F = a.F;
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                      // [d]  normalised input of stage 1, later of stage 3
+  bf16_t* xa = xs + d;                                               // [F]  act
+  bf16_t* xr = xa + F;                                               // [d]  the residual stream after the MLP
+  float* red = reinterpret_cast<float*>(xr + d);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar branches on it)
+  const int G = gridDim.x, NW = G * MC_WV;
+  const int gw = blockIdx.x * MC_WV + wave;
+  const uint32_t tag = *a.epoch & 0xffffu;
+  uint4 wa[16], wb[16], tq[4];
+  unsigned long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
+#define MC_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
+  MC_T(0)
+
+  // down rows: one unit of two rows per wave (d == 2 * NW), MC_UNB_D k-iterations per batch
+  const int units_d = d / 2, r0 = gw * 2;
+  auto row_d = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(u * 2 + i) * F; };
+  const int half = F >> 1;                                           // act words per half; waves 0..6 fetch 1024 words of it each
+
+  // ---- stage 1: act = SwiGLU( RMSNorm(x) * ln2 . Wgu^T ): units of 4 features (8 weight rows), 7 waves per workgroup ----
+  const int units_g = (F + 3) / 4, NWG7 = G * 7, gidx = blockIdx.x * 7 + wave;
+  auto row_g = [&](int u, int i) __attribute__((always_inline)) -> size_t {
+    const int f = u * 4 + (i & 3);
+    const int fc = f < F ? f : F - 1;
+    return (size_t)((fc >> 4) * 32 + (fc & 15) + (i >= 4 ? 16 : 0)) * d;
+  };
+  mc_rms_stage(a.x, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
+    if (wave < 7) mc_prime<8, 2>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g);
+  });
+  if (wave < 7) {
+    mc_stream<8, 2>(a.wgu, d, xs, lane, gidx, NWG7, units_g, wa, wb, true, row_g, [&](int u, const float (&acc)[8]) __attribute__((always_inline)) {
+      if (lane == 0) {
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float g = rbf(acc[i]), up = rbf(acc[i + 4]);
+          o[i] = (tag << 16) | f2bf(rbf(silu_f(g)) * up);
+        }
+        st8_agent(a.act_tag + u * 4, o[0], o[1]);
+        st8_agent(a.act_tag + u * 4 + 2, o[2], o[3]);
+      }
+    }, [](int) __attribute__((always_inline)) {});
+    MC_T(1)
+    // ---- stage 2 begins for this wave: first half of act, then the first two batches of its down rows ----
+    mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);
+  }
+  mc_prime<2, MC_UNB_D>(a.wdown, F, lane, gw, NW, units_d, wa, wb, row_d);
+  if (wave < 7) {
+    mc_fetch_finish<4>(a.act_tag, wave * 1024, lane, tag, xa, tq, a.err, 6u);
+    mc_fetch_issue<4>(a.act_tag, half + wave * 1024, lane, tq);   // second half: checked nb/2 batches from now
+  }
+  __syncthreads();
+  MC_T(2)
+  const bool chain = a.wqkv_next != nullptr;
+  const int units_q = (a.Nq + 2) / 3;
+  auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { const int r = u * 3 + i; return (size_t)(r < a.Nq ? r : a.Nq - 1) * d; };
+  float acc[2] = {0.f, 0.f};
+  const int it_half = (F >> 9) / 2;
+  mc_stream<2, MC_UNB_D>(a.wdown, F, xa, lane, gw, NW, units_d, wa, wb, true, row_d,
+                         [&](int u, const float (&acc2)[2]) __attribute__((always_inline)) { acc[0] = acc2[0]; acc[1] = acc2[1]; },
+                         [&](int it0) __attribute__((always_inline)) {
+                           if (it0 == it_half) {   // (workgroup-uniform: every wave walks the same batches of its one unit)
+                             if (wave < 7) mc_fetch_finish<4>(a.act_tag, half + wave * 1024, lane, tag, xa, tq, a.err, 7u);
+                             __syncthreads();
+                             MC_T(3)
+                           }
+                         });
+  // ---- x_out = x + act . Wdown^T ----
+  if (lane == 0) {
+    uint32_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v = rbf(acc[i]);
+      v = rbf(v + bf2f(a.x[r0 + i]));
+      o[i] = f2bf(v);
+    }
+    *reinterpret_cast<uint32_t*>(a.x_out + r0) = o[0] | (o[1] << 16);
+    if (chain) st8_agent(a.x_tag + r0, (tag << 16) | o[0], (tag << 16) | o[1]);
+  }
+  MC_T(4)
+  if (!chain) return;
+  // ---- stage 3: qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T.  The tagged vector is asked for first, then every row ----
+  uint4 tx[2];
+  mc_fetch_issue<2>(a.x_tag, wave * 512, lane, tx);
+  mc_prime<3, 5>(a.wqkv_next, d, lane, gw, NW, units_q, wa, wb, row_q);
+  mc_fetch_finish<2>(a.x_tag, wave * 512, lane, tag, xr, tx, a.err, 8u);
+  __syncthreads();
+  MC_T(5)
+  mc_rms_stage(xr, a.ln_next, d, vthr_qkv, a.rms_eps, a.rms_cast, xs, red, []() __attribute__((always_inline)) {});
+  MC_T(6)
+  mc_stream<3, 5>(a.wqkv_next, d, xs, lane, gw, NW, units_q, wa, wb, true, row_q, [&](int u, const float (&acc3)[3]) __attribute__((always_inline)) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int n = u * 3 + i;
+        if (n < a.Nq) a.qkv_next[n] = f2bf(rbf(acc3[i]));
+      }
+    }
+  }, [](int) __attribute__((always_inline)) {});
+  MC_T(7)
+#undef MC_T
+}
+
 }  // namespace
+
+bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
+  // 256 workgroups, one per CU, must all be resident (every hand-over needs every workgroup's rows).  Geometry: one down unit
+  // (two rows) per wave, act halves of whole k-batches, a wave's share of a tagged vector in 4 (act) / 2 (x) loads per lane.
+  const int NW = GEMV_CUS * MC_WV;
+  if (n_cu < GEMV_CUS || a.d != 2 * NW || a.d != MC_WV * 512 || a.F != 2 * 7 * 1024 || a.F % (2 * 512 * MC_UNB_D)) return false;
+  const size_t smem = (size_t)(2 * a.d + a.F) * 2 + 128;
+  if (smem > 64 * 1024) return false;
+  if (a.wqkv_next && a.Nq <= 0) return false;
+  auto vthr_of = [](int N) {   // threads of the stand-alone RMS-fused launch (launch_nb / pick_grid): the order of its statistic
+    const int R = ((N + 3) / 4 < GEMV_MAX_WAVES) ? 2 : 4;
+    int blocks, wpb;
+    pick_grid((N + R - 1) / R, blocks, wpb);
+    return wpb * 64;
+  };
+  hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, vthr_of(a.F), a.wqkv_next ? vthr_of(a.Nq) : 64);
+  return true;
+}
+
 
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   PcyGemvArgs a0 = a00;

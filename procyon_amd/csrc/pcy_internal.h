@@ -22,6 +22,24 @@ struct PcyGemvArgs {
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
+// Batch-1 decode: the MLP of a layer and the qkv projection of the NEXT layer in ONE launch (pcy_gemv.hip, mlp_chain_kernel):
+//   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) ;  x_out = x + act . Wdown^T ;  qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T
+// One workgroup per CU, all resident; the vectors handed from stage to stage travel as {tag : bf16} words (no flags, no
+// drains), see the kernel.  Bit-identical to the three stand-alone GEMV launches.
+struct PcyMlpChainArgs {
+  const bf16_t* x; bf16_t* x_out;          // residual stream [d] (may alias)
+  const bf16_t* ln2; const bf16_t* wgu;    // [d], [2F, d] gate/up interleaved in blocks of 16 rows
+  const bf16_t* wdown;                     // [d, F]
+  const bf16_t* ln_next; const bf16_t* wqkv_next; bf16_t* qkv_next; int Nq;   // nullptr / 0: no projection follows (last layer)
+  int d, F; float rms_eps; int rms_cast;
+  uint32_t* act_tag; uint32_t* x_tag;      // [F], [d] tagged hand-over vectors, private to THIS layer's launch
+  const unsigned* epoch;                   // device word advanced once per decode step that runs these launches (tag = low 16 bits)
+  unsigned* err;                           // watchdog word
+  unsigned long long* trace;               // measurement aid: [grid][16] time stamps (nullptr: none)
+};
+// false = geometry not covered (nothing launched)
+bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu);
+
 struct PcyGemmArgs {
   const bf16_t* A;      // [M,K] lda
   const bf16_t* W;      // [N,K] row-major; EPI_SWIGLU: N counts interleaved gate/up rows (output width N/2)
@@ -57,7 +75,8 @@ void pcy_launch_layernorm(hipStream_t s, const bf16_t* x, const bf16_t* w, const
 void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* ids, const bf16_t* soft,
                              const int32_t* soft_map, bf16_t* out, int rows, int d);
 // epoch (optional): device word incremented by the launch (decode step: epoch of the in-launch hand-overs)
-void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch = nullptr);
+void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch = nullptr,
+                                 unsigned* epoch2 = nullptr);
 void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* toks, const int32_t* cu, int nseq,
                           int max_len, bf16_t* out, int d, int mask_pads);
 // rope on heads [0,nh) located at column col0 of a token-major buffer; pos[tok] = rotary position.

@@ -240,6 +240,44 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
             assert torch.equal(x, y), use_graph
 
 
+@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (40, 12, 2), (1100, 6, 2)])
+def test_decode_mlp_chain_launch_bit_identical(monkeypatch, T, N, n_layers):
+    """PCY_MLP_CHAIN (default on): gate/up + SwiGLU, down + residual and the NEXT layer's qkv projection in ONE launch, the two
+    all-to-all dependencies as in-launch flag hand-overs hidden behind the next stage's weight prefetch.  Same per-row arithmetic
+    and the same order of the RMSNorm statistic as the three stand-alone launches: logits, tokens, log-probabilities and the
+    appended K/V must be BIT-identical to PCY_MLP_CHAIN=0, eager and under hipGraph replay, over enough steps that a stale flag or
+    a vector read too early would show; the watchdog must stay silent."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))
+    torch.manual_seed(4)
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(chain, use_graph):
+        monkeypatch.setenv("PCY_MLP_CHAIN", "1" if chain else "0")
+        cache = eng.new_cache(1, T + N + 2)
+        st = GenState(1, kw["vocab"], N + 2, "cuda")
+        logits, _ = eng.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng.pick(cache, st, 1, advance_pos=False)
+        out = []
+        for i in range(N):
+            if i % 3 == 2:
+                continue
+            eng.greedy_steps(cache, st, 1, 2 if i % 3 == 1 else 1, use_graph=use_graph)
+            out.append(st.logits[0].clone())
+        Context.get().sync()
+        return (torch.stack(out).cpu(), st.tokens_out[0, :N + 1].cpu(), st.logprob.cpu().clone(), cache.k[:, 0, :, T:T + N].cpu(),
+                cache.v[:, 0, :, T:T + N].cpu())
+
+    ref = run(False, False)
+    for use_graph in (False, True, True):
+        got = run(True, use_graph)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), use_graph
+
+
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
     """Batched decode (B > 4, skinny-MFMA GEMVs with K split): the finish kernel of the o / down projections also writes the
     RMSNorm that follows (PCY_FINISH_NORM, default on).  Same element assignment and reduction order as the two separate
