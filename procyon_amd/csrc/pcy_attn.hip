@@ -12,6 +12,7 @@
 // (2) attn_dec_scores / attn_dec_pv: one new token per row against the KV cache, RoPE + cache append fused.
 #include <stdlib.h>
 #include "pcy_internal.h"
+#include "pcy_handover.h"
 
 namespace {
 
@@ -685,6 +686,169 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Decode attention block (batch 1): qkv projection + attention + o projection in ONE launch (PcyAttnBlockArgs).
+//
+// The attention of a decode step is a latency chain, the two projections around it are bandwidth.  As launches (qkv GEMV,
+// attention + o) the chain starts only when the whole qkv vector is in memory and a kernel boundary later.  Here
+//   workgroups [0, n_attn)   run attn_dec_body unchanged: the cache rows (keys, V slices), the rotary rows and the position are
+//                            requested in the first cycle -- they do not depend on the new token -- and only then the body's
+//                            inputs_ready hook waits for the G + 2 rows of the new token's q / k / v that THIS kv head needs
+//                            (tagged words, pcy_handover.h), staged in LDS;
+//   workgroups [n_attn, 256) hold their 4 rows of Wqkv in registers (32 KB per wave, requested right behind x), project,
+//                            store tagged; then pull their 3 rows of Wo into the same registers while the attention runs,
+//                            take the attention output (tagged) and finish with the residual epilogue.
+// Attention workgroups have the lowest indices and wait only for projection workgroups, which wait for nobody before their
+// stores: no dead-lock whatever the residency.  Per-row arithmetic, accumulation order and rounding points are those of
+// gemv_stream_kernel (qkv: RMSNorm statistic summed with the stand-alone launch's `vthr` threads) and of attn_o_kernel.
+template <int DH, int G>
+__global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, int n_attn, const unsigned* step_epoch,
+                                                         int vthr_qkv, size_t stage_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t tag = *p.epoch & 0xffffu;
+  if ((int)blockIdx.x < n_attn) {
+    constexpr int slices = DH / 16;
+    const int unit = blockIdx.x;
+    const int bx = (unit / a.Hkv) % slices, kvh = unit % a.Hkv;   // kv head in the low digits: the slices of a head share an XCD's L2
+    bf16_t* stage = reinterpret_cast<bf16_t*>(smem + stage_off);   // [G + 2][DH]
+    a.xepoch = *step_epoch;
+    a.xerr = p.err;
+    a.staged = stage; a.o_tag = p.ao_tag; a.tag = tag;
+    const uint32_t* qt = p.qkv_tag;
+    const int H = a.H, Hkv = a.Hkv;
+    unsigned* err = p.err;
+    auto hook = [=]() __attribute__((always_inline)) {
+      constexpr int NV4 = (G + 2) * DH / 4;          // one uint4 of tagged words per thread
+      const int seg = tid / (DH / 4), e4 = tid % (DH / 4);
+      const int w0 = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
+      const bool mine = tid < NV4;
+      if (wave * 64 < NV4) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        unsigned spins = 0;
+        for (;;) {
+          if (mine) v = ld16_agent(qt + w0);
+          const bool ok = !mine || ((v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag);
+          if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+          if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        if (mine) *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
+      }
+      lds_barrier();
+    };
+    attn_dec_body<DH, G, 16>(a, smem, bx, kvh, 0, hook);
+    return;
+  }
+  // ---- projection workgroups ----
+  const int d = p.d, K = a.H * DH;
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);             // [d]  RMSNorm(x) * ln1
+  bf16_t* xa = xs + d;                                      // [K]  attention output
+  float* red = reinterpret_cast<float*>(xa + K);
+  const int gwo = ((int)blockIdx.x - n_attn) * 8 + wave;
+  uint4 w[32];
+  // qkv rows [rq0, rq0 + 4): all 32 KB of this wave requested right behind x
+  const int rq0 = gwo * 4;
+  mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + (it * 64 + lane) * 8);
+  });
+  {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(xs + (it * 64 + lane) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = dot8(w[i * 8 + it], xv, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+      uint32_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (tag << 16) | f2bf(rbf(acc[i]));
+      st8_agent(p.qkv_tag + rq0, o[0], o[1]);
+      st8_agent(p.qkv_tag + rq0 + 2, o[2], o[3]);
+    }
+  }
+  // o rows [r0, r0 + 3): into the same registers while the attention runs
+  const int r0 = gwo * 3;
+  const bool active = r0 < d;
+  float res[3] = {0.f, 0.f, 0.f};
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int r = r0 + i < d ? r0 + i : d - 1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (c * 64 + lane) * 8);
+      res[i] = bf2f(p.x[r]);
+    }
+  }
+  // the attention output: one wave watches a 1 KB sample (192 workgroups asking for all 16 KB in a loop would load the fabric
+  // while the attention workgroups are inside their latency chain), then every wave takes its share
+  if (wave == 0) {
+    unsigned spins = 0;
+    for (;;) {
+      const uint4 v = ld16_agent(p.ao_tag + lane * 4);
+      const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (++spins > (1u << 19)) { if (lane == 0 && p.err) __hip_atomic_store(p.err, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  __syncthreads();
+  {
+    uint4 tq[2];
+    mc_fetch_issue<2>(p.ao_tag, wave * 512, lane, tq);
+    mc_fetch_finish<2>(p.ao_tag, wave * 512, lane, tag, xa, tq, p.err, 11u);
+  }
+  __syncthreads();
+  if (!active) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const uint4 xv = *reinterpret_cast<const uint4*>(xa + (c * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = dot8(w[i * 8 + c], xv, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (r0 + i >= d) continue;
+      float v = rbf(acc[i]);
+      v = rbf(v + res[i]);
+      p.x_out[r0 + i] = f2bf(v);
+    }
+  }
+}
+
+template <int DH, int G>
+bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const unsigned* step_epoch, unsigned* xflags) {
+  const int n_attn = (DH / 16) * a.Hkv, n_o = 256 - n_attn;
+  if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 3 || a.H * DH != 8 * 512 || p.d != 4096) return false;
+  a.o_sc1 = 0;
+  const char* xe = getenv("PCY_AO_XMIN");   // key split between the slice workgroups (see launch_attn_o_rw)
+  const int xmin = xe ? atoi(xe) : 768;
+  a.xflags = (xmin > 0 && a.scratch) ? xflags : nullptr;
+  a.xmin = xmin;
+  a.unit_map = 1;
+  const size_t stage_off = (attn_dec_smem_bytes(G, 16, DH, a.Tmax) + 15) & ~(size_t)15;
+  const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(p.d + a.H * DH) * 2 + 128;
+  const size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
+  static size_t configured = 0;
+  if (smem > 65536 && smem > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = smem;
+  }
+  hipLaunchKernelGGL((attn_block_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq), stage_off);
+  return true;
+}
+
 template <int DH, int G>
 void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
   // widest slice that still leaves >= ~1 workgroup per CU (PCY_DEC_DS overrides, for measurements)
@@ -772,6 +936,20 @@ bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs
     case 2: return launch_attn_o_rw<128, 2>(s, a, o, n_cu, epoch, flags, err, xflags);
     case 4: return launch_attn_o_rw<128, 4>(s, a, o, n_cu, epoch, flags, err, xflags);
     case 8: return launch_attn_o_rw<128, 8>(s, a, o, n_cu, epoch, flags, err, xflags);
+  }
+  return false;
+}
+
+// Decode attention block (see attn_block_kernel).  Returns false (nothing launched) when the shape is not covered: batch 1,
+// head_dim 128, H * dh = d = 4096, G in {1,2,4,8}, Nq = 4 rows per projection wave, 256 CUs.
+bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
+                           unsigned* xflags) {
+  if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256) return false;
+  switch (a.H / a.Hkv) {
+    case 1: return launch_attn_block<128, 1>(s, a, p, step_epoch, xflags);
+    case 2: return launch_attn_block<128, 2>(s, a, p, step_epoch, xflags);
+    case 4: return launch_attn_block<128, 4>(s, a, p, step_epoch, xflags);
+    case 8: return launch_attn_block<128, 8>(s, a, p, step_epoch, xflags);
   }
   return false;
 }

@@ -138,14 +138,20 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
   static_assert((G + 1) * (DH / 8) <= NT, "one rope item per thread");
   const bool roper = tid < (G + 1) * (DH / 8);
   const int rh = tid / (DH / 8), rch = tid % (DH / 8);
-  const bf16_t* rsrc = (rh < G) ? row + (kvh * G + rh) * DH : row + (a.H + kvh) * DH;
+  // (a.staged: the kv head's [G q heads][k][v] of the new token in LDS, filled by the inputs_ready hook)
+  const bf16_t* rsrc = a.staged ? a.staged + rh * DH : ((rh < G) ? row + (kvh * G + rh) * DH : row + (a.H + kvh) * DH);
   Rope8In rin;
   if (kPlainInputs && roper) rin = rope8_load<DH>(rsrc, cs, sn, rch * 8);
+  if (!kPlainInputs && roper) {   // the position's cos / sin rows now, q / k when the hook has delivered them
+    rin.c = *reinterpret_cast<const uint4*>(cs + rch * 8);
+    rin.s = *reinterpret_cast<const uint4*>(sn + rch * 8);
+  }
   const int sub = DS == 16 ? lane >> 5 : lane % LPR;
   const int grp = DS == 16 ? wave * 32 + (lane & 31) : wave * RPW + lane / LPR;
   constexpr int NGV = NWV * RPW;
   constexpr int UV = DS == 16 ? 4 : 8;
-  const bf16_t* vnew = row + (a.H + a.Hkv + kvh) * DH + c0 + sub * 8;
+  const bf16_t* vrow = a.staged ? a.staged + (G + 1) * DH : row + (a.H + a.Hkv + kvh) * DH;
+  const bf16_t* vnew = vrow + c0 + sub * 8;
   const bf16_t* vsl = vc + c0 + sub * 8;
   uint4 vpre[UV];
 #pragma unroll
@@ -191,7 +197,11 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     load_group(0);
     inputs_ready();
     // rope q (G heads) and the new key ONCE per block into LDS (bf16), then pick fragments from there
-    if (!kPlainInputs && roper) rin = rope8_load<DH>(rsrc, cs, sn, rch * 8);
+    if (!kPlainInputs && roper) {
+      const int e0 = rch * 8, p0 = e0 < DH / 2 ? e0 + DH / 2 : e0 - DH / 2;
+      rin.a = *reinterpret_cast<const uint4*>(rsrc + e0);
+      rin.b = *reinterpret_cast<const uint4*>(rsrc + p0);
+    }
     if (roper) {
       const int hh = rh, ch = rch;
       float tmp[8];
@@ -203,7 +213,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     }
     if (bx == 0 && tid >= NT - DH / 8) {  // ... and its V
       const int ch = tid - (NT - DH / 8);
-      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + ch * 8) = *reinterpret_cast<const uint4*>(row + (a.H + a.Hkv + kvh) * DH + ch * 8);
+      *reinterpret_cast<uint4*>(vc + (size_t)t * DH + ch * 8) = *reinterpret_cast<const uint4*>(vrow + ch * 8);
     }
     lds_barrier();
     // A operand: roped q of head `fr` (zero rows for fr >= G); new key in B-fragment layout
@@ -390,7 +400,8 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     for (int w = 1; w < NWV; ++w) s += red[w * G * DS + i];
     const int g = i / DS, c = i % DS;
     const size_t oi = (size_t)b * a.ldo + (kvh * G + g) * DH + c0 + c;
-    if (a.o_sc1) __hip_atomic_store(a.o + oi, f2bf(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.o_tag) __hip_atomic_store(a.o_tag + oi, (a.tag << 16) | f2bf(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (a.o_sc1) __hip_atomic_store(a.o + oi, f2bf(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else a.o[oi] = f2bf(s);
   }
 }

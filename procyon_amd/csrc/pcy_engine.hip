@@ -54,6 +54,7 @@ struct pcy_ctx {
   uint32_t* mc_tags = nullptr;
   const void* mc_tags_model = nullptr;
   size_t mc_tags_words = 0;
+  int mc_tags_mode = -1;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
   int smp_hist_rows = 0;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
@@ -129,8 +130,19 @@ bool mlp_chain_enabled() {
   const char* e = getenv("PCY_MLP_CHAIN");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0); }
+// PCY_ATTN_BLOCK=0 switches the qkv + attention + o launch of the batch-1 decode step off (default on; needs the two
+// switches above on): pcy_attn.hip, attn_block_kernel.  Read on every call, bit-identical either way.
+bool attn_block_enabled() {
+  const char* e = getenv("PCY_ATTN_BLOCK");
+  return !e || atoi(e) != 0;
+}
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0) | (attn_block_enabled() ? 16 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
+
+// tagged vectors of one layer: act [ffn], x after the MLP [d], qkv [(H + 2 Hkv) dh], attention output [H dh]
+size_t tag_words_per_layer(const pcy_llama_desc* m) {
+  return (size_t)m->ffn + m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
+}
 
 // device words of the in-launch hand-overs; must run outside stream capture
 int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
@@ -151,15 +163,16 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
   }
   // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
   // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
-  const size_t words = (size_t)m->n_layers * ((size_t)m->ffn + m->d);
-  if (c->mc_tags_model != m || c->mc_tags_words != words) {
+  // (a change of the launch mix as well: a slot the new mix reads may not have been rewritten for a while)
+  const size_t words = (size_t)m->n_layers * tag_words_per_layer(m);
+  if (c->mc_tags_model != m || c->mc_tags_words != words || c->mc_tags_mode != decode_mode()) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->mc_tags) hipFree(c->mc_tags);
     c->mc_tags = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
     HIP_TRY(hipMemset(c->mc_tags, 0, words * 4));
     HIP_TRY(hipMemset(c->ao_sync + 1, 0, 4));
-    c->mc_tags_model = m; c->mc_tags_words = words;
+    c->mc_tags_model = m; c->mc_tags_words = words; c->mc_tags_mode = decode_mode();
   }
   return 0;
 }
@@ -192,6 +205,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
                               try_mc ? c->ao_sync + 1 : nullptr);
   bool qkv_done = false;   // the previous layer's MLP chain launch has already produced this layer's qkv
+  bool try_blk = attn_block_enabled() && try_mc && try_ao;   // qkv + attention + o in one launch (then the chain stops after down)
+  const size_t tag_stride = tag_words_per_layer(m);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
   for (int l = 0; l < m->n_layers; ++l) {
@@ -205,8 +220,6 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       xn_ready = 0;
       g.x = xn; g.rms_w = nullptr;
     }
-    if (!qkv_done) pcy_launch_gemv(s, g);
-    qkv_done = false;
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k + l * layer_stride; t.vcache = (bf16_t*)kv->v + l * layer_stride;
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
@@ -218,25 +231,40 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
-    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
-                                       c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
-      pcy_launch_attn_decode(s, t);
-      pcy_launch_gemv(s, o);
+    uint32_t* tags = c->mc_tags ? c->mc_tags + (size_t)l * tag_stride : nullptr;
+    bool blk_done = false;
+    if (try_blk) {
+      PcyAttnBlockArgs bp{};
+      bp.x = x; bp.x_out = x; bp.ln1 = (const bf16_t*)L.ln1; bp.wqkv = (const bf16_t*)L.wqkv; bp.wo = (const bf16_t*)L.wo;
+      bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast;
+      bp.qkv_tag = tags + F + d; bp.ao_tag = bp.qkv_tag + qkvw;
+      bp.epoch = c->ao_sync + 1; bp.err = c->xwg_err;
+      blk_done = pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS);
+      if (!blk_done) try_blk = false;   // geometry not covered: the same for every layer
     }
+    if (!blk_done) {
+      if (!qkv_done) pcy_launch_gemv(s, g);
+      if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
+                                         c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
+        pcy_launch_attn_decode(s, t);
+        pcy_launch_gemv(s, o);
+      }
+    }
+    qkv_done = false;
     if (try_mc) {   // gate/up + down + the next layer's qkv in one launch
       PcyMlpChainArgs mc{};
       mc.x = x; mc.x_out = x; mc.ln2 = (const bf16_t*)L.ln2; mc.wgu = (const bf16_t*)L.wgu; mc.wdown = (const bf16_t*)L.wdown;
-      if (l + 1 < m->n_layers) {
+      if (l + 1 < m->n_layers && !try_blk) {
         mc.ln_next = (const bf16_t*)m->layers[l + 1].ln1; mc.wqkv_next = (const bf16_t*)m->layers[l + 1].wqkv; mc.qkv_next = qkv; mc.Nq = qkvw;
       }
       mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast;
-      mc.act_tag = c->mc_tags + (size_t)l * (F + d); mc.x_tag = mc.act_tag + F;
+      mc.act_tag = tags; mc.x_tag = tags + F;
       mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
       if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
         if (!g_mc_trace) { hipMalloc(&g_mc_trace, 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 128 * 256 * 16 * 8); }
         mc.trace = g_mc_trace + (size_t)l * 256 * 16;
       }
-      if (pcy_launch_mlp_chain(s, mc, c->n_cu)) { qkv_done = l + 1 < m->n_layers; continue; }
+      if (pcy_launch_mlp_chain(s, mc, c->n_cu)) { qkv_done = mc.wqkv_next != nullptr; continue; }
     }
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;

@@ -15,6 +15,7 @@
 //     bias+GELU), see pcy_common.h.
 #include <stdlib.h>
 #include "pcy_internal.h"
+#include "pcy_handover.h"
 
 namespace {
 
@@ -762,81 +763,6 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
 // points); the RMSNorm statistic is summed in the order of the stand-alone launch (`vthr` threads, block_sum_rt): bit-identical.
 constexpr int MC_NT = 512, MC_WV = 8, MC_UNB_D = 7;
 
-__device__ __forceinline__ void st8_agent(void* p, uint32_t lo, uint32_t hi) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// This wave's share of a tagged vector -> LDS as plain bf16: words [w0 + (j*64 + lane)*4, +4), j < NV.  `pre` holds loads issued
-// earlier by mc_fetch_issue (checked first); asks again until every tag matches.
-template <int NV>
-__device__ __forceinline__ void mc_fetch_issue(const uint32_t* src, int w0, int lane, uint4 (&pre)[NV]) {
-#pragma unroll
-  for (int j = 0; j < NV; ++j) pre[j] = ld16_agent(src + w0 + (j * 64 + lane) * 4);
-}
-template <int NV>
-__device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int lane, uint32_t tag, bf16_t* dst, uint4 (&pre)[NV], unsigned* err,
-                                                unsigned code) {
-  unsigned spins = 0;
-  for (;;) {
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-      ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
-    if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-    if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    __builtin_amdgcn_s_sleep(16);
-    mc_fetch_issue<NV>(src, w0, lane, pre);
-  }
-#pragma unroll
-  for (int j = 0; j < NV; ++j)
-    *reinterpret_cast<uint2*>(dst + w0 + (j * 64 + lane) * 4) =
-        make_uint2((pre[j].x & 0xffffu) | (pre[j].y << 16), (pre[j].z & 0xffffu) | (pre[j].w << 16));
-}
-
-// xs[0..K) = bf16( RMSNorm(x) * w ) with the statistic summed like gemv_stream_kernel launched with `vthr` threads.  x: global
-// (written before this launch) or LDS.  K <= 8 * MC_NT.  All threads; ends with a barrier.
-template <typename AfterLoads>
-__device__ __forceinline__ void mc_rms_stage(const bf16_t* x, const bf16_t* __restrict__ w, int K, int vthr, float eps, int cast,
-                                             bf16_t* xs, float* red, AfterLoads after_loads) {
-  const int tid = threadIdx.x;
-  auto ldx = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const uint4*>(x + k); };
-  // vector loads return in order: x (a few KiB, the head of the dependent chain) is requested BEFORE any weight batch
-  uint4 xr[4], xv = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = (tid + i * vthr) * 8;
-    xr[i] = (tid < vthr && k < K) ? ldx(k) : make_uint4(0, 0, 0, 0);
-  }
-  const int ks = tid * 8;
-  if (ks < K) { xv = ldx(ks); g = *reinterpret_cast<const uint4*>(w + ks); }
-  after_loads();
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = (tid + i * vthr) * 8;
-    if (tid < vthr && k < K) {
-      const uint32_t w4[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
-    }
-  }
-  ss = block_sum_rt(ss, red, vthr >> 6);
-  const float rs = rsqrtf(ss / (float)K + eps);
-  if (ks < K) {
-    const uint32_t xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {g.x, g.y, g.z, g.w};
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float x0 = lo_bf(xin[j]) * rs, x1 = hi_bf(xin[j]) * rs;
-      if (cast == 0) { x0 = rbf(x0); x1 = rbf(x1); }
-      o[j] = pack_bf(lo_bf(gin[j]) * x0, hi_bf(gin[j]) * x1);
-    }
-    *reinterpret_cast<uint4*>(xs + ks) = make_uint4(o[0], o[1], o[2], o[3]);
-  }
-  __syncthreads();
-}
-
 // One wave streams its units (RW weight rows each, row i of unit u at W + row_off(u, i)) against xs, UNB k-iterations of 512
 // elements per batch, two batches in flight (wa / wb).  primed: the first two batches of (u0, it 0) are already in wa / wb.
 // before_batch(it0) runs ahead of the arithmetic of every batch (the down stage waits there for the second half of its input).
@@ -1028,6 +954,14 @@ __global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, 
 
 }  // namespace
 
+// threads of the stand-alone RMS-fused launch (launch_nb / pick_grid) for N output rows: the order of its statistic
+int pcy_gemv_rms_threads(int N) {
+  const int R = ((N + 3) / 4 < GEMV_MAX_WAVES) ? 2 : 4;
+  int blocks, wpb;
+  pick_grid((N + R - 1) / R, blocks, wpb);
+  return wpb * 64;
+}
+
 bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
   // 256 workgroups, one per CU, must all be resident (every hand-over needs every workgroup's rows).  Geometry: one down unit
   // (two rows) per wave, act halves of whole k-batches, a wave's share of a tagged vector in 4 (act) / 2 (x) loads per lane.
@@ -1036,12 +970,7 @@ bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
   const size_t smem = (size_t)(2 * a.d + a.F) * 2 + 128;
   if (smem > 64 * 1024) return false;
   if (a.wqkv_next && a.Nq <= 0) return false;
-  auto vthr_of = [](int N) {   // threads of the stand-alone RMS-fused launch (launch_nb / pick_grid): the order of its statistic
-    const int R = ((N + 3) / 4 < GEMV_MAX_WAVES) ? 2 : 4;
-    int blocks, wpb;
-    pick_grid((N + R - 1) / R, blocks, wpb);
-    return wpb * 64;
-  };
+  auto vthr_of = [](int N) { return pcy_gemv_rms_threads(N); };
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, vthr_of(a.F), a.wqkv_next ? vthr_of(a.Nq) : 64);
   return true;
 }

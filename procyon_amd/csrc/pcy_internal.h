@@ -119,6 +119,9 @@ struct PcyDecAttnArgs {
   // `scratch` ([B*H*(Tmax+1)] fp32) carries the exchanged scores
   unsigned* xflags; unsigned xepoch; int xmin; unsigned* xerr;
   int unit_map;                   // fused launch: 1 = kv head in the low digits of the workgroup index (slices of a head share an XCD)
+  // attention block launch only (device-side fields, zero otherwise): the new token's roped-to-be q heads / k / v of this kv head
+  // staged in LDS as [G + 2][dh] (nullptr: read from `qkv`); `o` stored as {tag : bf16} words into o_tag instead
+  const bf16_t* staged; uint32_t* o_tag; uint32_t tag;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;
@@ -126,6 +129,27 @@ struct PcyGemvArgs;
 // nothing launched.  epoch: device word that differs between consecutive calls on the same `flags` (max_flags words).
 bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
                        unsigned* flags, int max_flags, unsigned* err, unsigned* xflags = nullptr);
+
+// Batch-1 decode, the attention half of a layer in ONE launch (pcy_attn.hip, attn_block_kernel):
+//   qkv = RMSNorm(x) * ln1 . Wqkv^T ;  attention over the cache (+ append) ;  x_out = x + attn . Wo^T
+// Workgroups [0, n_attn) run the decode attention body (cache rows requested at once, the new token's q/k/v taken from the
+// tagged qkv vector when it arrives); the others project qkv (all their rows in registers from the first cycle), pull their Wo
+// rows while the attention runs and finish with the o projection.  Bit-identical to qkv GEMV + fused attention/o launch.
+struct PcyAttnBlockArgs {
+  const bf16_t* x; bf16_t* x_out;           // residual stream [d] (may alias)
+  const bf16_t* ln1; const bf16_t* wqkv;    // [d], [Nq, d]
+  const bf16_t* wo;                         // [d, H*dh]
+  int d, Nq; float rms_eps; int rms_cast;
+  uint32_t* qkv_tag; uint32_t* ao_tag;      // [Nq], [H*dh] tagged hand-over vectors, private to THIS layer's launch
+  const unsigned* epoch;                    // tag counter (see pcy_handover.h)
+  unsigned* err;
+};
+// false = geometry not covered (nothing launched).  xflags / step_epoch: key-split exchange of the attention workgroups
+// (as pcy_launch_attn_o).
+bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
+                           unsigned* xflags);
+// threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
+int pcy_gemv_rms_threads(int N);
 
 // pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
 size_t pcy_pool_ws_bytes(int nprot, int d);
