@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 5
+#define PCY_ABI_VERSION 6
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -57,6 +57,12 @@ int pcy_gemm(pcy_ctx*, const void* A, int lda, const void* W, const void* bias, 
 /* y[B,N] = epi(x[B,K] . W[N,K]^T); rms_w != NULL fuses RMSNorm(x)*rms_w in front (rms_cast 0: >=4.32, 1: 4.31) */
 int pcy_gemv(pcy_ctx*, const void* W, const void* x, int ldx, const void* bias, const void* resid, void* y, int ldy,
              const void* rms_w, float rms_eps, int rms_cast, int N, int K, int B, int epi);
+/* One token through a Llama MLP, in place: x[d] += (silu(g) * u) . Wdown^T with [g; u] = (RMSNorm(x) * ln2) . Wgu^T
+   (transformers LlamaDecoderLayer.forward: post_attention_layernorm -> LlamaMLP -> residual, as run per generated token by
+   model_unified.py:883-915).  wgu: [2*ffn, d] in the 16-row gate/up interleave of pcy_gemv(EPI_SWIGLU); wdown: [d, ffn].
+   Llama-3-8B geometry runs as ONE launch (the decode step's MLP chain kernel), anything else as the two pcy_gemv launches;
+   same bits either way. */
+int pcy_decode_mlp(pcy_ctx*, void* x, const void* ln2, const void* wgu, const void* wdown, int d, int ffn, float rms_eps, int rms_cast);
 int pcy_rmsnorm(pcy_ctx*, const void* x, const void* w, void* y, int rows, int d, float eps, int cast);
 int pcy_layernorm(pcy_ctx*, const void* x, const void* w, const void* b, void* y, int rows, int d, float eps);
 /* out[r] = soft_map[r] >= 0 ? soft[soft_map[r]] : table[ids[r]]   (model_unified.py:1146-1167) */

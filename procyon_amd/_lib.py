@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
-ABI_VERSION = 5
+ABI_VERSION = 6
 # pcy_debug_dispatch_count kinds
 DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8 = range(6)
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "pcy_timer_stop": (ci, [vp, C.POINTER(C.c_float)]),
     "pcy_gemm": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_gemv": (ci, [vp, vp, vp, ci, vp, vp, vp, ci, vp, C.c_float, ci, ci, ci, ci, ci]),
+    "pcy_decode_mlp": (ci, [vp, vp, vp, vp, vp, ci, ci, C.c_float, ci]),
     "pcy_rmsnorm": (ci, [vp, vp, vp, vp, ci, ci, C.c_float, ci]),
     "pcy_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, C.c_float]),
     "pcy_embed_splice": (ci, [vp, vp, vp, vp, vp, vp, ci, ci]),

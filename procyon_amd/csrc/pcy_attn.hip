@@ -704,10 +704,13 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 // gemv_stream_kernel (qkv: RMSNorm statistic summed with the stand-alone launch's `vthr` threads) and of attn_o_kernel.
 template <int DH, int G>
 __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, int n_attn, const unsigned* step_epoch,
-                                                         int vthr_qkv, size_t stage_off) {
+                                                         int vthr_qkv, size_t stage_off, int wo_delay) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
+  unsigned long long* tr = p.trace ? p.trace + (size_t)blockIdx.x * 16 : nullptr;
+#define AB_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
+  AB_T(0)
   if ((int)blockIdx.x < n_attn) {
     constexpr int slices = DH / 16;
     const int unit = blockIdx.x;
@@ -737,8 +740,10 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
         if (mine) *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
       }
       lds_barrier();
+      if (tr && tid == 0) tr[1] = wall_clock64();
     };
     attn_dec_body<DH, G, 16>(a, smem, bx, kvh, 0, hook);
+    AB_T(2)
     return;
   }
   // ---- projection workgroups ----
@@ -774,7 +779,13 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
       st8_agent(p.qkv_tag + rq0 + 2, o[2], o[3]);
     }
   }
-  // o rows [r0, r0 + 3): into the same registers while the attention runs
+  AB_T(1)
+  // o rows [r0, r0 + 3): into the same registers while the attention runs -- a little later, so that the attention workgroups'
+  // requests for the fresh q / k / v do not queue behind 33 MB of weight reads (the rows are needed ~12 us from now)
+  if (wo_delay > 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)wo_delay) __builtin_amdgcn_s_sleep(8);
+  }
   const int r0 = gwo * 3;
   const bool active = r0 < d;
   float res[3] = {0.f, 0.f, 0.f};
@@ -796,16 +807,18 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       if (++spins > (1u << 19)) { if (lane == 0 && p.err) __hip_atomic_store(p.err, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      __builtin_amdgcn_s_sleep(32);
+      __builtin_amdgcn_s_sleep(4);
     }
   }
   __syncthreads();
+  AB_T(2)
   {
     uint4 tq[2];
     mc_fetch_issue<2>(p.ao_tag, wave * 512, lane, tq);
     mc_fetch_finish<2>(p.ao_tag, wave * 512, lane, tag, xa, tq, p.err, 11u);
   }
   __syncthreads();
+  AB_T(3)
   if (!active) return;
   float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -825,6 +838,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
       p.x_out[r0 + i] = f2bf(v);
     }
   }
+  AB_T(4)
+#undef AB_T
 }
 
 template <int DH, int G>
@@ -845,7 +860,11 @@ bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
-  hipLaunchKernelGGL((attn_block_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq), stage_off);
+  // Wo prefetch 2 us behind the qkv stores: decode step 2.91 (no delay) -> 2.83 (2 us) -> 2.83 (4 us) -> 2.85 ms (6 us) at t = 520..780;
+  // PCY_AB_DELAY overrides, in 10 ns ticks
+  static const int wo_delay = [] { const char* e = getenv("PCY_AB_DELAY"); return e ? atoi(e) : 200; }();   // 10 ns ticks
+  hipLaunchKernelGGL((attn_block_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq), stage_off,
+                     wo_delay);
   return true;
 }
 

@@ -1084,6 +1084,9 @@ void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* 
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
   if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr, (unsigned*)nullptr);
 }
+__global__ void bump_word_kernel(unsigned* w) { *w += 1; }
+void pcy_launch_bump(hipStream_t s, unsigned* word) { hipLaunchKernelGGL(bump_word_kernel, dim3(1), dim3(1), 0, s, word); }
+
 void pcy_launch_embed_tokens_dev(hipStream_t s, const bf16_t* table, const int32_t* ids, bf16_t* out, int rows, int d, unsigned* epoch,
                                  unsigned* epoch2) {
   if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, nullptr, nullptr, out, d, epoch, epoch2);

@@ -55,6 +55,8 @@ struct pcy_ctx {
   const void* mc_tags_model = nullptr;
   size_t mc_tags_words = 0;
   int mc_tags_mode = -1;
+  uint32_t* op_tags = nullptr;        // tagged vectors of pcy_decode_mlp ([ffn + d] words, its own counter)
+  size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
   int smp_hist_rows = 0;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
@@ -145,7 +147,7 @@ size_t tag_words_per_layer(const pcy_llama_desc* m) {
 }
 
 // device words of the in-launch hand-overs; must run outside stream capture
-int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
+int ensure_sync_words(pcy_ctx* c) {
   if (!c->n_cu) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -156,18 +158,23 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
     HIP_TRY(hipMemset(c->xwg_err, 0, 64));
   }
   if (!c->ao_sync) {
-    // [0] step epoch, [1] epoch of the MLP chain launches, attention->o flags, score-exchange flags
+    // [0] step epoch, [1] tag counter of the decode step's fused launches, [2] tag counter of pcy_decode_mlp, attention->o flags,
+    // score-exchange flags
     const size_t bytes = (size_t)(64 + 2 * AO_MAX_LAYERS * AO_FLAGS) * sizeof(unsigned);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ao_sync), bytes));
     HIP_TRY(hipMemset(c->ao_sync, 0, bytes));
   }
+  return 0;
+}
+int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
+  if (int r = ensure_sync_words(c)) return r;
   // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
   // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
   // (a change of the launch mix as well: a slot the new mix reads may not have been rewritten for a while)
   const size_t words = (size_t)m->n_layers * tag_words_per_layer(m);
   if (c->mc_tags_model != m || c->mc_tags_words != words || c->mc_tags_mode != decode_mode()) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->mc_tags) hipFree(c->mc_tags);
+    if (c->mc_tags) HIP_TRY(hipFree(c->mc_tags));
     c->mc_tags = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
     HIP_TRY(hipMemset(c->mc_tags, 0, words * 4));
@@ -239,6 +246,10 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast;
       bp.qkv_tag = tags + F + d; bp.ao_tag = bp.qkv_tag + qkvw;
       bp.epoch = c->ao_sync + 1; bp.err = c->xwg_err;
+      if (getenv("PCY_MC_TRACE")) {   // measurement aid: stamps of this launch behind those of the chain launches
+        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
+        bp.trace = g_mc_trace + (size_t)(128 + l) * 256 * 16;
+      }
       blk_done = pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS);
       if (!blk_done) try_blk = false;   // geometry not covered: the same for every layer
     }
@@ -261,7 +272,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       mc.act_tag = tags; mc.x_tag = tags + F;
       mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
       if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
-        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 128 * 256 * 16 * 8); }
+        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
         mc.trace = g_mc_trace + (size_t)l * 256 * 16;
       }
       if (pcy_launch_mlp_chain(s, mc, c->n_cu)) { qkv_done = mc.wqkv_next != nullptr; continue; }
@@ -411,6 +422,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->mc_tags) hipFree(c->mc_tags);
+  if (c->op_tags) hipFree(c->op_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -460,6 +472,39 @@ int pcy_gemv(pcy_ctx* c, const void* W, const void* x, int ldx, const void* bias
   g.rms_w = (const bf16_t*)rms_w; g.rms_eps = rms_eps; g.rms_cast = rms_cast; g.N = N; g.K = K; g.B = B; g.ldx = ldx; g.ldy = ldy; g.epi = epi;
   pcy_launch_gemv(c->stream, g);
   return check_launch("pcy_gemv");
+}
+
+int pcy_decode_mlp(pcy_ctx* c, void* x, const void* ln2, const void* wgu, const void* wdown, int d, int ffn, float rms_eps, int rms_cast) {
+  if (d % 8 || ffn % 8 || (size_t)d * 2 > 65536) return fail(1, "pcy_decode_mlp: d=%d ffn=%d not covered", d, ffn);
+  if (int r = ensure_sync_words(c)) return r;
+  const size_t words = (size_t)ffn + d;
+  if (c->op_tags_words != words) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->op_tags) HIP_TRY(hipFree(c->op_tags));
+    c->op_tags = nullptr; c->op_tags_words = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->op_tags), words * 4));
+    HIP_TRY(hipMemset(c->op_tags, 0, words * 4));
+    HIP_TRY(hipMemset(c->ao_sync + 2, 0, 4));
+    c->op_tags_words = words;
+  }
+  if (mlp_chain_enabled()) {
+    PcyMlpChainArgs mc{};
+    mc.x = (const bf16_t*)x; mc.x_out = (bf16_t*)x; mc.ln2 = (const bf16_t*)ln2; mc.wgu = (const bf16_t*)wgu; mc.wdown = (const bf16_t*)wdown;
+    mc.d = d; mc.F = ffn; mc.rms_eps = rms_eps; mc.rms_cast = rms_cast;
+    mc.act_tag = c->op_tags; mc.x_tag = c->op_tags + ffn; mc.epoch = c->ao_sync + 2; mc.err = c->xwg_err;
+    pcy_launch_bump(c->stream, c->ao_sync + 2);   // a fresh tag for every use of the slot
+    if (pcy_launch_mlp_chain(c->stream, mc, c->n_cu)) return check_launch("pcy_decode_mlp");
+  }
+  if (int r = c->reserve((size_t)ffn * 2 + 256)) return r;
+  PcyGemvArgs u{};
+  u.W = (const bf16_t*)wgu; u.x = (const bf16_t*)x; u.y = (bf16_t*)c->ws; u.rms_w = (const bf16_t*)ln2; u.rms_eps = rms_eps; u.rms_cast = rms_cast;
+  u.N = ffn; u.K = d; u.B = 1; u.ldx = d; u.ldy = ffn; u.epi = EPI_SWIGLU;
+  pcy_launch_gemv(c->stream, u);
+  PcyGemvArgs w{};
+  w.W = (const bf16_t*)wdown; w.x = (const bf16_t*)c->ws; w.y = (bf16_t*)x; w.resid = (const bf16_t*)x; w.N = d; w.K = ffn; w.B = 1; w.ldx = ffn; w.ldy = d;
+  w.epi = EPI_RESID;
+  pcy_launch_gemv(c->stream, w);
+  return check_launch("pcy_decode_mlp");
 }
 
 int pcy_rmsnorm(pcy_ctx* c, const void* x, const void* w, void* y, int rows, int d, float eps, int cast) {

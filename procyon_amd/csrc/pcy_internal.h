@@ -37,6 +37,7 @@ struct PcyMlpChainArgs {
   unsigned* err;                           // watchdog word
   unsigned long long* trace;               // measurement aid: [grid][16] time stamps (nullptr: none)
 };
+void pcy_launch_bump(hipStream_t s, unsigned* word);   // *word += 1 (tag counters, pcy_handover.h)
 // false = geometry not covered (nothing launched)
 bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu);
 
@@ -143,6 +144,7 @@ struct PcyAttnBlockArgs {
   uint32_t* qkv_tag; uint32_t* ao_tag;      // [Nq], [H*dh] tagged hand-over vectors, private to THIS layer's launch
   const unsigned* epoch;                    // tag counter (see pcy_handover.h)
   unsigned* err;
+  unsigned long long* trace;                // measurement aid: [grid][16] time stamps (nullptr: none)
 };
 // false = geometry not covered (nothing launched).  xflags / step_epoch: key-split exchange of the attention workgroups
 // (as pcy_launch_attn_o).

@@ -84,6 +84,13 @@ class Context:
                                   N, K, B, epi), "pcy_gemv")
         return out
 
+    def decode_mlp(self, x, ln2, wgu, wdown, rms_eps=1e-5, rms_cast=0):
+        """One token through a Llama MLP, in place: x[1, d] += down(SwiGLU(gate/up(RMSNorm(x) * ln2))); wgu packed like gemv(EPI_SWIGLU)."""
+        _chk_bf16(x, ln2, wgu, wdown)
+        d, ffn = x.shape[-1], wdown.shape[1]
+        L.check(self.lib.pcy_decode_mlp(self.h, _p(x), _p(ln2), _p(wgu), _p(wdown), d, ffn, rms_eps, rms_cast), "pcy_decode_mlp")
+        return x
+
     def quant_rows_fp8(self, x):
         """Per-row symmetric OCP e4m3 quantisation of a bf16 matrix [rows,K] -> (q uint8 [rows,K], scale fp32 [rows])."""
         _chk_bf16(x)

@@ -102,6 +102,31 @@ def test_gemv_fused_rms_and_swiglu(ctx, B, cast):
     assert_bf16_close(out, F.linear(xn, Wq), "gemv rms+store")
 
 
+@pytest.mark.parametrize("d,ffn", [(4096, 14336), (2048, 4096)])
+def test_decode_mlp_one_launch_vs_oracle(ctx, monkeypatch, d, ffn):
+    """pcy_decode_mlp: one token through post_attention_layernorm -> LlamaMLP -> residual.  At the Llama-3-8B geometry this is
+    the decode step's MLP chain kernel (gate/up + SwiGLU and down + residual in ONE launch, `act` handed between the stages as
+    tagged words); other shapes run the two GEMV launches.  Checked against the oracle's arithmetic, and the one-launch path
+    bit-for-bit against the two launches, over repeated calls on one slot (a stale tag would show)."""
+    from oracle.llama_ref import rms_norm
+    from procyon_amd.engine import interleave_gate_up
+    w = (1 + 0.02 * torch.randn(d)).to(BF)
+    g, u, dn = rnd(ffn, d, seed=2, std=0.03), rnd(ffn, d, seed=3, std=0.03), rnd(d, ffn, seed=4, std=0.02)
+    wgu, wd, wc = interleave_gate_up(g, u).cuda(), dn.cuda(), w.cuda()
+    for i in range(6):
+        x = rnd(1, d, seed=10 + i)
+        xn = rms_norm(x, w, 1e-5, "hf5")
+        act = F.silu(F.linear(xn, g)) * F.linear(xn, u)
+        ref = x + F.linear(act, dn)
+        monkeypatch.setenv("PCY_MLP_CHAIN", "1")
+        out = ctx.decode_mlp(x.cuda(), wc, wgu, wd).cpu()
+        monkeypatch.setenv("PCY_MLP_CHAIN", "0")
+        two = ctx.decode_mlp(x.cuda(), wc, wgu, wd).cpu()
+        ctx.sync()
+        assert torch.equal(out, two), i
+        assert_bf16_close(out, ref, f"decode mlp d{d} ffn{ffn}", ulps=2, inter=x.float().abs() + F.linear(act, dn).float().abs())
+
+
 @pytest.mark.parametrize("d", [4096, 1280, 136])
 def test_norms(ctx, d):
     from oracle.llama_ref import rms_norm

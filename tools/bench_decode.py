@@ -27,32 +27,22 @@ ctx.sync()
 if os.environ.get("PCY_MC_TRACE"):
     import ctypes, numpy as np
     from procyon_amd import _lib
-    L = _lib.lib() if hasattr(_lib, "lib") else None
     lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.__file__), "libpcy.so"))
-    n = 32 * 256 * 16
+    n = 2 * 128 * 256 * 16
     buf = np.zeros(n, dtype=np.uint64)
     lib.pcy_debug_mc_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.pcy_debug_mc_trace(buf.ctypes.data, n)
-    t = buf.reshape(32, 256, 16)[:, :, :8].astype(np.int64)
-    for l in (1, 10, 20, 31):
-        tl = t[l]
+    t = buf.reshape(2, 128, 256, 16).astype(np.int64)
+    def show(tl, names, title):
         t0 = tl[:, 0].min()
         r = (tl - t0) / 100.0   # us (100 MHz)
-        names = ["start", "s1 done(w0)", "act A in LDS", "act B in LDS", "s2 done", "x in LDS", "rms done", "end"]
-        print(f"layer {l}: (us since first WG start)  min / median / max over 256 WGs")
+        print(title, "(us since first WG start)  min / median / max")
         for i, nm in enumerate(names):
             if tl[:, i].max() == 0: continue
-            print(f"  {nm:14s} {r[:, i].min():7.2f} {np.median(r[:, i]):7.2f} {r[:, i].max():7.2f}")
-    s1 = (t[1:32, :, 1] - t[1:32, :, 0].min(axis=1, keepdims=True)) / 100.0   # [layers, WG] stage-1 finishing time of wave 0
-    dev = s1 - np.median(s1, axis=1, keepdims=True)
-    print("stage-1 finishing time minus the layer median, mean over layers, per XCD (workgroup % 8):", np.round([dev[:, x::8].mean() for x in range(8)], 2))
-    m = dev.mean(axis=0)
-    print("per-workgroup mean deviation: min %.2f max %.2f std %.2f ; std of the residual (per layer noise) %.2f" % (m.min(), m.max(), m.std(), (dev - m).std()))
-    order = np.argsort(m)
-    print("slowest workgroups:", order[-16:], np.round(m[order[-16:]], 1))
-    print("fastest workgroups:", order[:16], np.round(m[order[:16]], 1))
-    s2 = (t[1:31, :, 4] - t[1:31, :, 0].min(axis=1, keepdims=True)) / 100.0
-    dev2 = s2 - np.median(s2, axis=1, keepdims=True)
-    m2 = dev2.mean(axis=0)
-    print("stage-2: per-workgroup mean deviation: min %.2f max %.2f std %.2f ; residual std %.2f ; corr with stage 1 %.2f" % (m2.min(), m2.max(), m2.std(), (dev2 - m2).std(), np.corrcoef(m, m2)[0, 1]))
-    print("per XCD stage 2:", np.round([dev2[:, x::8].mean() for x in range(8)], 2))
+            print(f"  {nm:22s} {r[:, i].min():7.2f} {np.median(r[:, i]):7.2f} {r[:, i].max():7.2f}")
+    for l in (1, 16, 30):
+        show(t[1, l, :64], ["start", "q/k/v staged", "attention done"], f"layer {l} attention block, 64 attention WGs")
+        show(t[1, l, 64:], ["start", "qkv rows stored", "ao sample seen", "ao in LDS", "end"], f"layer {l} attention block, 192 projection WGs")
+        show(t[0, l], ["start", "s1 done(w0)", "act A in LDS", "act B in LDS", "s2 done"], f"layer {l} MLP chain")
+        print("  gap attention block end -> chain start: %.2f us ; chain end -> next block start: %.2f us" % (
+            (t[0, l, :, 0].min() - t[1, l, :, :5].max()) / 100.0, (t[1, l + 1, :, 0].min() - t[0, l, :, :5].max()) / 100.0))
