@@ -566,6 +566,59 @@ __global__ __launch_bounds__(256) void gemv_splitk_finish_norm_kernel(PcyGemvArg
   }
 }
 
+// Epilogue of the batched MFMA GEMVs: lane holds D[n = fq*4 + r][b = fr] of every (row tile, batch tile)
+template <int EPI, int RT, int BT>
+__device__ __forceinline__ void mfma_gemv_epilogue(const PcyGemvArgs& a, f32x4 (&acc)[RT][BT], int r0, int nrows, int ksplit, int fr, int fq) {
+  if (r0 >= nrows) return;
+  if (ksplit > 1) {
+    float* ws = a.splitk_ws + (size_t)blockIdx.y * a.B * a.N;
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+      const int b = bt * 16 + fr;
+      if (b >= a.B) continue;
+      const int n = r0 + fq * 4;
+      if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)b * a.N + n) = acc[0][bt];
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) ws[(size_t)b * a.N + n + r] = acc[0][bt][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int bt = 0; bt < BT; ++bt) {
+    const int b = bt * 16 + fr;
+    if (b >= a.B) continue;
+    if (EPI == EPI_SWIGLU) {
+      const int f = (r0 >> 5) * 16 + fq * 4;
+      if (f >= a.N) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = rbf(silu_f(rbf(acc[0][bt][r]))) * rbf(acc[RT - 1][bt][r]);
+      *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+    } else {
+      const int n = r0 + fq * 4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = (n + r) < a.N ? n + r : a.N - 1;
+        v[r] = rbf(acc[0][bt][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
+        if (EPI == EPI_RESID) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)b * a.ldy + nn]));
+        if (EPI == EPI_GELU_ERF) v[r] = rbf(gelu_erf_f(v[r]));
+        if (EPI == EPI_GELU_ESM) v[r] = gelu_esm_chain(v[r]);
+      }
+      if (n + 3 < a.N && (a.ldy & 3) == 0) {
+        *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) a.y[(size_t)b * a.ldy + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
 template <int EPI, int BT>
 __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -655,55 +708,124 @@ __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int kspl
       __builtin_amdgcn_s_barrier();
     }
   }
-  // D[n = fq*4 + r][b = fr]
-  if (r0 >= nrows) return;
-  if (ksplit > 1) {
-    float* ws = a.splitk_ws + (size_t)blockIdx.y * a.B * a.N;
+  mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
+}
+
+// The same GEMV with the weights through LDS-DMA instead of registers.  A register load of an MFMA A fragment asks for 64
+// contiguous bytes per weight row (16 rows per instruction); measured with the arithmetic in place, 256 contiguous bytes per
+// row (4 rows per instruction) stream 25 % faster (gate/up at batch 32: 54.3 -> 43.3 us).  The DMA can have that shape: each
+// wave copies ITS 16 (32) rows of a 128-k super-step as 4 (8) instructions of 4 rows x 256 B into a private LDS tile
+// [16 rows][256 B] -- the 16-byte pieces of a row XOR-swizzled by the row index on the source side, so the fragment reads
+// (16 rows x one piece) touch every bank once -- S super-steps ahead, and nobody else reads the tile: a counted vmcnt orders
+// the wave's own copy and read, no barrier.  x travels as before (shared, 256-k chunks).  Same MFMA order: same bits.
+template <int EPI, int BT, int S>
+__global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int KC = 256;                      // k per x chunk = two super-steps
+  constexpr int XROW = KC * 2 + 16;
+  constexpr int XBUF = BT * 16 * XROW;
+  constexpr int WT = 16 * 256;                 // one row tile of one super-step
+  extern __shared__ __attribute__((aligned(1024))) char smem3[];
+  char* xs = smem3 + 4 * S * RT * WT;          // [2][XBUF] behind the four waves' weight rings
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* wring = smem3 + wave * S * RT * WT;    // [S][RT][16 rows][256 B]
+  const int fr = lane & 15, fq = lane >> 4;
+  const int K = a.K;
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  const int r0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  const int ks = K / ksplit;                   // multiple of KC
+  const int kbeg = blockIdx.y * ks;
+  const int nss = ks / 128, nchunk = ks / KC;
+  // DMA source of this lane: row (lane >> 4) of each group of four rows, piece (lane & 15) ^ row of the 256-byte segment
+  const bf16_t* wsrc[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 4 + (lane >> 4);
+      int r = r0 + rt * 16 + row;
+      r = r < nrows ? r : nrows - 1;
+      wsrc[rt][q] = a.W + (size_t)r * K + kbeg + ((lane & 15) ^ row) * 8;
+    }
+  auto issue_w = [&](int ss) __attribute__((always_inline)) {   // (past the end: the last super-step again, so that the counts below stay uniform)
+    const int k = (ss < nss ? ss : nss - 1) * 128;
+    char* dst = wring + (ss % S) * RT * WT;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_global_load_lds((gv_gptr_t)(wsrc[rt][q] + k), (gv_lds_ptr_t)(dst + rt * WT + q * 1024), 16, 0, 0);
+  };
+  auto stage_x = [&](int c) __attribute__((always_inline)) {
+    const int cc = c < nchunk ? c : nchunk - 1;
+    char* buf = xs + (c & 1) * XBUF;
+#pragma unroll
+    for (int i = 0; i < BT * 4; ++i) {
+      const int row = wave * BT * 4 + i;
+      const int b = row < a.B ? row : a.B - 1;
+      const bf16_t* src = a.x + (size_t)b * a.ldx + kbeg + cc * KC + (lane & 31) * 8;   // 512 B per row: lanes 32-63 repeat (land in the padding-free tail, unused)
+      if (lane < 32) __builtin_amdgcn_global_load_lds((gv_gptr_t)src, (gv_lds_ptr_t)(buf + row * XROW), 16, 0, 0);
+    }
+  };
+  f32x4 acc[RT][BT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int ss) __attribute__((always_inline)) {
+    const char* wb = wring + (ss % S) * RT * WT;
+    const char* buf = xs + ((ss >> 1) & 1) * XBUF;
+    bf16x8 wf[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[rt][j] = *reinterpret_cast<const bf16x8*>(wb + rt * WT + fr * 256 + (((j * 4 + fq) ^ fr) << 4));
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) {
-      const int b = bt * 16 + fr;
-      if (b >= a.B) continue;
-      const int n = r0 + fq * 4;
-      if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)b * a.N + n) = acc[0][bt];
-      else
+      bf16x8 xf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.N) ws[(size_t)b * a.N + n + r] = acc[0][bt][r];
+      for (int j = 0; j < 4; ++j)
+        xf[j] = *reinterpret_cast<const bf16x8*>(buf + (bt * 16 + fr) * XROW + ((ss & 1) * 128 + j * 32 + fq * 8) * 2);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[j], acc[rt][bt], 0, 0, 0);
     }
-    return;
+  };
+  // issue order per wave: X(0) W(0..S-2) | per chunk c: X(c+1) W(2c+S-1) [use 2c] W(2c+S) [use 2c+1] | ...
+  stage_x(0);
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i) issue_w(i);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * RT * 4) : "memory");   // x(0) is older than the weight copies
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nchunk; ++c) {
+    stage_x(c + 1);
+    issue_w(2 * c + S - 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * RT * 4 + BT * 4) : "memory");   // W(2c) has landed
+    mma(2 * c);
+    issue_w(2 * c + S);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * RT * 4 + BT * 4) : "memory");   // W(2c+1) has landed
+    mma(2 * c + 1);
+    // x(c+1) has landed (two weight copies are younger) and every wave is done with x(c)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * RT * 4) : "memory");
+    __builtin_amdgcn_s_barrier();
   }
-#pragma unroll
-  for (int bt = 0; bt < BT; ++bt) {
-    const int b = bt * 16 + fr;
-    if (b >= a.B) continue;
-    if (EPI == EPI_SWIGLU) {
-      const int f = (r0 >> 5) * 16 + fq * 4;
-      if (f >= a.N) continue;
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = rbf(silu_f(rbf(acc[0][bt][r]))) * rbf(acc[RT - 1][bt][r]);
-      *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
-    } else {
-      const int n = r0 + fq * 4;
-      if (n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = (n + r) < a.N ? n + r : a.N - 1;
-        v[r] = rbf(acc[0][bt][r] + (a.bias ? bf2f(a.bias[nn]) : 0.f));
-        if (EPI == EPI_RESID) v[r] = rbf(v[r] + bf2f(a.resid[(size_t)b * a.ldy + nn]));
-        if (EPI == EPI_GELU_ERF) v[r] = rbf(gelu_erf_f(v[r]));
-        if (EPI == EPI_GELU_ESM) v[r] = gelu_esm_chain(v[r]);
-      }
-      if (n + 3 < a.N && (a.ldy & 3) == 0) {
-        *reinterpret_cast<uint2*>(a.y + (size_t)b * a.ldy + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.N) a.y[(size_t)b * a.ldy + n + r] = f2bf(v[r]);
-      }
-    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this workgroup's LDS may still be written when it retires
+  mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
+}
+
+template <int EPI, int BT>
+void launch_mfma3(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int S = RT == 2 ? 3 : 6;           // 96 KB of weight rings per workgroup either way
+  constexpr size_t smem = (size_t)4 * S * RT * 4096 + 2 * BT * 16 * (256 * 2 + 16);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma3_kernel<EPI, BT, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
   }
+  hipLaunchKernelGGL((gemv_mfma3_kernel<EPI, BT, S>), dim3(bx, ksplit), dim3(256), smem, s, a, ksplit);
 }
 
 template <int EPI>
@@ -712,12 +834,20 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
   {
     const int rpw = (EPI == EPI_SWIGLU) ? 32 : 16;          // weight rows per wave
     const int bx = (nrows + 4 * rpw - 1) / (4 * rpw);
-    // K split: enough workgroups for two per CU; only with a plain / residual epilogue and a workspace
+    // K split until ~3/4 of the CUs have a workgroup (measured batch-32 decode step with the fill target at 128 / 192 / 256 / 512
+    // workgroups: 4.46 / 4.21 / 4.28 / 4.56 ms); only with a plain / residual epilogue and a workspace
     int ksplit = 1;
+    constexpr int kfill = 192;
     if ((EPI == EPI_STORE || EPI == EPI_RESID) && a.splitk_ws && a.N % 4 == 0 && (a.ldy & 3) == 0)
-      while (ksplit < 8 && bx * ksplit < 256 && a.K % (ksplit * 2 * 512) == 0 &&
+      while (ksplit < 8 && bx * ksplit < kfill && a.K % (ksplit * 2 * 512) == 0 &&
              (size_t)(ksplit * 2) * a.B * a.N * 4 <= a.splitk_ws_bytes) ksplit *= 2;
-    if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 1>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
+    // PCY_GEMV_LDS=0: weights through registers (gemv_mfma2_kernel) instead of LDS-DMA (gemv_mfma3_kernel); read per call, same bits
+    const char* lds_env = getenv("PCY_GEMV_LDS");
+    const bool lds = !(lds_env && atoi(lds_env) == 0) && a.K % (ksplit * 256) == 0;
+    if (lds) {
+      if (a.B <= 16) launch_mfma3<EPI, 1>(s, a, bx, ksplit);
+      else launch_mfma3<EPI, 2>(s, a, bx, ksplit);
+    } else if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 1>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
     else hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 2>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
     if (ksplit > 1) {
       const int eb = (int)(((size_t)a.B * (a.N / 4) + 255) / 256);
