@@ -189,7 +189,7 @@ size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
   return align_up((size_t)B * m->d * 2, 256) + align_up(B * qkvw * 2, 256) +
          align_up((size_t)B * m->n_heads * m->head_dim * 2, 256) + align_up((size_t)B * m->ffn * 2, 256) +
          align_up((size_t)B * m->n_heads * (Tmax + 1) * 4, 256) + align_up((size_t)B * 64 * 16, 256) +
-         align_up((size_t)B * m->d * 2, 256) + (B > 4 ? align_up((size_t)8 * B * qkvw * 4, 256) : 0) + 4096;
+         align_up((size_t)B * m->d * 2, 256) + (B >= pcy_mfma_min_batch() ? align_up((size_t)8 * B * qkvw * 4, 256) : 0) + 4096;
 }
 
 void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
@@ -204,9 +204,9 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* scores = cv.take<float>((size_t)B * H * (kv->Tmax + 1));
   cv.take<char>((size_t)B * 64 * 16);                 // pick partials (same carve as enqueue_pick)
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
-  const size_t sk_bytes = B > 4 ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
+  const size_t sk_bytes = B >= pcy_mfma_min_batch() ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
-  const bool batched = B > 4 && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
+  const bool batched = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
   const bool try_mc = mlp_chain_enabled() && B == 1 && c->ao_sync && c->xwg_err && c->mc_tags;
   pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,

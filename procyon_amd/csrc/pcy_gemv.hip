@@ -1106,12 +1106,16 @@ bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
 }
 
 
+// Smallest batch that takes the MFMA GEMVs (weights once per 16 / 32 rows) instead of the streaming kernel (x rows in LDS, one
+// dot product per row and lane): decode step at T = 128, batch 2 / 3 / 4: 3.49 / 3.99 / 4.42 ms streaming, 4.01 / 4.01 / 4.02 MFMA
+int pcy_mfma_min_batch() { return 4; }
+
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   PcyGemvArgs a0 = a00;
   a0.plain_loads = 0;
-  // B > 4 on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused RMSNorm prologue is a
-  // B <= 4 feature)
-  if (a0.B > 4 && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
+  // batches from pcy_mfma_min_batch() on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused
+  // RMSNorm prologue is a feature of the streaming kernel)
+  if (a0.B >= pcy_mfma_min_batch() && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
     for (int b0 = 0; b0 < a0.B; b0 += 32) {
       PcyGemvArgs a = a0;
       a.B = (a0.B - b0) < 32 ? (a0.B - b0) : 32;

@@ -21,6 +21,7 @@ struct PcyGemvArgs {
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
+int pcy_mfma_min_batch();   // smallest batch that takes the MFMA GEMVs
 
 // Batch-1 decode: the MLP of a layer and the qkv projection of the NEXT layer in ONE launch (pcy_gemv.hip, mlp_chain_kernel):
 //   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) ;  x_out = x + act . Wdown^T ;  qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T
