@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include "pcy_internal.h"
 #include "pcy_handover.h"
+#include "pcy_mlp_chain.h"
 
 namespace {
 
@@ -410,16 +411,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     {
       uint4 ka[KLD], kb_[KLD];
       fetch_k(0, ka);
-      __syncthreads();                         // previous readers of buffer 0 are done
+      lds_barrier();                         // previous readers of buffer 0 are done
       put_k(smem, ka);
       if (32 < kend) fetch_k(32, ka);          // block 1 -> ka
-      __syncthreads();
+      lds_barrier();
 #define PCY_P1_STEP(NEXT, FAR)                                                          \
       {                                                                                 \
         if (kb0 + 64 < kend) fetch_k(kb0 + 64, FAR);      /* block i+2 */               \
         p1_step(kb0, cur);                                                              \
         if (kb0 + 32 < kend) put_k(smem + (cur ^ 1) * KTILE, NEXT);   /* block i+1 */   \
-        __syncthreads();                                                                \
+        lds_barrier();                                                                   \
         kb0 += 32; cur ^= 1;                                                            \
       }
       int kb0 = 0, cur = 0;
@@ -467,16 +468,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   {
     uint4 ka[KLD], va[VLD], kb_[KLD], vb_[VLD];
     fetch_k(0, ka); fetch_v(0, va);
-    __syncthreads();
+    lds_barrier();
     put_k(kb_base, ka); put_v(vb_base, va);
     if (32 < kend) { fetch_k(32, ka); fetch_v(32, va); }
-    __syncthreads();
+    lds_barrier();
 #define PCY_P2_STEP(KN, VN, KF, VF)                                                                        \
     {                                                                                                      \
       if (kb0 + 64 < kend) { fetch_k(kb0 + 64, KF); fetch_v(kb0 + 64, VF); }                               \
       p2_step(kb0, cur);                                                                                   \
       if (kb0 + 32 < kend) { put_k(kb_base + (cur ^ 1) * KTILE, KN); put_v(vb_base + (cur ^ 1) * VTILE, VN); } \
-      __syncthreads();                                                                                     \
+      lds_barrier();                                                                                        \
       kb0 += 32; cur ^= 1;                                                                                 \
     }
     int kb0 = 0, cur = 0;
@@ -697,14 +698,18 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 //                            inputs_ready hook waits for the G + 2 rows of the new token's q / k / v that THIS kv head needs
 //                            (tagged words, pcy_handover.h), staged in LDS;
 //   workgroups [n_attn, 256) hold their 4 rows of Wqkv in registers (32 KB per wave, requested right behind x), project,
-//                            store tagged; then pull their 3 rows of Wo into the same registers while the attention runs,
+//                            store tagged; then (the first 128 of them) pull 4 rows of Wo into the same registers while the attention runs,
 //                            take the attention output (tagged) and finish with the residual epilogue.
 // Attention workgroups have the lowest indices and wait only for projection workgroups, which wait for nobody before their
 // stores: no dead-lock whatever the residency.  Per-row arithmetic, accumulation order and rounding points are those of
 // gemv_stream_kernel (qkv: RMSNorm statistic summed with the stand-alone launch's `vthr` threads) and of attn_o_kernel.
-template <int DH, int G>
-__global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, int n_attn, const unsigned* step_epoch,
-                                                         int vthr_qkv, size_t stage_off, int wo_delay) {
+// MLP = true: the whole layer in this launch.  The o projection hands the residual stream over as tagged words (p.xo_tag) instead of
+// storing it, every workgroup -- attention ones included -- takes it into LDS (the second RMSNorm needs all of it: a barrier in
+// all but name) and runs mc_mlp_body; the projection workgroups have requested the first 16 KB of their gate/up rows while they
+// waited for the attention, so the stream restarts from registers.
+template <int DH, int G, bool MLP>
+__global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
+                                                         const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int wo_delay, int vthr_gu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
@@ -744,6 +749,16 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     };
     attn_dec_body<DH, G, 16>(a, smem, bx, kvh, 0, hook);
     AB_T(2)
+    if constexpr (MLP) {
+      uint4 wa[16], wb[16];
+      if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, true);   // 32 KB per wave while x is on its way
+      __syncthreads();                                   // the attention's LDS is dead
+      bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
+      mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);   // by the wave that has no gate/up rows (and nothing in flight)
+      AB_T(3)
+      mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr);
+      AB_T(5)
+    }
     return;
   }
   // ---- projection workgroups ----
@@ -780,24 +795,29 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     }
   }
   AB_T(1)
-  // o rows [r0, r0 + 3): into the same registers while the attention runs -- a little later, so that the attention workgroups'
-  // requests for the fresh q / k / v do not queue behind 33 MB of weight reads (the rows are needed ~12 us from now)
+  // o rows [r0, r0 + 4) (the first d / 32 projection workgroups: 32 rows = ONE 128-byte line of the result per workgroup -- words
+  // of a line stored one by one from several CUs took 3.6 us to become visible, a line written by one instruction ~1): into
+  // the same registers while the attention runs -- a little later, so that the attention workgroups' requests for the fresh
+  // q / k / v do not queue behind 33 MB of weight reads (the rows are needed ~12 us from now)
   if (wo_delay > 0) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < (unsigned long long)wo_delay) __builtin_amdgcn_s_sleep(8);
   }
-  const int r0 = gwo * 3;
-  const bool active = r0 < d;
-  float res[3] = {0.f, 0.f, 0.f};
+  const int r0 = gwo * 4;
+  const bool active = r0 < d;                 // (workgroup-uniform: d % 32 == 0)
+  uint4 wa[16], wb[16];
+  float res[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int r = r0 + i < d ? r0 + i : d - 1;
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + i;
 #pragma unroll
       for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (c * 64 + lane) * 8);
       res[i] = bf2f(p.x[r]);
     }
   }
+  // gate/up rows of the MLP while the attention runs: 16 KB per wave beside the Wo rows (both batches: 256 VGPRs and spills)
+  if constexpr (MLP) { if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false); }
   // the attention output: one wave watches a 1 KB sample (192 workgroups asking for all 16 KB in a loop would load the fabric
   // while the attention workgroups are inside their latency chain), then every wave takes its share
   if (wave == 0) {
@@ -819,33 +839,48 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
   }
   __syncthreads();
   AB_T(3)
-  if (!active) return;
-  float acc[3] = {0.f, 0.f, 0.f};
+  if (active) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint4 xv = *reinterpret_cast<const uint4*>(xa + (c * 64 + lane) * 8);
+    for (int c = 0; c < 8; ++c) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(xa + (c * 64 + lane) * 8);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) acc[i] = dot8(w[i * 8 + c], xv, acc[i]);
-  }
+      for (int i = 0; i < 4; ++i) acc[i] = dot8(w[i * 8 + c], xv, acc[i]);
+    }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) acc[i] = wave_sum(acc[i]);
-  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    uint32_t* line = reinterpret_cast<uint32_t*>(red);   // the workgroup's 32 results, stored as one line by one wave
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (r0 + i >= d) continue;
-      float v = rbf(acc[i]);
-      v = rbf(v + res[i]);
-      p.x_out[r0 + i] = f2bf(v);
+      for (int i = 0; i < 4; ++i) {
+        float v = rbf(acc[i]);
+        v = rbf(v + res[i]);
+        line[wave * 4 + i] = f2bf(v);
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 32) {
+      const int r = (r0 & ~31) + lane;   // r0 of wave 0 is the workgroup's first row
+      if (MLP) __hip_atomic_store(p.xo_tag + r, (tag << 16) | line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else p.x_out[r] = (bf16_t)line[lane];
     }
   }
   AB_T(4)
+  if constexpr (MLP) {
+    __syncthreads();                                     // every wave is done with the attention output in LDS
+    bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
+    mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
+    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 1, wa, wb, nullptr);
+    AB_T(5)
+  }
 #undef AB_T
 }
 
 template <int DH, int G>
-bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const unsigned* step_epoch, unsigned* xflags) {
+bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const unsigned* step_epoch, unsigned* xflags,
+                       const PcyMlpChainArgs* mc) {
   const int n_attn = (DH / 16) * a.Hkv, n_o = 256 - n_attn;
-  if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 3 || a.H * DH != 8 * 512 || p.d != 4096) return false;
+  if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 4 || a.H * DH != 8 * 512 || p.d != 4096) return false;
   a.o_sc1 = 0;
   const char* xe = getenv("PCY_AO_XMIN");   // key split between the slice workgroups (see launch_attn_o_rw)
   const int xmin = xe ? atoi(xe) : 768;
@@ -854,17 +889,27 @@ bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& 
   a.unit_map = 1;
   const size_t stage_off = (attn_dec_smem_bytes(G, 16, DH, a.Tmax) + 15) & ~(size_t)15;
   const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(p.d + a.H * DH) * 2 + 128;
-  const size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
-  static size_t configured = 0;
-  if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured = smem;
+  size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
+  if (mc) {   // the MLP body: same geometry conditions as pcy_launch_mlp_chain
+    if (mc->d != p.d || mc->d != 2 * 256 * 8 || mc->F != 2 * 7 * 1024 || mc->wqkv_next) return false;
+    const size_t smem_mlp = (size_t)(2 * mc->d + mc->F) * 2 + 128;
+    smem = smem > smem_mlp ? smem : smem_mlp;
+  }
+  static size_t configured[2] = {0, 0};
+  if (smem > 65536 && smem > configured[mc ? 1 : 0]) {
+    if (mc) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured[mc ? 1 : 0] = smem;
   }
   // Wo prefetch 2 us behind the qkv stores: decode step 2.91 (no delay) -> 2.83 (2 us) -> 2.83 (4 us) -> 2.85 ms (6 us) at t = 520..780;
   // PCY_AB_DELAY overrides, in 10 ns ticks
   static const int wo_delay = [] { const char* e = getenv("PCY_AB_DELAY"); return e ? atoi(e) : 200; }();   // 10 ns ticks
-  hipLaunchKernelGGL((attn_block_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq), stage_off,
-                     wo_delay);
+  if (mc)
+    hipLaunchKernelGGL((attn_block_kernel<DH, G, true>), dim3(256), dim3(512), smem, s, a, p, *mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
+                       stage_off, wo_delay, pcy_gemv_rms_threads(mc->F));
+  else
+    hipLaunchKernelGGL((attn_block_kernel<DH, G, false>), dim3(256), dim3(512), smem, s, a, p, PcyMlpChainArgs{}, n_attn, step_epoch,
+                       pcy_gemv_rms_threads(p.Nq), stage_off, wo_delay, 64);
   return true;
 }
 
@@ -962,13 +1007,13 @@ bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs
 // Decode attention block (see attn_block_kernel).  Returns false (nothing launched) when the shape is not covered: batch 1,
 // head_dim 128, H * dh = d = 4096, G in {1,2,4,8}, Nq = 4 rows per projection wave, 256 CUs.
 bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
-                           unsigned* xflags) {
+                           unsigned* xflags, const PcyMlpChainArgs* mc) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256) return false;
   switch (a.H / a.Hkv) {
-    case 1: return launch_attn_block<128, 1>(s, a, p, step_epoch, xflags);
-    case 2: return launch_attn_block<128, 2>(s, a, p, step_epoch, xflags);
-    case 4: return launch_attn_block<128, 4>(s, a, p, step_epoch, xflags);
-    case 8: return launch_attn_block<128, 8>(s, a, p, step_epoch, xflags);
+    case 1: return launch_attn_block<128, 1>(s, a, p, step_epoch, xflags, mc);
+    case 2: return launch_attn_block<128, 2>(s, a, p, step_epoch, xflags, mc);
+    case 4: return launch_attn_block<128, 4>(s, a, p, step_epoch, xflags, mc);
+    case 8: return launch_attn_block<128, 8>(s, a, p, step_epoch, xflags, mc);
   }
   return false;
 }

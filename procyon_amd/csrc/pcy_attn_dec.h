@@ -93,10 +93,6 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // DS = output columns per workgroup.  16 (DH/16 workgroups per (kv head, sequence), each recomputing the scores) fills
 // the chip when B x Hkv is small; at beam / batch sizes where B x Hkv x DH/DS already covers the CUs the redundant score
 // passes are the dominant cost and a wider slice (up to the whole head) is used instead.
-// Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt (its release fence covers global stores, and
-// loads share the counter): the first barrier of the kernel then waits for every prefetched key tile and V row to arrive
-// from HBM (measured: 6.8 us from the position load to the first barrier) and the prefetch overlaps nothing.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct AttnDecNoHook { __device__ __forceinline__ void operator()() const {} };
 

@@ -138,12 +138,20 @@ bool attn_block_enabled() {
   const char* e = getenv("PCY_ATTN_BLOCK");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0) | (attn_block_enabled() ? 16 : 0); }
+// PCY_LAYER_FUSED=0: the attention block and the MLP chain as two launches per layer instead of one (default one; needs the
+// switches above on).  Read on every call, bit-identical either way.
+bool layer_fused_enabled() {
+  const char* e = getenv("PCY_LAYER_FUSED");
+  return !e || atoi(e) != 0;
+}
+int decode_mode() {
+  return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0) | (attn_block_enabled() ? 16 : 0) | (layer_fused_enabled() ? 32 : 0);
+}
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
-// tagged vectors of one layer: act [ffn], x after the MLP [d], qkv [(H + 2 Hkv) dh], attention output [H dh]
+// tagged vectors of one layer: act [ffn], x after the MLP [d], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
 size_t tag_words_per_layer(const pcy_llama_desc* m) {
-  return (size_t)m->ffn + m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
+  return (size_t)m->ffn + 2 * (size_t)m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
 }
 
 // device words of the in-launch hand-overs; must run outside stream capture
@@ -213,6 +221,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
                               try_mc ? c->ao_sync + 1 : nullptr);
   bool qkv_done = false;   // the previous layer's MLP chain launch has already produced this layer's qkv
   bool try_blk = attn_block_enabled() && try_mc && try_ao;   // qkv + attention + o in one launch (then the chain stops after down)
+  bool try_layer = try_blk && layer_fused_enabled();          // ... and the MLP in the same launch
   const size_t tag_stride = tag_words_per_layer(m);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
@@ -244,14 +253,22 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       PcyAttnBlockArgs bp{};
       bp.x = x; bp.x_out = x; bp.ln1 = (const bf16_t*)L.ln1; bp.wqkv = (const bf16_t*)L.wqkv; bp.wo = (const bf16_t*)L.wo;
       bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast;
-      bp.qkv_tag = tags + F + d; bp.ao_tag = bp.qkv_tag + qkvw;
+      bp.qkv_tag = tags + F + d; bp.ao_tag = bp.qkv_tag + qkvw; bp.xo_tag = bp.ao_tag + H * dh;
       bp.epoch = c->ao_sync + 1; bp.err = c->xwg_err;
       if (getenv("PCY_MC_TRACE")) {   // measurement aid: stamps of this launch behind those of the chain launches
         if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
         bp.trace = g_mc_trace + (size_t)(128 + l) * 256 * 16;
       }
+      if (try_layer) {   // the whole layer as one launch
+        PcyMlpChainArgs mc{};
+        mc.x = x; mc.x_out = x; mc.ln2 = (const bf16_t*)L.ln2; mc.wgu = (const bf16_t*)L.wgu; mc.wdown = (const bf16_t*)L.wdown;
+        mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast;
+        mc.act_tag = tags; mc.x_tag = tags + F; mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
+        if (pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS, &mc)) continue;
+        try_layer = false;   // geometry not covered: the same for every layer
+      }
       blk_done = pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS);
-      if (!blk_done) try_blk = false;   // geometry not covered: the same for every layer
+      if (!blk_done) try_blk = false;
     }
     if (!blk_done) {
       if (!qkv_done) pcy_launch_gemv(s, g);

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include "pcy_internal.h"
 #include "pcy_handover.h"
+#include "pcy_mlp_chain.h"
 
 namespace {
 
@@ -891,176 +892,26 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
 //
 // Arithmetic per output row = gemv_stream_kernel's (same k order of the accumulation, same reduction tree, same rounding
 // points); the RMSNorm statistic is summed in the order of the stand-alone launch (`vthr` threads, block_sum_rt): bit-identical.
-constexpr int MC_NT = 512, MC_WV = 8, MC_UNB_D = 7;
-
-// One wave streams its units (RW weight rows each, row i of unit u at W + row_off(u, i)) against xs, UNB k-iterations of 512
-// elements per batch, two batches in flight (wa / wb).  primed: the first two batches of (u0, it 0) are already in wa / wb.
-// before_batch(it0) runs ahead of the arithmetic of every batch (the down stage waits there for the second half of its input).
-template <int RW, int UNB, typename RowOff, typename Finish, typename Before>
-__device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, const bf16_t* xs, int lane, int u0, int ustride, int uend,
-                                          uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch) {
-  static_assert(RW * UNB <= 16, "batch size");
-  const int nit = K >> 9;
-  auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int un = 0; un < UNB; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
-      const bool ok = (it0 + un) < nit;
-#pragma unroll
-      for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  float acc[RW];
-#pragma unroll
-  for (int i = 0; i < RW; ++i) acc[i] = 0.f;
-  auto compute = [&](int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int un = 0; un < UNB; ++un) {
-      if ((it0 + un) < nit) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(xs + ((it0 + un) * 64 + lane) * 8);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) acc[i] = dot8(w[un * RW + i], xv, acc[i]);
-      }
-    }
-  };
-  auto next_pos = [&](int cu, int cit, int& nu, int& nit_) __attribute__((always_inline)) { nit_ = cit + UNB; nu = cu; if (nit_ >= nit) { nit_ = 0; nu = cu + ustride; } };
-  int u = u0, it0 = 0, u1, it1;
-  bool have = u < uend;
-  next_pos(u, 0, u1, it1);
-  bool have1 = have && u1 < uend;
-  if (!primed) {
-    if (have) issue(u, 0, wa);
-    if (have1) issue(u1, it1, wb);
-  }
-#define PCY_MC_STEP(CUR)                                   \
-  {                                                        \
-    before_batch(it0);                                     \
-    compute(it0, CUR);                                     \
-    if (it0 + UNB >= nit) {                                \
-      _Pragma("unroll") for (int i = 0; i < RW; ++i) acc[i] = wave_sum(acc[i]); \
-      finish(u, acc);                                      \
-      _Pragma("unroll") for (int i = 0; i < RW; ++i) acc[i] = 0.f; \
-    }                                                      \
-    int u2, it2;                                           \
-    next_pos(u1, it1, u2, it2);                            \
-    const bool have2 = have1 && u2 < uend;                 \
-    if (have2) issue(u2, it2, CUR);                        \
-    u = u1; it0 = it1; have = have1;                       \
-    u1 = u2; it1 = it2; have1 = have2;                     \
-  }
-  while (have) {
-    PCY_MC_STEP(wa)
-    if (!have) break;
-    PCY_MC_STEP(wb)
-  }
-#undef PCY_MC_STEP
-}
-// request the first two batches of unit u0 (what mc_stream(primed = true) expects to find)
-template <int RW, int UNB, typename RowOff>
-__device__ __forceinline__ void mc_prime(const bf16_t* __restrict__ W, int K, int lane, int u0, int ustride, int uend, uint4 (&wa)[16], uint4 (&wb)[16],
-                                         RowOff row_off) {
-  const int nit = K >> 9;
-  auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int un = 0; un < UNB; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
-      const bool ok = (it0 + un) < nit;
-#pragma unroll
-      for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  if (u0 < uend) {
-    issue(u0, 0, wa);
-    int u1 = u0, it1 = UNB;
-    if (it1 >= nit) { it1 = 0; u1 = u0 + ustride; }
-    if (u1 < uend) issue(u1, it1, wb);
-  }
-}
-
 __global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, int vthr_gu, int vthr_qkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int d = a.d, F = a.F;
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                      // [d]  normalised input of stage 1, later of stage 3
-  bf16_t* xa = xs + d;                                               // [F]  act
-  bf16_t* xr = xa + F;                                               // [d]  the residual stream after the MLP
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                      // LDS layout of mc_mlp_body: [d] | [F] | [d] | red
+  bf16_t* xr = xs + d + F;
   float* red = reinterpret_cast<float*>(xr + d);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar branches on it)
   const int G = gridDim.x, NW = G * MC_WV;
   const int gw = blockIdx.x * MC_WV + wave;
   const uint32_t tag = *a.epoch & 0xffffu;
-  uint4 wa[16], wb[16], tq[4];
+  uint4 wa[16], wb[16];
   unsigned long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
 #define MC_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
   MC_T(0)
-
-  // down rows: one unit of two rows per wave (d == 2 * NW), MC_UNB_D k-iterations per batch
-  const int units_d = d / 2, r0 = gw * 2;
-  auto row_d = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(u * 2 + i) * F; };
-  const int half = F >> 1;                                           // act words per half; waves 0..6 fetch 1024 words of it each
-
-  // ---- stage 1: act = SwiGLU( RMSNorm(x) * ln2 . Wgu^T ): units of 4 features (8 weight rows), 7 waves per workgroup ----
-  const int units_g = (F + 3) / 4, NWG7 = G * 7, gidx = blockIdx.x * 7 + wave;
-  auto row_g = [&](int u, int i) __attribute__((always_inline)) -> size_t {
-    const int f = u * 4 + (i & 3);
-    const int fc = f < F ? f : F - 1;
-    return (size_t)((fc >> 4) * 32 + (fc & 15) + (i >= 4 ? 16 : 0)) * d;
-  };
-  mc_rms_stage(a.x, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
-    if (wave < 7) mc_prime<8, 2>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g);
-  });
-  if (wave < 7) {
-    mc_stream<8, 2>(a.wgu, d, xs, lane, gidx, NWG7, units_g, wa, wb, true, row_g, [&](int u, const float (&acc)[8]) __attribute__((always_inline)) {
-      if (lane == 0) {
-        uint32_t o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float g = rbf(acc[i]), up = rbf(acc[i + 4]);
-          o[i] = (tag << 16) | f2bf(rbf(silu_f(g)) * up);
-        }
-        st8_agent(a.act_tag + u * 4, o[0], o[1]);
-        st8_agent(a.act_tag + u * 4 + 2, o[2], o[3]);
-      }
-    }, [](int) __attribute__((always_inline)) {});
-    MC_T(1)
-    // ---- stage 2 begins for this wave: first half of act, then the first two batches of its down rows ----
-    mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);
-  }
-  mc_prime<2, MC_UNB_D>(a.wdown, F, lane, gw, NW, units_d, wa, wb, row_d);
-  if (wave < 7) {
-    mc_fetch_finish<4>(a.act_tag, wave * 1024, lane, tag, xa, tq, a.err, 6u);
-    mc_fetch_issue<4>(a.act_tag, half + wave * 1024, lane, tq);   // second half: checked nb/2 batches from now
-  }
-  __syncthreads();
-  MC_T(2)
-  const bool chain = a.wqkv_next != nullptr;
+  mc_mlp_body<false>(a, smem, vthr_gu, tag, G, blockIdx.x, 0, wa, wb, tr);
+  MC_T(4)
+  if (a.wqkv_next == nullptr) return;
+  // ---- stage 3: qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T.  The tagged vector is asked for first, then every row ----
   const int units_q = (a.Nq + 2) / 3;
   auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { const int r = u * 3 + i; return (size_t)(r < a.Nq ? r : a.Nq - 1) * d; };
-  float acc[2] = {0.f, 0.f};
-  const int it_half = (F >> 9) / 2;
-  mc_stream<2, MC_UNB_D>(a.wdown, F, xa, lane, gw, NW, units_d, wa, wb, true, row_d,
-                         [&](int u, const float (&acc2)[2]) __attribute__((always_inline)) { acc[0] = acc2[0]; acc[1] = acc2[1]; },
-                         [&](int it0) __attribute__((always_inline)) {
-                           if (it0 == it_half) {   // (workgroup-uniform: every wave walks the same batches of its one unit)
-                             if (wave < 7) mc_fetch_finish<4>(a.act_tag, half + wave * 1024, lane, tag, xa, tq, a.err, 7u);
-                             __syncthreads();
-                             MC_T(3)
-                           }
-                         });
-  // ---- x_out = x + act . Wdown^T ----
-  if (lane == 0) {
-    uint32_t o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float v = rbf(acc[i]);
-      v = rbf(v + bf2f(a.x[r0 + i]));
-      o[i] = f2bf(v);
-    }
-    *reinterpret_cast<uint32_t*>(a.x_out + r0) = o[0] | (o[1] << 16);
-    if (chain) st8_agent(a.x_tag + r0, (tag << 16) | o[0], (tag << 16) | o[1]);
-  }
-  MC_T(4)
-  if (!chain) return;
-  // ---- stage 3: qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T.  The tagged vector is asked for first, then every row ----
   uint4 tx[2];
   mc_fetch_issue<2>(a.x_tag, wave * 512, lane, tx);
   mc_prime<3, 5>(a.wqkv_next, d, lane, gw, NW, units_q, wa, wb, row_q);

@@ -44,6 +44,27 @@ __device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int
         make_uint2((pre[j].x & 0xffffu) | (pre[j].y << 16), (pre[j].z & 0xffffu) | (pre[j].w << 16));
 }
 
+// A whole tagged vector of 8 x 512 words -> LDS: one wave watches a 1 KB sample until it is current (a workgroup then asks for
+// 1 KB per round trip instead of 16 KB while it waits), then every wave takes its 512 words.  All 512 threads; ends with a barrier.
+__device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == watch_wave) {
+    unsigned spins = 0;
+    for (;;) {
+      const uint4 v = ld16_agent(src + n - 256 + lane * 4);
+      const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  uint4 t[2];
+  mc_fetch_issue<2>(src, wave * 512, lane, t);
+  mc_fetch_finish<2>(src, wave * 512, lane, tag, dst, t, err, code);
+  __syncthreads();
+}
+
 // xs[0..K) = bf16( RMSNorm(x) * w ) with the statistic summed like gemv_stream_kernel launched with `vthr` threads.  x: global
 // (written before this launch) or LDS.  K <= 8 * MC_NT.  All threads; ends with a barrier.
 template <typename AfterLoads>

@@ -144,14 +144,18 @@ struct PcyAttnBlockArgs {
   const bf16_t* wo;                         // [d, H*dh]
   int d, Nq; float rms_eps; int rms_cast;
   uint32_t* qkv_tag; uint32_t* ao_tag;      // [Nq], [H*dh] tagged hand-over vectors, private to THIS layer's launch
+  uint32_t* xo_tag;                         // [d] the residual stream after the o projection (whole-layer launch only)
   const unsigned* epoch;                    // tag counter (see pcy_handover.h)
   unsigned* err;
   unsigned long long* trace;                // measurement aid: [grid][16] time stamps (nullptr: none)
 };
 // false = geometry not covered (nothing launched).  xflags / step_epoch: key-split exchange of the attention workgroups
 // (as pcy_launch_attn_o).
+// mc != nullptr: the MLP of the layer in the same launch (x_out of `p` unused; mc->x / mc->x_out: mc->x unused, the result of
+// the layer goes to mc->x_out; mc->wqkv_next must be null).
+struct PcyMlpChainArgs;
 bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
-                           unsigned* xflags);
+                           unsigned* xflags, const PcyMlpChainArgs* mc = nullptr);
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
 int pcy_gemv_rms_threads(int N);
 

@@ -242,7 +242,7 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
 
 @pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (40, 12, 2), (1100, 6, 2)])
 def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
-    """The batch-1 decode step as two launches per layer (defaults):
+    """The batch-1 decode step as ONE launch per layer (default; PCY_LAYER_FUSED=0: two):
       PCY_ATTN_BLOCK: qkv projection + attention + o projection (the attention workgroups request their cache rows at once and
         take the new token's q / k / v from the tagged qkv vector when the projection workgroups deliver it);
       PCY_MLP_CHAIN:  gate/up + SwiGLU, down + residual (and, with PCY_ATTN_BLOCK=0, the NEXT layer's qkv projection);
@@ -258,9 +258,10 @@ def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
-    def run(chain, block, use_graph):
+    def run(chain, block, use_graph, layer=False):
         monkeypatch.setenv("PCY_MLP_CHAIN", "1" if chain else "0")
         monkeypatch.setenv("PCY_ATTN_BLOCK", "1" if block else "0")
+        monkeypatch.setenv("PCY_LAYER_FUSED", "1" if layer else "0")
         cache = eng.new_cache(1, T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
@@ -277,10 +278,11 @@ def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
                 cache.v[:, 0, :, T:T + N].cpu())
 
     ref = run(False, False, False)
-    for chain, block, use_graph in ((True, False, False), (True, False, True), (True, True, False), (True, True, True), (True, True, True)):
-        got = run(chain, block, use_graph)
+    for chain, block, use_graph, layer in ((True, False, False, False), (True, False, True, False), (True, True, False, False),
+                                           (True, True, True, False), (True, True, False, True), (True, True, True, True), (True, True, True, True)):
+        got = run(chain, block, use_graph, layer)
         for x, y in zip(got, ref):
-            assert torch.equal(x, y), (chain, block, use_graph)
+            assert torch.equal(x, y), (chain, block, use_graph, layer)
 
 
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):

@@ -41,8 +41,11 @@ if os.environ.get("PCY_MC_TRACE"):
             if tl[:, i].max() == 0: continue
             print(f"  {nm:22s} {r[:, i].min():7.2f} {np.median(r[:, i]):7.2f} {r[:, i].max():7.2f}")
     for l in (1, 16, 30):
-        show(t[1, l, :64], ["start", "q/k/v staged", "attention done"], f"layer {l} attention block, 64 attention WGs")
-        show(t[1, l, 64:], ["start", "qkv rows stored", "ao sample seen", "ao in LDS", "end"], f"layer {l} attention block, 192 projection WGs")
-        show(t[0, l], ["start", "s1 done(w0)", "act A in LDS", "act B in LDS", "s2 done"], f"layer {l} MLP chain")
-        print("  gap attention block end -> chain start: %.2f us ; chain end -> next block start: %.2f us" % (
-            (t[0, l, :, 0].min() - t[1, l, :, :5].max()) / 100.0, (t[1, l + 1, :, 0].min() - t[0, l, :, :5].max()) / 100.0))
+        show(t[1, l, :64], ["start", "q/k/v staged", "attention done", "x after o in LDS", "-", "layer end"], f"layer {l} attention block, 64 attention WGs")
+        show(t[1, l, 64:], ["start", "qkv rows stored", "ao sample seen", "ao in LDS", "o done", "layer end", "x sample seen", "x fetched"], f"layer {l} attention block, 192 projection WGs")
+        if t[0, l].max() > 0:
+            show(t[0, l], ["start", "s1 done(w0)", "act A in LDS", "act B in LDS", "s2 done"], f"layer {l} MLP chain")
+            print("  gap attention block end -> chain start: %.2f us ; chain end -> next block start: %.2f us" % (
+                (t[0, l, :, 0].min() - t[1, l, :, :5].max()) / 100.0, (t[1, l + 1, :, 0].min() - t[0, l, :, :5].max()) / 100.0))
+        else:
+            print("  layer end -> next layer start: %.2f us" % ((t[1, l + 1, :, 0].min() - t[1, l, :, :6].max()) / 100.0))
