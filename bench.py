@@ -9,7 +9,7 @@ inputs resident in HBM.  value = generated tokens / wall time of the timed steps
 + decode), whole job over all ranks; N > 1 runs N independent replicas (generation rows are independent,
 SURVEY.md section 8e: "replicas only") plus a DP-sharded retrieval leg with ONE RCCL all-gather.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the decode MLP chain launch, algorithmic bytes /
+Extra objects on the JSON line: `roofline` (dominant kernel = the decode layer launch, algorithmic bytes /
 HIP-event time measured live), `cpu_baseline` (the oracle on this box's host cores, bounded sample), `phases`.
 """
 import argparse
@@ -201,36 +201,33 @@ def main():
                   decode_step_algorithmic_GB=(step_bytes + kv_bytes) / 1e9,
                   decode_step_GBps=(step_bytes + kv_bytes) / 1e9 / (dec_ms / 1e3))
 
-    # ---- roofline of the dominant kernel: the decode MLP chain launch (gate/up + SwiGLU, down + residual), one per layer per token
-    x = torch.randn(1, cfg.d, device=dev).bfloat16()
-    wl = [k[2] for k in eng._keep]   # packed gate/up weights of every layer (with the down matrices 11 GB: defeats the 256 MiB L3)
-    wd = [k[3] for k in eng._keep]
-    ln = [k[5] for k in eng._keep]
-    one_launch = cfg.d == 4096 and cfg.ffn == 14336 and os.environ.get("PCY_MLP_CHAIN", "1") != "0"
-    for i in range(len(wl)):
-        ctx.decode_mlp(x, ln[i], wl[i], wd[i], cfg.rms_eps)
-    reps = 4
+    # ---- roofline of the dominant kernel: the decode LAYER launch (qkv + attention + o + gate/up + down of one layer, one per layer per token)
+    one_launch = (cfg.d == 4096 and cfg.ffn == 14336 and cfg.n_heads * cfg.head_dim == 4096 and
+                  all(os.environ.get(k, "1") != "0" for k in ("PCY_MLP_CHAIN", "PCY_ATTN_BLOCK", "PCY_ATTN_O", "PCY_LAYER_FUSED")))
+    t_mid = int(st.pos.item())                     # cache length of the measured launches (the timed decode ended here)
+    reps = 8
+    eng.decode_layers(cache, st, 1, 2)
     ctx.timer_start()
-    for _ in range(reps):
-        for i in range(len(wl)):
-            ctx.decode_mlp(x, ln[i], wl[i], wd[i], cfg.rms_eps)
-    k_ms = ctx.timer_stop() / (reps * len(wl))   # (includes the 1-thread tag-counter launch in front of each call, ~2 us)
-    k_bytes = 3 * cfg.ffn * cfg.d * 2            # Wgu [2F, d] + Wdown [d, F] in bf16: SURVEY.md section 8(d) weight bytes per token and layer
+    eng.decode_layers(cache, st, 1, reps)          # reps x n_layers layer launches (+ 2 one-thread counter launches per pass)
+    k_ms = ctx.timer_stop() / (reps * cfg.n_layers)
+    qkvw = (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim
+    # weight bytes of one layer per token (Wqkv, Wo, Wgu, Wdown, two norm vectors) + the cached K/V rows it reads
+    k_bytes = 2 * (cfg.d * qkvw + cfg.n_heads * cfg.head_dim * cfg.d + 3 * cfg.d * cfg.ffn + 2 * cfg.d) + 2 * cfg.n_kv_heads * cfg.head_dim * 2 * t_mid
     traffic, traffic_source = None, None
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
-    # `--pmc WRITE_SIZE` passes over tools/bench_decode_mlp.py (the same kernel, the same shapes), committed under profiles/
+    # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mlp_chain.json")))["kernels"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_decode_layer.json")))["kernels"]
         if a.geometry == "full" and one_launch:
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "mlp_chain_kernel" in k][0]
-            traffic_source = "profiles/r02_pmc_mlp_chain.json (rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "attn_block_kernel" in k][0]
+            traffic_source = "profiles/r02_pmc_decode_layer.json (rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": ("mlp_chain_kernel (Llama gate/up + SwiGLU + down + residual, 32 launches/token)" if one_launch
-                                           else "gemv_stream_kernel gate/up + down (two launches)"),
+    roofline = {"bound": "hbm", "kernel": ("attn_block_kernel<128,4,MLP> (one Llama decoder layer per launch: qkv, attention, o, gate/up, down; 32 launches/token)"
+                                           if one_launch else "decoder layer as separate launches (average per layer)"),
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
+                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "cache_len": t_mid}
 
     # ---- retrieval leg (config 3 shape): DP-sharded forward_sequences + ONE all-gather --------------
     from procyon_amd.distributed import embed_sharded

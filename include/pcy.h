@@ -210,6 +210,10 @@ typedef struct {
 } pcy_gen_state;
 /* one decode step: next_tok -> logits (and K/V appended at slot *pos); does not pick or advance */
 int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
+/* Measurement aid (bench.py roofline leg): `reps` passes over the decoder layers of a decode step -- no token embedding (the
+ * residual stream is whatever the workspace holds), no lm_head, no pick; K/V of slot *pos are rewritten each pass.  With HIP
+ * events around it: time per layer launch = elapsed / (reps * n_layers). */
+int pcy_llama_decode_layers(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int reps);
 /* the same step as ONE replayed hipGraph (captured on first use per model / cache / state / batch): for host-driven loops that
  * do their own selection between steps (sampling, diverse beam search).  next_tok and *pos are read from device memory. */
 int pcy_llama_decode_graph(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);

@@ -786,13 +786,14 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    // the workgroup's 32 rows = one 128-byte line of the tagged vector, stored by one instruction
+    uint32_t* line = reinterpret_cast<uint32_t*>(red) + 16;
     if (lane == 0) {
-      uint32_t o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (tag << 16) | f2bf(rbf(acc[i]));
-      st8_agent(p.qkv_tag + rq0, o[0], o[1]);
-      st8_agent(p.qkv_tag + rq0 + 2, o[2], o[3]);
+      for (int i = 0; i < 4; ++i) line[wave * 4 + i] = (tag << 16) | f2bf(rbf(acc[i]));
     }
+    __syncthreads();
+    if (wave == 0 && lane < 32) __hip_atomic_store(p.qkv_tag + (rq0 & ~31) + lane, line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   AB_T(1)
   // o rows [r0, r0 + 4) (the first d / 32 projection workgroups: 32 rows = ONE 128-byte line of the result per workgroup -- words

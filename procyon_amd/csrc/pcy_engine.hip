@@ -200,7 +200,9 @@ size_t decode_ws_bytes(const pcy_llama_desc* m, int B, int Tmax) {
          align_up((size_t)B * m->d * 2, 256) + (B >= pcy_mfma_min_batch() ? align_up((size_t)8 * B * qkvw * 4, 256) : 0) + 4096;
 }
 
-void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+// layers_only (measurement, pcy_llama_decode_layers): the decoder layers without the token embedding (the residual stream is whatever
+// the workspace holds) and without lm_head; the hand-over counters are advanced by two one-thread launches instead.
+void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, bool layers_only = false) {
   hipStream_t s = c->stream;
   const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
   const int qkvw = (H + 2 * Hkv) * dh;
@@ -217,8 +219,13 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   const bool batched = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
   const bool try_mc = mlp_chain_enabled() && B == 1 && c->ao_sync && c->xwg_err && c->mc_tags;
-  pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
-                              try_mc ? c->ao_sync + 1 : nullptr);
+  if (layers_only) {
+    if (try_ao) pcy_launch_bump(s, c->ao_sync);
+    if (try_mc) pcy_launch_bump(s, c->ao_sync + 1);
+  } else {
+    pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
+                                try_mc ? c->ao_sync + 1 : nullptr);
+  }
   bool qkv_done = false;   // the previous layer's MLP chain launch has already produced this layer's qkv
   bool try_blk = attn_block_enabled() && try_mc && try_ao;   // qkv + attention + o in one launch (then the chain stops after down)
   bool try_layer = try_blk && layer_fused_enabled();          // ... and the MLP in the same launch
@@ -312,6 +319,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     }
     pcy_launch_gemv(s, w);
   }
+  if (layers_only) return;
   PcyGemvArgs h{};
   h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
   h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = B; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
@@ -883,6 +891,14 @@ int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (int r = ensure_decode_state(c, m)) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
+}
+
+int pcy_llama_decode_layers(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int reps) {
+  if (B > kv->B) return fail(1, "pcy_llama_decode_layers: B=%d exceeds cache rows %d", B, kv->B);
+  if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
+  if (int r = ensure_decode_state(c, m)) return r;
+  for (int i = 0; i < reps; ++i) enqueue_decode(c, m, kv, st, B, true);
+  return check_launch("pcy_llama_decode_layers");
 }
 
 int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int advance_pos) {

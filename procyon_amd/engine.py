@@ -489,6 +489,10 @@ class LlamaEngine:
     def decode(self, cache: KVCache, st: GenState, B):
         L.check(self.ctx.lib.pcy_llama_decode(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode")
 
+    def decode_layers(self, cache: KVCache, st: GenState, B, reps=1):
+        """measurement aid: `reps` passes over the decoder layers of a decode step (no embedding, no lm_head, no pick)."""
+        L.check(self.ctx.lib.pcy_llama_decode_layers(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, reps), "pcy_llama_decode_layers")
+
     def decode_graph(self, cache: KVCache, st: GenState, B):
         """decode step as one replayed hipGraph (~190 launches otherwise): loops that select between steps on the device."""
         L.check(self.ctx.lib.pcy_llama_decode_graph(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode_graph")
