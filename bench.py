@@ -203,7 +203,7 @@ def main():
 
     # ---- roofline of the dominant kernel: the decode LAYER launch (qkv + attention + o + gate/up + down of one layer, one per layer per token)
     one_launch = (cfg.d == 4096 and cfg.ffn == 14336 and cfg.n_heads * cfg.head_dim == 4096 and
-                  all(os.environ.get(k, "1") != "0" for k in ("PCY_MLP_CHAIN", "PCY_ATTN_BLOCK", "PCY_ATTN_O", "PCY_LAYER_FUSED")))
+                  all(os.environ.get(k, "1") != "0" for k in ("PCY_DECODE_LAYER", "PCY_ATTN_O")))
     t_mid = int(st.pos.item())                     # cache length of the measured launches (the timed decode ended here)
     reps = 8
     eng.decode_layers(cache, st, 1, 2)
@@ -219,11 +219,11 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_decode_layer.json")))["kernels"]
         if a.geometry == "full" and one_launch:
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "attn_block_kernel" in k][0]
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
             traffic_source = "profiles/r02_pmc_decode_layer.json (rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": ("attn_block_kernel<128,4,MLP> (one Llama decoder layer per launch: qkv, attention, o, gate/up, down; 32 launches/token)"
+    roofline = {"bound": "hbm", "kernel": ("decode_layer_kernel<128,4> (one Llama decoder layer per launch: qkv, attention, o, gate/up, down; 32 launches/token)"
                                            if one_launch else "decoder layer as separate launches (average per layer)"),
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,

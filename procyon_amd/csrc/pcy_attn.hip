@@ -689,27 +689,28 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 
 
 // ------------------------------------------------------------------------------------------------
-// Decode attention block (batch 1): qkv projection + attention + o projection in ONE launch (PcyAttnBlockArgs).
+// Decode layer (batch 1): qkv projection + attention + o projection + MLP of one decoder layer in ONE launch.
 //
-// The attention of a decode step is a latency chain, the two projections around it are bandwidth.  As launches (qkv GEMV,
-// attention + o) the chain starts only when the whole qkv vector is in memory and a kernel boundary later.  Here
+// The attention of a decode step is a latency chain, the projections around it are bandwidth.  As launches (qkv GEMV,
+// attention + o, gate/up, down) the chain starts only when the whole qkv vector is in memory and a kernel boundary later, and
+// every stage pays a boundary and a ramp.  Here
 //   workgroups [0, n_attn)   run attn_dec_body unchanged: the cache rows (keys, V slices), the rotary rows and the position are
 //                            requested in the first cycle -- they do not depend on the new token -- and only then the body's
 //                            inputs_ready hook waits for the G + 2 rows of the new token's q / k / v that THIS kv head needs
 //                            (tagged words, pcy_handover.h), staged in LDS;
 //   workgroups [n_attn, 256) hold their 4 rows of Wqkv in registers (32 KB per wave, requested right behind x), project,
-//                            store tagged; then (the first 128 of them) pull 4 rows of Wo into the same registers while the attention runs,
-//                            take the attention output (tagged) and finish with the residual epilogue.
+//                            store tagged; then (the first 128 of them) pull 4 rows of Wo into the same registers while the
+//                            attention runs -- and everyone the first 16 KB of its gate/up rows -- take the attention output
+//                            (tagged) and finish with the residual epilogue.
+// The o projection hands the residual stream over as tagged words (p.xo_tag), every workgroup -- attention ones included --
+// takes it into LDS (the second RMSNorm needs all of it: a barrier in all but name) and runs mc_mlp_body (pcy_mlp_chain.h); the
+// weight stream restarts from registers.  The kernel boundary that remains is the first RMSNorm of the next layer.
 // Attention workgroups have the lowest indices and wait only for projection workgroups, which wait for nobody before their
 // stores: no dead-lock whatever the residency.  Per-row arithmetic, accumulation order and rounding points are those of
-// gemv_stream_kernel (qkv: RMSNorm statistic summed with the stand-alone launch's `vthr` threads) and of attn_o_kernel.
-// MLP = true: the whole layer in this launch.  The o projection hands the residual stream over as tagged words (p.xo_tag) instead of
-// storing it, every workgroup -- attention ones included -- takes it into LDS (the second RMSNorm needs all of it: a barrier in
-// all but name) and runs mc_mlp_body; the projection workgroups have requested the first 16 KB of their gate/up rows while they
-// waited for the attention, so the stream restarts from registers.
-template <int DH, int G, bool MLP>
-__global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
-                                                         const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int wo_delay, int vthr_gu) {
+// gemv_stream_kernel (RMSNorm statistics summed with the stand-alone launches' thread counts) and of attn_o_kernel.
+template <int DH, int G>
+__global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
+                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int wo_delay, int vthr_gu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     };
     attn_dec_body<DH, G, 16>(a, smem, bx, kvh, 0, hook);
     AB_T(2)
-    if constexpr (MLP) {
+    {
       uint4 wa[16], wb[16];
       if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, true);   // 32 KB per wave while x is on its way
       __syncthreads();                                   // the attention's LDS is dead
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     }
   }
   // gate/up rows of the MLP while the attention runs: 16 KB per wave beside the Wo rows (both batches: 256 VGPRs and spills)
-  if constexpr (MLP) { if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false); }
+  if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false);
   // the attention output: one wave watches a 1 KB sample (192 workgroups asking for all 16 KB in a loop would load the fabric
   // while the attention workgroups are inside their latency chain), then every wave takes its share
   if (wave == 0) {
@@ -862,12 +863,11 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
     __syncthreads();
     if (wave == 0 && lane < 32) {
       const int r = (r0 & ~31) + lane;   // r0 of wave 0 is the workgroup's first row
-      if (MLP) __hip_atomic_store(p.xo_tag + r, (tag << 16) | line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else p.x_out[r] = (bf16_t)line[lane];
+      __hip_atomic_store(p.xo_tag + r, (tag << 16) | line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   AB_T(4)
-  if constexpr (MLP) {
+  {
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
@@ -878,10 +878,12 @@ __global__ __launch_bounds__(512) void attn_block_kernel(PcyDecAttnArgs a, PcyAt
 }
 
 template <int DH, int G>
-bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const unsigned* step_epoch, unsigned* xflags,
-                       const PcyMlpChainArgs* mc) {
+bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const unsigned* step_epoch,
+                         unsigned* xflags) {
   const int n_attn = (DH / 16) * a.Hkv, n_o = 256 - n_attn;
   if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 4 || a.H * DH != 8 * 512 || p.d != 4096) return false;
+  // the MLP body: same geometry conditions as pcy_launch_mlp_chain
+  if (mc.d != p.d || mc.d != 2 * 256 * 8 || mc.F != 2 * 7 * 1024) return false;
   a.o_sc1 = 0;
   const char* xe = getenv("PCY_AO_XMIN");   // key split between the slice workgroups (see launch_attn_o_rw)
   const int xmin = xe ? atoi(xe) : 768;
@@ -889,28 +891,20 @@ bool launch_attn_block(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& 
   a.xmin = xmin;
   a.unit_map = 1;
   const size_t stage_off = (attn_dec_smem_bytes(G, 16, DH, a.Tmax) + 15) & ~(size_t)15;
-  const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(p.d + a.H * DH) * 2 + 128;
+  const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(p.d + a.H * DH) * 2 + 256;
+  const size_t smem_mlp = (size_t)(2 * mc.d + mc.F) * 2 + 128;
   size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
-  if (mc) {   // the MLP body: same geometry conditions as pcy_launch_mlp_chain
-    if (mc->d != p.d || mc->d != 2 * 256 * 8 || mc->F != 2 * 7 * 1024 || mc->wqkv_next) return false;
-    const size_t smem_mlp = (size_t)(2 * mc->d + mc->F) * 2 + 128;
-    smem = smem > smem_mlp ? smem : smem_mlp;
+  smem = smem > smem_mlp ? smem : smem_mlp;
+  static size_t configured = 0;
+  if (smem > 65536 && smem > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = smem;
   }
-  static size_t configured[2] = {0, 0};
-  if (smem > 65536 && smem > configured[mc ? 1 : 0]) {
-    if (mc) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<DH, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured[mc ? 1 : 0] = smem;
-  }
-  // Wo prefetch 2 us behind the qkv stores: decode step 2.91 (no delay) -> 2.83 (2 us) -> 2.83 (4 us) -> 2.85 ms (6 us) at t = 520..780;
-  // PCY_AB_DELAY overrides, in 10 ns ticks
-  static const int wo_delay = [] { const char* e = getenv("PCY_AB_DELAY"); return e ? atoi(e) : 200; }();   // 10 ns ticks
-  if (mc)
-    hipLaunchKernelGGL((attn_block_kernel<DH, G, true>), dim3(256), dim3(512), smem, s, a, p, *mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
-                       stage_off, wo_delay, pcy_gemv_rms_threads(mc->F));
-  else
-    hipLaunchKernelGGL((attn_block_kernel<DH, G, false>), dim3(256), dim3(512), smem, s, a, p, PcyMlpChainArgs{}, n_attn, step_epoch,
-                       pcy_gemv_rms_threads(p.Nq), stage_off, wo_delay, 64);
+  // Wo prefetch 2 us behind the qkv stores: decode step 2.91 (no delay) -> 2.83 (2 us) -> 2.83 (4 us) -> 2.85 ms (6 us) at t = 520..780
+  // (measured with the MLP as a second launch)
+  constexpr int wo_delay = 200;   // 10 ns ticks
+  hipLaunchKernelGGL((decode_layer_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
+                     stage_off, wo_delay, pcy_gemv_rms_threads(mc.F));
   return true;
 }
 
@@ -1005,16 +999,16 @@ bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs
   return false;
 }
 
-// Decode attention block (see attn_block_kernel).  Returns false (nothing launched) when the shape is not covered: batch 1,
-// head_dim 128, H * dh = d = 4096, G in {1,2,4,8}, Nq = 4 rows per projection wave, 256 CUs.
-bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
-                           unsigned* xflags, const PcyMlpChainArgs* mc) {
+// One decoder layer of a batch-1 decode step (see decode_layer_kernel).  Returns false (nothing launched) when the shape is not
+// covered: batch 1, head_dim 128, H * dh = d = 4096, ffn = 14336, G in {1,2,4,8}, Nq = 4 rows per projection wave, 256 CUs.
+bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
+                             const unsigned* step_epoch, unsigned* xflags) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256) return false;
   switch (a.H / a.Hkv) {
-    case 1: return launch_attn_block<128, 1>(s, a, p, step_epoch, xflags, mc);
-    case 2: return launch_attn_block<128, 2>(s, a, p, step_epoch, xflags, mc);
-    case 4: return launch_attn_block<128, 4>(s, a, p, step_epoch, xflags, mc);
-    case 8: return launch_attn_block<128, 8>(s, a, p, step_epoch, xflags, mc);
+    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, xflags);
+    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, xflags);
+    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, xflags);
+    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, xflags);
   }
   return false;
 }

@@ -55,7 +55,7 @@ struct pcy_ctx {
   const void* mc_tags_model = nullptr;
   size_t mc_tags_words = 0;
   int mc_tags_mode = -1;
-  uint32_t* op_tags = nullptr;        // tagged vectors of pcy_decode_mlp ([ffn + d] words, its own counter)
+  uint32_t* op_tags = nullptr;        // tagged `act` vector of pcy_decode_mlp ([ffn] words, its own counter)
   size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
   int smp_hist_rows = 0;
@@ -124,34 +124,24 @@ bool attn_o_enabled() {
   const char* e = getenv("PCY_ATTN_O");
   return !e || atoi(e) != 0;
 }
-// PCY_MLP_CHAIN=0 switches the fused MLP + next-qkv launch of the batch-1 decode step off (default on): gate/up, down and the
-// next layer's qkv projection as ONE launch whose two all-to-all hand-overs hide behind the next stage's weight prefetch
-// (pcy_gemv.hip, mlp_chain_kernel).  Read on every call: tests compare both paths in one process (bit-identical).
+// PCY_MLP_CHAIN=0: pcy_decode_mlp runs the two GEMV launches instead of mlp_chain_kernel.  PCY_DECODE_LAYER=0: the batch-1 decode
+// step runs launch by launch (qkv GEMV, attention + o, gate/up, down) instead of one decode_layer_kernel per layer.  Both are
+// read on every call: tests compare the paths in one process (bit-identical).
 unsigned long long* g_mc_trace = nullptr;
 bool mlp_chain_enabled() {
   const char* e = getenv("PCY_MLP_CHAIN");
   return !e || atoi(e) != 0;
 }
-// PCY_ATTN_BLOCK=0 switches the qkv + attention + o launch of the batch-1 decode step off (default on; needs the two
-// switches above on): pcy_attn.hip, attn_block_kernel.  Read on every call, bit-identical either way.
-bool attn_block_enabled() {
-  const char* e = getenv("PCY_ATTN_BLOCK");
+bool decode_layer_enabled() {
+  const char* e = getenv("PCY_DECODE_LAYER");
   return !e || atoi(e) != 0;
 }
-// PCY_LAYER_FUSED=0: the attention block and the MLP chain as two launches per layer instead of one (default one; needs the
-// switches above on).  Read on every call, bit-identical either way.
-bool layer_fused_enabled() {
-  const char* e = getenv("PCY_LAYER_FUSED");
-  return !e || atoi(e) != 0;
-}
-int decode_mode() {
-  return (attn_o_enabled() ? 2 : 0) | (mlp_chain_enabled() ? 8 : 0) | (attn_block_enabled() ? 16 : 0) | (layer_fused_enabled() ? 32 : 0);
-}
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
-// tagged vectors of one layer: act [ffn], x after the MLP [d], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
+// tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
 size_t tag_words_per_layer(const pcy_llama_desc* m) {
-  return (size_t)m->ffn + 2 * (size_t)m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
+  return (size_t)m->ffn + (size_t)m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
 }
 
 // device words of the in-launch hand-overs; must run outside stream capture
@@ -218,17 +208,14 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   const bool batched = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
-  const bool try_mc = mlp_chain_enabled() && B == 1 && c->ao_sync && c->xwg_err && c->mc_tags;
+  bool try_layer = decode_layer_enabled() && try_ao && c->mc_tags;   // one launch per decoder layer
   if (layers_only) {
     if (try_ao) pcy_launch_bump(s, c->ao_sync);
-    if (try_mc) pcy_launch_bump(s, c->ao_sync + 1);
+    if (try_layer) pcy_launch_bump(s, c->ao_sync + 1);
   } else {
     pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
-                                try_mc ? c->ao_sync + 1 : nullptr);
+                                try_layer ? c->ao_sync + 1 : nullptr);
   }
-  bool qkv_done = false;   // the previous layer's MLP chain launch has already produced this layer's qkv
-  bool try_blk = attn_block_enabled() && try_mc && try_ao;   // qkv + attention + o in one launch (then the chain stops after down)
-  bool try_layer = try_blk && layer_fused_enabled();          // ... and the MLP in the same launch
   const size_t tag_stride = tag_words_per_layer(m);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
@@ -254,52 +241,29 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
-    uint32_t* tags = c->mc_tags ? c->mc_tags + (size_t)l * tag_stride : nullptr;
-    bool blk_done = false;
-    if (try_blk) {
+    if (try_layer) {   // the whole layer as one launch
+      uint32_t* tags = c->mc_tags + (size_t)l * tag_stride;
       PcyAttnBlockArgs bp{};
-      bp.x = x; bp.x_out = x; bp.ln1 = (const bf16_t*)L.ln1; bp.wqkv = (const bf16_t*)L.wqkv; bp.wo = (const bf16_t*)L.wo;
+      bp.x = x; bp.ln1 = (const bf16_t*)L.ln1; bp.wqkv = (const bf16_t*)L.wqkv; bp.wo = (const bf16_t*)L.wo;
       bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast;
-      bp.qkv_tag = tags + F + d; bp.ao_tag = bp.qkv_tag + qkvw; bp.xo_tag = bp.ao_tag + H * dh;
+      bp.qkv_tag = tags + F; bp.ao_tag = bp.qkv_tag + qkvw; bp.xo_tag = bp.ao_tag + H * dh;
       bp.epoch = c->ao_sync + 1; bp.err = c->xwg_err;
-      if (getenv("PCY_MC_TRACE")) {   // measurement aid: stamps of this launch behind those of the chain launches
+      if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
         if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
         bp.trace = g_mc_trace + (size_t)(128 + l) * 256 * 16;
       }
-      if (try_layer) {   // the whole layer as one launch
-        PcyMlpChainArgs mc{};
-        mc.x = x; mc.x_out = x; mc.ln2 = (const bf16_t*)L.ln2; mc.wgu = (const bf16_t*)L.wgu; mc.wdown = (const bf16_t*)L.wdown;
-        mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast;
-        mc.act_tag = tags; mc.x_tag = tags + F; mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
-        if (pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS, &mc)) continue;
-        try_layer = false;   // geometry not covered: the same for every layer
-      }
-      blk_done = pcy_launch_attn_block(s, t, bp, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS);
-      if (!blk_done) try_blk = false;
-    }
-    if (!blk_done) {
-      if (!qkv_done) pcy_launch_gemv(s, g);
-      if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
-                                         c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
-        pcy_launch_attn_decode(s, t);
-        pcy_launch_gemv(s, o);
-      }
-    }
-    qkv_done = false;
-    if (try_mc) {   // gate/up + down + the next layer's qkv in one launch
       PcyMlpChainArgs mc{};
       mc.x = x; mc.x_out = x; mc.ln2 = (const bf16_t*)L.ln2; mc.wgu = (const bf16_t*)L.wgu; mc.wdown = (const bf16_t*)L.wdown;
-      if (l + 1 < m->n_layers && !try_blk) {
-        mc.ln_next = (const bf16_t*)m->layers[l + 1].ln1; mc.wqkv_next = (const bf16_t*)m->layers[l + 1].wqkv; mc.qkv_next = qkv; mc.Nq = qkvw;
-      }
       mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast;
-      mc.act_tag = tags; mc.x_tag = tags + F;
-      mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
-      if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
-        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
-        mc.trace = g_mc_trace + (size_t)l * 256 * 16;
-      }
-      if (pcy_launch_mlp_chain(s, mc, c->n_cu)) { qkv_done = mc.wqkv_next != nullptr; continue; }
+      mc.act_tag = tags; mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
+      if (pcy_launch_decode_layer(s, t, bp, mc, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS)) continue;
+      try_layer = false;   // geometry not covered: the same for every layer
+    }
+    pcy_launch_gemv(s, g);
+    if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
+                                       c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
+      pcy_launch_attn_decode(s, t);
+      pcy_launch_gemv(s, o);
     }
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
@@ -506,7 +470,7 @@ int pcy_gemv(pcy_ctx* c, const void* W, const void* x, int ldx, const void* bias
 int pcy_decode_mlp(pcy_ctx* c, void* x, const void* ln2, const void* wgu, const void* wdown, int d, int ffn, float rms_eps, int rms_cast) {
   if (d % 8 || ffn % 8 || (size_t)d * 2 > 65536) return fail(1, "pcy_decode_mlp: d=%d ffn=%d not covered", d, ffn);
   if (int r = ensure_sync_words(c)) return r;
-  const size_t words = (size_t)ffn + d;
+  const size_t words = (size_t)ffn;
   if (c->op_tags_words != words) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->op_tags) HIP_TRY(hipFree(c->op_tags));
@@ -520,7 +484,7 @@ int pcy_decode_mlp(pcy_ctx* c, void* x, const void* ln2, const void* wgu, const 
     PcyMlpChainArgs mc{};
     mc.x = (const bf16_t*)x; mc.x_out = (bf16_t*)x; mc.ln2 = (const bf16_t*)ln2; mc.wgu = (const bf16_t*)wgu; mc.wdown = (const bf16_t*)wdown;
     mc.d = d; mc.F = ffn; mc.rms_eps = rms_eps; mc.rms_cast = rms_cast;
-    mc.act_tag = c->op_tags; mc.x_tag = c->op_tags + ffn; mc.epoch = c->ao_sync + 2; mc.err = c->xwg_err;
+    mc.act_tag = c->op_tags; mc.epoch = c->ao_sync + 2; mc.err = c->xwg_err;
     pcy_launch_bump(c->stream, c->ao_sync + 2);   // a fresh tag for every use of the slot
     if (pcy_launch_mlp_chain(c->stream, mc, c->n_cu)) return check_launch("pcy_decode_mlp");
   }

@@ -868,69 +868,35 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Batch-1 decode: gate/up + SwiGLU -> down + residual -> the NEXT layer's qkv projection as ONE launch (PcyMlpChainArgs).
+// Batch-1 decode: gate/up + SwiGLU -> down + residual as ONE launch (PcyMlpChainArgs; pcy_decode_mlp).  The body, shared with the
+// decode layer launch (pcy_attn.hip), lives in pcy_mlp_chain.h.
 //
-// As three launches each stage pays a kernel boundary (~1.7 us) and its own ramp (~3.4 us: first bytes after the launch, uneven
-// tail) on 12-42 us of streaming, and HBM idles meanwhile.  Here 256 workgroups (one per CU, 8 waves, all resident) run the
-// three stages back to back.  A stage needs the WHOLE output vector of the one before it, produced by all workgroups.
+// As two launches each stage pays a kernel boundary (~1.7 us) and its own ramp (~3.4 us: first bytes after the launch, uneven
+// tail) on 22-42 us of streaming, and HBM idles meanwhile.  Here 256 workgroups (one per CU, 8 waves, all resident) run the
+// stages back to back.  The down projection needs the WHOLE `act` vector, produced by all workgroups.
 //
-// Hand-over without flags: a producer stores every element as ONE 32-bit word {tag : bf16 value}, tag = low half of a device
-// counter that advances once per decode step, written through to memory (agent scope) and never waited for.  A consumer loads
-// the words it wants with L1-bypassing loads and accepts them when every tag is the current one, else asks again: one memory
-// round trip when the data is there, no store drain, no second trip for a flag (in-kernel stamps of the flag version: 5 us from
-// the last flag to the vector in LDS, both trips queued behind the workgroup's own weight prefetch).  Each vector lives in a
-// per-layer slot, so a word with the current tag can only have been written by THIS launch.
+// Hand-over without flags (pcy_handover.h): a producer stores every element as ONE 32-bit word {tag : bf16 value}, written
+// through to memory and never waited for; a consumer loads the words it wants with L1-bypassing loads and accepts them when
+// every tag is the current one, else asks again (in-kernel stamps of a flag version: 5 us from the last flag to the vector in
+// LDS, both trips queued behind the workgroup's own weight prefetch; flags bought nothing over three launches).
 //
 //   gate/up -> down: a wave produces its two units in slot order, so the first half of `act` is complete chip-wide when a wave
 //     is half way through its rows.  A wave that has finished its gate/up rows requests its share of the first half of act and,
 //     right behind it, the first two batches (28 KB) of its down rows; the second half of act is requested next and checked only
 //     two batches later (~9 us), by when the slowest workgroup has delivered it.  Nobody waits for the hop and the spread of
-//     the workgroups' finishing times (34-43 us) is absorbed instead of added.
-//   down -> qkv:  a true barrier (RMSNorm needs every element).  Each wave asks for its share of the tagged residual stream
-//     FIRST, then requests ALL of its qkv rows (24 KB, they depend on nothing) -- loads return in order, so the first answer is not
-//     queued behind the weights; early workgroups stream the 50 MB of Wqkv while the late ones finish.
+//     the workgroups' finishing times (even XCDs get ~7 % less bandwidth than odd ones: 34-43 us) is absorbed instead of added.
 //
 // Arithmetic per output row = gemv_stream_kernel's (same k order of the accumulation, same reduction tree, same rounding
 // points); the RMSNorm statistic is summed in the order of the stand-alone launch (`vthr` threads, block_sum_rt): bit-identical.
-__global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, int vthr_gu, int vthr_qkv) {
+__global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, int vthr_gu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int d = a.d, F = a.F;
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                      // LDS layout of mc_mlp_body: [d] | [F] | [d] | red
-  bf16_t* xr = xs + d + F;
-  float* red = reinterpret_cast<float*>(xr + d);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar branches on it)
-  const int G = gridDim.x, NW = G * MC_WV;
-  const int gw = blockIdx.x * MC_WV + wave;
+  const int tid = threadIdx.x;
   const uint32_t tag = *a.epoch & 0xffffu;
   uint4 wa[16], wb[16];
   unsigned long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
-#define MC_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
-  MC_T(0)
-  mc_mlp_body<false>(a, smem, vthr_gu, tag, G, blockIdx.x, 0, wa, wb, tr);
-  MC_T(4)
-  if (a.wqkv_next == nullptr) return;
-  // ---- stage 3: qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T.  The tagged vector is asked for first, then every row ----
-  const int units_q = (a.Nq + 2) / 3;
-  auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { const int r = u * 3 + i; return (size_t)(r < a.Nq ? r : a.Nq - 1) * d; };
-  uint4 tx[2];
-  mc_fetch_issue<2>(a.x_tag, wave * 512, lane, tx);
-  mc_prime<3, 5>(a.wqkv_next, d, lane, gw, NW, units_q, wa, wb, row_q);
-  mc_fetch_finish<2>(a.x_tag, wave * 512, lane, tag, xr, tx, a.err, 8u);
-  __syncthreads();
-  MC_T(5)
-  mc_rms_stage(xr, a.ln_next, d, vthr_qkv, a.rms_eps, a.rms_cast, xs, red, []() __attribute__((always_inline)) {});
-  MC_T(6)
-  mc_stream<3, 5>(a.wqkv_next, d, xs, lane, gw, NW, units_q, wa, wb, true, row_q, [&](int u, const float (&acc3)[3]) __attribute__((always_inline)) {
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int n = u * 3 + i;
-        if (n < a.Nq) a.qkv_next[n] = f2bf(rbf(acc3[i]));
-      }
-    }
-  }, [](int) __attribute__((always_inline)) {});
-  MC_T(7)
-#undef MC_T
+  if (tr && tid == 0) tr[0] = wall_clock64();
+  mc_mlp_body<false>(a, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 0, wa, wb, tr);
+  if (tr && tid == 0) tr[4] = wall_clock64();
 }
 
 }  // namespace
@@ -944,15 +910,13 @@ int pcy_gemv_rms_threads(int N) {
 }
 
 bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
-  // 256 workgroups, one per CU, must all be resident (every hand-over needs every workgroup's rows).  Geometry: one down unit
-  // (two rows) per wave, act halves of whole k-batches, a wave's share of a tagged vector in 4 (act) / 2 (x) loads per lane.
+  // 256 workgroups, one per CU, must all be resident (the hand-over needs every workgroup's rows).  Geometry: one down unit
+  // (two rows) per wave, act halves of whole k-batches, a wave's share of a half in 4 loads per lane.
   const int NW = GEMV_CUS * MC_WV;
   if (n_cu < GEMV_CUS || a.d != 2 * NW || a.d != MC_WV * 512 || a.F != 2 * 7 * 1024 || a.F % (2 * 512 * MC_UNB_D)) return false;
   const size_t smem = (size_t)(2 * a.d + a.F) * 2 + 128;
   if (smem > 64 * 1024) return false;
-  if (a.wqkv_next && a.Nq <= 0) return false;
-  auto vthr_of = [](int N) { return pcy_gemv_rms_threads(N); };
-  hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, vthr_of(a.F), a.wqkv_next ? vthr_of(a.Nq) : 64);
+  hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, pcy_gemv_rms_threads(a.F));
   return true;
 }
 

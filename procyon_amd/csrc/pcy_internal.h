@@ -23,17 +23,16 @@ struct PcyGemvArgs {
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 int pcy_mfma_min_batch();   // smallest batch that takes the MFMA GEMVs
 
-// Batch-1 decode: the MLP of a layer and the qkv projection of the NEXT layer in ONE launch (pcy_gemv.hip, mlp_chain_kernel):
-//   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) ;  x_out = x + act . Wdown^T ;  qkv_next = RMSNorm(x_out) * ln_next . Wqkv_next^T
-// One workgroup per CU, all resident; the vectors handed from stage to stage travel as {tag : bf16} words (no flags, no
-// drains), see the kernel.  Bit-identical to the three stand-alone GEMV launches.
+// Batch-1 decode, the MLP of a layer in ONE launch (pcy_gemv.hip, mlp_chain_kernel; the body also runs inside the decode layer launch):
+//   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) ;  x_out = x + act . Wdown^T
+// One workgroup per CU, all resident; `act` travels between the stages as {tag : bf16} words (no flags, no drains), see
+// pcy_handover.h / pcy_mlp_chain.h.  Bit-identical to the two stand-alone GEMV launches.
 struct PcyMlpChainArgs {
   const bf16_t* x; bf16_t* x_out;          // residual stream [d] (may alias)
   const bf16_t* ln2; const bf16_t* wgu;    // [d], [2F, d] gate/up interleaved in blocks of 16 rows
   const bf16_t* wdown;                     // [d, F]
-  const bf16_t* ln_next; const bf16_t* wqkv_next; bf16_t* qkv_next; int Nq;   // nullptr / 0: no projection follows (last layer)
   int d, F; float rms_eps; int rms_cast;
-  uint32_t* act_tag; uint32_t* x_tag;      // [F], [d] tagged hand-over vectors, private to THIS layer's launch
+  uint32_t* act_tag;                       // [F] tagged hand-over vector, private to THIS launch's layer
   const unsigned* epoch;                   // device word advanced once per decode step that runs these launches (tag = low 16 bits)
   unsigned* err;                           // watchdog word
   unsigned long long* trace;               // measurement aid: [grid][16] time stamps (nullptr: none)
@@ -133,29 +132,27 @@ struct PcyGemvArgs;
 bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs& o, int n_cu, const unsigned* epoch,
                        unsigned* flags, int max_flags, unsigned* err, unsigned* xflags = nullptr);
 
-// Batch-1 decode, the attention half of a layer in ONE launch (pcy_attn.hip, attn_block_kernel):
-//   qkv = RMSNorm(x) * ln1 . Wqkv^T ;  attention over the cache (+ append) ;  x_out = x + attn . Wo^T
+// Batch-1 decode, ONE launch per decoder layer (pcy_attn.hip, decode_layer_kernel):
+//   qkv = RMSNorm(x) * ln1 . Wqkv^T ;  attention over the cache (+ append) ;  x' = x + attn . Wo^T ;  x_out = x' + MLP(x')
 // Workgroups [0, n_attn) run the decode attention body (cache rows requested at once, the new token's q/k/v taken from the
 // tagged qkv vector when it arrives); the others project qkv (all their rows in registers from the first cycle), pull their Wo
-// rows while the attention runs and finish with the o projection.  Bit-identical to qkv GEMV + fused attention/o launch.
+// rows and the first gate/up rows while the attention runs and finish the o projection; then every workgroup runs the MLP
+// body (mc).  Bit-identical to the launch-per-stage step.
 struct PcyAttnBlockArgs {
-  const bf16_t* x; bf16_t* x_out;           // residual stream [d] (may alias)
+  const bf16_t* x;                          // residual stream [d] (the result goes to mc.x_out, which may alias)
   const bf16_t* ln1; const bf16_t* wqkv;    // [d], [Nq, d]
   const bf16_t* wo;                         // [d, H*dh]
   int d, Nq; float rms_eps; int rms_cast;
   uint32_t* qkv_tag; uint32_t* ao_tag;      // [Nq], [H*dh] tagged hand-over vectors, private to THIS layer's launch
-  uint32_t* xo_tag;                         // [d] the residual stream after the o projection (whole-layer launch only)
+  uint32_t* xo_tag;                         // [d] the residual stream after the o projection
   const unsigned* epoch;                    // tag counter (see pcy_handover.h)
   unsigned* err;
   unsigned long long* trace;                // measurement aid: [grid][16] time stamps (nullptr: none)
 };
 // false = geometry not covered (nothing launched).  xflags / step_epoch: key-split exchange of the attention workgroups
-// (as pcy_launch_attn_o).
-// mc != nullptr: the MLP of the layer in the same launch (x_out of `p` unused; mc->x / mc->x_out: mc->x unused, the result of
-// the layer goes to mc->x_out; mc->wqkv_next must be null).
-struct PcyMlpChainArgs;
-bool pcy_launch_attn_block(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, int n_cu, const unsigned* step_epoch,
-                           unsigned* xflags, const PcyMlpChainArgs* mc = nullptr);
+// (as pcy_launch_attn_o).  mc: the layer's MLP (mc.x unused).
+bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
+                             const unsigned* step_epoch, unsigned* xflags);
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
 int pcy_gemv_rms_threads(int N);
 

@@ -199,7 +199,6 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
       o[i] = f2bf(v);
     }
     *reinterpret_cast<uint32_t*>(a.x_out + r0) = o[0] | (o[1] << 16);
-    if (a.wqkv_next != nullptr) st8_agent(a.x_tag + r0, (tag << 16) | o[0], (tag << 16) | o[1]);
   }
 #undef MC_T
 }

@@ -241,16 +241,14 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
 
 
 @pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (40, 12, 2), (1100, 6, 2)])
-def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
-    """The batch-1 decode step as ONE launch per layer (default; PCY_LAYER_FUSED=0: two):
-      PCY_ATTN_BLOCK: qkv projection + attention + o projection (the attention workgroups request their cache rows at once and
-        take the new token's q / k / v from the tagged qkv vector when the projection workgroups deliver it);
-      PCY_MLP_CHAIN:  gate/up + SwiGLU, down + residual (and, with PCY_ATTN_BLOCK=0, the NEXT layer's qkv projection);
-    the vectors between the stages travel as {tag : bf16} words inside the launch.  Same per-row arithmetic and the same order
-    of the RMSNorm statistics as the stand-alone launches: logits, tokens, log-probabilities and the appended K/V must be
-    BIT-identical to the launch-per-stage step (both switches off), eager and under hipGraph replay, over enough steps that a
-    stale tag or a vector read too early would show -- T = 1100 also crosses into the key-split exchange of the attention
-    workgroups; the watchdog word must stay clear."""
+def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers):
+    """The batch-1 decode step runs ONE launch per decoder layer (decode_layer_kernel; PCY_DECODE_LAYER=0: launch by launch): qkv
+    projection, attention (cache rows requested before the new token's q / k / v arrive), o projection, gate/up + SwiGLU and down,
+    the vectors between the stages as {tag : bf16} words inside the launch.  Same per-row arithmetic and the same order of the
+    RMSNorm statistics as the stand-alone launches: logits, tokens, log-probabilities and the appended K/V must be BIT-identical
+    to the launch-per-stage step (with and without the fused attention + o launch), eager and under hipGraph replay, over enough
+    steps that a stale tag or a vector read too early would show -- T = 1100 also crosses into the key-split exchange of the
+    attention workgroups; the watchdog word must stay clear (Context.sync raises on it)."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
     kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
@@ -258,10 +256,9 @@ def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
-    def run(chain, block, use_graph, layer=False):
-        monkeypatch.setenv("PCY_MLP_CHAIN", "1" if chain else "0")
-        monkeypatch.setenv("PCY_ATTN_BLOCK", "1" if block else "0")
-        monkeypatch.setenv("PCY_LAYER_FUSED", "1" if layer else "0")
+    def run(layer, attn_o, use_graph):
+        monkeypatch.setenv("PCY_DECODE_LAYER", "1" if layer else "0")
+        monkeypatch.setenv("PCY_ATTN_O", "1" if attn_o else "0")
         cache = eng.new_cache(1, T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
@@ -278,11 +275,10 @@ def test_decode_fused_layer_launches_bit_identical(monkeypatch, T, N, n_layers):
                 cache.v[:, 0, :, T:T + N].cpu())
 
     ref = run(False, False, False)
-    for chain, block, use_graph, layer in ((True, False, False, False), (True, False, True, False), (True, True, False, False),
-                                           (True, True, True, False), (True, True, False, True), (True, True, True, True), (True, True, True, True)):
-        got = run(chain, block, use_graph, layer)
+    for layer, attn_o, use_graph in ((False, True, False), (True, True, False), (True, True, True), (True, True, True)):
+        got = run(layer, attn_o, use_graph)
         for x, y in zip(got, ref):
-            assert torch.equal(x, y), (chain, block, use_graph, layer)
+            assert torch.equal(x, y), (layer, attn_o, use_graph)
 
 
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
