@@ -447,10 +447,6 @@ int pcy_gemm(pcy_ctx* c, const void* A, int lda, const void* W, const void* bias
   PcyGemmArgs a{};
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = (const bf16_t*)bias; a.resid = (const bf16_t*)resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
-  if (getenv("PCY_GEMM_TRACE")) {   // measurement aid: in-kernel stamps of the 256x256 kernel, read back with pcy_debug_mc_trace
-    if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
-    a.trace = g_mc_trace;
-  }
   pcy_launch_gemm(c->stream, a);
   return check_launch("pcy_gemm");
 }

@@ -544,14 +544,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   int m0, n0;
   tile_origin<TBM, TBN>(a, tile, m0, n0);
-  unsigned long long* tr = a.trace ? a.trace + (size_t)bid * 8 : nullptr;
-  if (tr && threadIdx.x == 0) {
-    tr[0] = wall_clock64();
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    tr[4] = ((unsigned long long)xcc << 32) | hw;
-  }
 
   f32x4 acc[WTN][WTM];
 #pragma unroll
@@ -565,7 +557,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
   stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
   __syncthreads();
-  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -642,7 +633,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     }
     __syncthreads();
   }
-  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
   if constexpr (F8) {
     // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
     float sx[WTM];
@@ -674,7 +664,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     return;
   }
   gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
-  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tr[3] = wall_clock64(); }
 }
 
 // Persistent variant of gemm_kernel_big for the ESM fc1 GEMM (EPI_GELU_ESM, K = 1280: 20 k-steps per tile, so the first-stage

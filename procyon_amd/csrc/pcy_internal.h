@@ -58,7 +58,6 @@ struct PcyGemmArgs {
   // fp8 path (BASELINE configs[4]): A and W point to OCP e4m3 bytes ([M,K] lda bytes / [N,K]), K % 128 == 0;
   // C = epi( bf16-rounding chain of ((acc * sa[m]) * sw[n]) ), sa / sw = per-token / per-output-row dequantisation scales
   int fp8; const float* sa; const float* sw;
-  unsigned long long* trace;   // measurement aid (tools/bench_gemm_k.py): [tile][8] stamps, nullptr = none
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)
