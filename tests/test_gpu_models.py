@@ -281,6 +281,37 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers):
             assert torch.equal(x, y), (layer, attn_o, use_graph)
 
 
+def test_decode_layers_only_entry_runs_the_layer_launches():
+    """pcy_llama_decode_layers (the bench's roofline leg): passes over the decoder layers of a step without embedding / lm_head /
+    pick.  It must leave the step's outputs (logits, tokens, position) untouched and a following ordinary step must still match
+    a run that never called it (the tag counters advance, the slots are rewritten)."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=512))
+    torch.manual_seed(5)
+    emb = (torch.randn(1, 70, 4096) * 0.02).to(BF).cuda()
+
+    def run(with_layers_only):
+        cache = eng.new_cache(1, 96)
+        st = GenState(1, kw["vocab"], 16, "cuda")
+        logits, _ = eng.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(70)
+        eng.pick(cache, st, 1, advance_pos=False)
+        eng.greedy_steps(cache, st, 1, 3, use_graph=False)
+        before = (st.logits.clone(), st.tokens_out.clone(), int(st.pos.item()))
+        if with_layers_only:
+            eng.decode_layers(cache, st, 1, 3)
+            Context.get().sync()
+            assert torch.equal(st.logits, before[0]) and torch.equal(st.tokens_out, before[1]) and int(st.pos.item()) == before[2]
+        eng.greedy_steps(cache, st, 1, 3, use_graph=False)
+        Context.get().sync()
+        return st.logits.cpu().clone(), st.tokens_out.cpu().clone()
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
     """Batched decode (B > 4, skinny-MFMA GEMVs with K split): the finish kernel of the o / down projections also writes the
     RMSNorm that follows (PCY_FINISH_NORM, default on).  Same element assignment and reduction order as the two separate
