@@ -304,10 +304,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   }
   const bf16_t* kglob = a.k + (size_t)t0 * a.ldk + a.kcol0 + kvh * DH;
   const bf16_t* vglob = a.vt + (size_t)kvh * DH * a.vt_total + vt0;
-  auto kswz = [](int row) { return DH == 64 ? (row & 7) : (row & 15); };
-  auto vswz = [](int d) { return (d >> 2) & 3; };
+  auto kswz = [](int row) __attribute__((always_inline)) { return DH == 64 ? (row & 7) : (row & 15); };
+  auto vswz = [](int d) __attribute__((always_inline)) { return (d >> 2) & 3; };
   // cooperative global -> register fetch of key block kb0 (K part / Vt part)
-  auto fetch_k = [&](int kb0, uint4 (&r)[KLD]) {
+  // (register sets travel by value: arrays handed to the lambdas by reference ended up in scratch memory -- a load, a wait and
+  // a scratch store per prefetch, 40 of the 48 us of the single-prompt launch)
+  struct KRegs { uint4 v[KLD]; };
+  struct VRegs { uint4 v[VLD]; };
+  auto fetch_k = [&](int kb0) __attribute__((always_inline)) {
+    KRegs rr;
+    uint4 (&r)[KLD] = rr.v;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
       const int c = tid + i * 256, key = c / KCH, ch = c % KCH;
@@ -315,22 +321,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       kj = kj < len ? kj : len - 1;
       r[i] = *reinterpret_cast<const uint4*>(kglob + (size_t)kj * a.ldk + ch * 8);
     }
+    return rr;
   };
-  auto put_k = [&](char* buf, const uint4 (&r)[KLD]) {
+  auto put_k = [&](char* buf, const KRegs& rr) __attribute__((always_inline)) {
+    const uint4 (&r)[KLD] = rr.v;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
       const int c = tid + i * 256, key = c / KCH, ch = c % KCH;
       *reinterpret_cast<uint4*>(buf + (key * KCH + (ch ^ kswz(key))) * 16) = r[i];
     }
   };
-  auto fetch_v = [&](int kb0, uint4 (&r)[VLD]) {
+  const int vlast = len > 0 ? ((len - 1) / 32) * 32 : 0;   // first key of the sequence's last (32-padded) block
+  auto fetch_v = [&](int kb0) __attribute__((always_inline)) {
+    VRegs rr;
+    uint4 (&r)[VLD] = rr.v;
 #pragma unroll
     for (int i = 0; i < VLD; ++i) {
       const int c = tid + i * 256, d = c >> 2, ch = c & 3;
-      r[i] = *reinterpret_cast<const uint4*>(vglob + (size_t)d * a.vt_total + kb0 + ch * 8);
+      r[i] = *reinterpret_cast<const uint4*>(vglob + (size_t)d * a.vt_total + (kb0 < vlast ? kb0 : vlast) + ch * 8);
     }
+    return rr;
   };
-  auto put_v = [&](char* buf, const uint4 (&r)[VLD]) {
+  auto put_v = [&](char* buf, const VRegs& rr) __attribute__((always_inline)) {
+    const uint4 (&r)[VLD] = rr.v;
 #pragma unroll
     for (int i = 0; i < VLD; ++i) {
       const int c = tid + i * 256, d = c >> 2, ch = c & 3;
@@ -338,15 +351,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
   };
   const int krow_a = (fr >> 2) * 8 + (fr & 3);
-  auto kfrag = [&](const char* buf, int tile, int kb) {
+  auto kfrag = [&](const char* buf, int tile, int kb) __attribute__((always_inline)) {
     const int row = krow_a + tile * 4;
     return *reinterpret_cast<const bf16x8*>(buf + (row * KCH + ((kb * 4 + fq) ^ kswz(row))) * 16);
   };
-  auto vfrag = [&](const char* buf, int n) {
+  auto vfrag = [&](const char* buf, int n) __attribute__((always_inline)) {
     const int d = n * 16 + fr;
     return *reinterpret_cast<const bf16x8*>(buf + (d * 4 + (fq ^ vswz(d))) * 16);
   };
-  auto scores = [&](const char* kbuf, int kb0, int qt, float (&s)[8]) {
+  auto scores = [&](const char* kbuf, int kb0, int qt, float (&s)[8]) __attribute__((always_inline)) {
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // Key blocks travel global -> registers -> LDS.  A block is requested TWO iterations before it is read (two register sets
     // ka / kb_): with one iteration of look-ahead every 32-key step waited for a full L2 / HBM round trip (the matrix pipe
     // was busy 8.7 % of the time on the Llama prefill shape, PMC).
-    auto p1_step = [&](int kb0, int cur) {
+    auto p1_step = [&](int kb0, int cur) __attribute__((always_inline)) {
       const char* kbuf = smem + cur * KTILE;
       if (active) {
 #pragma unroll
@@ -409,17 +422,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       }
     };
     {
-      uint4 ka[KLD], kb_[KLD];
-      fetch_k(0, ka);
+      KRegs ka = fetch_k(0), kb_;
       lds_barrier();                         // previous readers of buffer 0 are done
       put_k(smem, ka);
-      if (32 < kend) fetch_k(32, ka);          // block 1 -> ka
+      ka = fetch_k(32);                        // block 1 -> ka
       lds_barrier();
 #define PCY_P1_STEP(NEXT, FAR)                                                          \
       {                                                                                 \
-        if (kb0 + 64 < kend) fetch_k(kb0 + 64, FAR);      /* block i+2 */               \
-        p1_step(kb0, cur);                                                              \
-        if (kb0 + 32 < kend) put_k(smem + (cur ^ 1) * KTILE, NEXT);   /* block i+1 */   \
+        FAR = fetch_k(kb0 + 64);      /* block i+2; past the end: clamped rows, never read (unconditional: a conditional */ \
+        p1_step(kb0, cur);            /* definition made the compiler merge the two register sets and wait for the load */ \
+        put_k(smem + (cur ^ 1) * KTILE, NEXT);   /* block i+1                              it had just issued) */       \
         lds_barrier();                                                                   \
         kb0 += 32; cur ^= 1;                                                            \
       }
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int n = 0; n < NT; ++n) oacc[qt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   char* kb_base = smem;
   char* vb_base = smem + 2 * KTILE;
-  auto p2_step = [&](int kb0, int cur) {
+  auto p2_step = [&](int kb0, int cur) __attribute__((always_inline)) {
     const char* kbuf = kb_base + cur * KTILE;
     const char* vbuf = vb_base + cur * VTILE;
     if (active) {
@@ -466,17 +478,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
   };
   {
-    uint4 ka[KLD], va[VLD], kb_[KLD], vb_[VLD];
-    fetch_k(0, ka); fetch_v(0, va);
+    KRegs ka = fetch_k(0), kb_;
+    VRegs va = fetch_v(0), vb_;
     lds_barrier();
     put_k(kb_base, ka); put_v(vb_base, va);
-    if (32 < kend) { fetch_k(32, ka); fetch_v(32, va); }
+    ka = fetch_k(32); va = fetch_v(32);
     lds_barrier();
 #define PCY_P2_STEP(KN, VN, KF, VF)                                                                        \
     {                                                                                                      \
-      if (kb0 + 64 < kend) { fetch_k(kb0 + 64, KF); fetch_v(kb0 + 64, VF); }                               \
+      KF = fetch_k(kb0 + 64); VF = fetch_v(kb0 + 64);                                                        \
       p2_step(kb0, cur);                                                                                   \
-      if (kb0 + 32 < kend) { put_k(kb_base + (cur ^ 1) * KTILE, KN); put_v(vb_base + (cur ^ 1) * VTILE, VN); } \
+      put_k(kb_base + (cur ^ 1) * KTILE, KN); put_v(vb_base + (cur ^ 1) * VTILE, VN);                        \
       lds_barrier();                                                                                        \
       kb0 += 32; cur ^= 1;                                                                                 \
     }
