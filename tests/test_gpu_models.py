@@ -240,26 +240,27 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
             assert torch.equal(x, y), use_graph
 
 
-@pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (40, 12, 2), (1100, 6, 2)])
-def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers):
+@pytest.mark.parametrize("T,N,n_layers,cap", [(300, 24, 3, 0), (40, 12, 2, 0), (1100, 6, 2, 0), (765, 8, 2, 4096)])
+def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
     """The batch-1 decode step runs ONE launch per decoder layer (decode_layer_kernel; PCY_DECODE_LAYER=0: launch by launch): qkv
     projection, attention (cache rows requested before the new token's q / k / v arrive), o projection, gate/up + SwiGLU and down,
     the vectors between the stages as {tag : bf16} words inside the launch.  Same per-row arithmetic and the same order of the
     RMSNorm statistics as the stand-alone launches: logits, tokens, log-probabilities and the appended K/V must be BIT-identical
     to the launch-per-stage step (with and without the fused attention + o launch), eager and under hipGraph replay, over enough
     steps that a stale tag or a vector read too early would show -- T = 1100 also crosses into the key-split exchange of the
-    attention workgroups; the watchdog word must stay clear (Context.sync raises on it)."""
+    attention workgroups, T = 765..773 walks over its threshold (768 keys) inside one run with a 4096-slot cache (the attention's
+    LDS image then exceeds 64 KB); the watchdog word must stay clear (Context.sync raises on it)."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
     kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
-    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=max(2048, cap)))
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
     def run(layer, attn_o, use_graph):
         monkeypatch.setenv("PCY_DECODE_LAYER", "1" if layer else "0")
         monkeypatch.setenv("PCY_ATTN_O", "1" if attn_o else "0")
-        cache = eng.new_cache(1, T + N + 2)
+        cache = eng.new_cache(1, cap or T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
         st.logits.copy_(logits); st.pos.fill_(T)
