@@ -669,14 +669,12 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   const int xmin = xe ? atoi(xe) : 768;
   a.xflags = (xmin > 0 && a.scratch) ? xflags : nullptr;
   a.xmin = xmin;
-  { const char* me = getenv("PCY_AO_MAP"); a.unit_map = me ? atoi(me) : 1; }
-  // timing experiments (results invalid): 1 = no wait for the attention, 2 = attention workgroups only, 3 = no attention
-  static const int dbg = [] { const char* e = getenv("PCY_AO_DBG"); return e ? atoi(e) : 0; }();
+  a.unit_map = 1;
   // The attention issues all of its cache reads (<= 1024 keys) in its first microsecond; 33.5 MB of weight reads queued at
   // the same moment delay them (attention workgroups alone 15.2 us, beside the immediate weight stream 17.9 us).  The o
   // workgroups therefore start ~5 us late: decode step 3.335 (no delay) -> 3.285 (4 us) -> 3.277 ms (8 us) at t = 512..768;
-  // 5 us still leaves the stream (~6 us) inside the shortest attention.  PCY_AO_DELAY overrides, in 10 ns ticks.
-  static const int delay = [] { const char* e = getenv("PCY_AO_DELAY"); return e ? atoi(e) : 500; }();
+  // 5 us still leaves the stream (~6 us) inside the shortest attention.
+  constexpr int dbg = 0, delay = 500;   // delay in 10 ns ticks
   const size_t smem = attn_dec_smem_bytes(G, 16, DH, a.Tmax);
   const dim3 grid(n_attn + (o.N + rw * 8 - 1) / (rw * 8)), block(512);
 #define PCY_AO_LAUNCH(RWV)                                                                                          \
@@ -922,8 +920,8 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
 
 template <int DH, int G>
 void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
-  // widest slice that still leaves >= ~1 workgroup per CU (PCY_DEC_DS overrides, for measurements)
-  static const int force = [] { const char* e = getenv("PCY_DEC_DS"); return e ? atoi(e) : 0; }();
+  // widest slice that still leaves >= ~1 workgroup per CU 
+  constexpr int force = 0;
   int ds = 16;
   if constexpr (DH == 128) {
     const int units = a.Hkv * a.B;
@@ -950,29 +948,24 @@ void launch_dec_g(hipStream_t s, const PcyDecAttnArgs& a) {
 
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
-  // q rows per block = 4 waves x QT x 16.  More q tiles per wave amortise the K / Vt fragment loads and the loop overhead
-  // (QT 2 -> 3: 343 -> 396 proteins/s for dh = 64); QT = 4 (PCY_ATTN_QT=4) needs 174 VGPRs and is slower again (372).
-  static const int var = [] { const char* e = getenv("PCY_ATTN_VAR"); return e ? atoi(e) : 0; }();
-  // var 1 = LDS-shared K/Vt tiles (attn_lds_kernel): measured equal to the register-fragment kernel (341 vs 346
-  // proteins/s) -- the kernel is not L2-bound -- so the simpler one stays the default
-  if (var == 1 && a.dh == 64) { hipLaunchKernelGGL((attn_lds_kernel<64, 3>), dim3((a.max_len + 191) / 192, a.H, a.nseq), dim3(256), 0, s, a); return; }
-  // head_dim 128 (Llama prefill): one q tile per wave leaves 16 K/Vt fragment loads of 1 KiB per 16 MFMAs to every wave of
-  // the register-fragment kernel -- L1/L2 bound (44 TFLOP/s at B = 64, T = 450).  The LDS-shared variant fetches each key
-  // block once per workgroup: Llama-3-8B pair-scoring prefill 870 -> 932 TFLOP/s (bf16), 1350 -> 1490 (fp8 weights).
-  // PCY_ATTN_VAR=2 selects the register-fragment kernel again; PCY_ATTN_LDS_QT = q tiles per wave (1 or 2).
-  if (var != 2 && a.dh == 128) {
+  // head_dim 128 (Llama prefill): the LDS-shared kernel.  One q tile per wave leaves 16 K/Vt fragment loads of 1 KiB per 16 MFMAs
+  // to every wave of the register-fragment kernel -- L1/L2 bound (44 TFLOP/s at B = 64, T = 450); fetching each key block once
+  // per workgroup: Llama-3-8B pair-scoring prefill 870 -> 932 TFLOP/s (bf16), 1350 -> 1490 (fp8 weights).
+  if (a.dh == 128) {
     // two q tiles per wave halve the K / Vt fragment reads per MFMA (the LDS pipe is the limiter at one); capped at 256
-    // VGPRs (amdgpu_waves_per_eu(2): 211 used, no spills -- uncapped the compiler took 260 and one wave per SIMD, slower):
+    // VGPRs (amdgpu_waves_per_eu(2): no spills -- uncapped the compiler took 260 and one wave per SIMD, slower):
     // 938 -> 975 TFLOP/s (bf16), 1555 -> 1664 (fp8 weights) on the pair-scoring prefill
-    static const int qt_env = [] { const char* e = getenv("PCY_ATTN_LDS_QT"); return e ? atoi(e) : 0; }();
     // ... but a small grid (one 512-token prompt: 4 x 32 workgroups of two tiles) is a latency chain per workgroup: keep one
     // tile per wave until two-tile workgroups alone fill the chip twice
     const long wg2 = (long)((a.max_len + 127) / 128) * a.H * a.nseq;
-    const int qt = qt_env ? qt_env : (wg2 >= 512 ? 2 : 1);
-    if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<128, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
+    if (wg2 >= 512) hipLaunchKernelGGL((attn_lds_kernel<128, 2>), dim3((a.max_len + 127) / 128, a.H, a.nseq), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_lds_kernel<128, 1>), dim3((a.max_len + 63) / 64, a.H, a.nseq), dim3(256), 0, s, a);
     return;
   }
+  // head_dim 64 / 32 (ESM): the register-fragment kernel (the LDS-shared one measured equal at head_dim 64, 341 vs 346 proteins/s:
+  // the kernel is VALU-issue bound, not L2 bound).  q rows per block = 4 waves x QT x 16: more q tiles per wave amortise the
+  // K / Vt fragment loads and the loop overhead (QT 2 -> 3: 343 -> 396 proteins/s; QT = 4 needs 174 VGPRs and is slower again, 372;
+  // forcing 4 waves/SIMD spills: 322)
   const bool scaled = a.scale != 1.0f;
 #define PCY_ATTN_LAUNCH(DHV, QTV, ROWS)                                                                                    \
   do {                                                                                                                      \
@@ -980,12 +973,7 @@ void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
     if (scaled) hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, true>), grid, dim3(256), 0, s, a);                         \
     else hipLaunchKernelGGL((attn_kernel<DHV, QTV, true, false>), grid, dim3(256), 0, s, a);                               \
   } while (0)
-  if (a.dh == 128) PCY_ATTN_LAUNCH(128, 1, 64);
-  else if (a.dh == 64) {
-    static const int qt64 = [] { const char* e = getenv("PCY_ATTN_QT"); return e ? atoi(e) : 3; }();
-    if (qt64 == 4) PCY_ATTN_LAUNCH(64, 4, 256);
-    else PCY_ATTN_LAUNCH(64, 3, 192);   // QT = 2: 343 vs 396 proteins/s; forcing 4 waves/SIMD (spills): 322
-  }
+  if (a.dh == 64) PCY_ATTN_LAUNCH(64, 3, 192);
   else PCY_ATTN_LAUNCH(32, 2, 128);
 #undef PCY_ATTN_LAUNCH
 }

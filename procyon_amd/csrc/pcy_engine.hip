@@ -751,7 +751,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   // Row stride of the transposed V ([Hkv*dh][vt_total]): a power-of-two stride (one 512-token prompt: 1 KB) sends the 128 rows of a
   // key block's V tile to the same few L2 channels; pad it to an odd multiple of 64 bytes
   int vt_total = B * Tp;
-  if ((getenv("PCY_VT_PAD") ? atoi(getenv("PCY_VT_PAD")) != 0 : true) && (vt_total / 32) % 2 == 0) vt_total += 32;
+  if ((vt_total / 32) % 2 == 0) vt_total += 32;
   const size_t need = align_up((size_t)M * d * 2, 256) * 2 + align_up((size_t)M * qkvw * 2, 256) + align_up((size_t)M * H * dh * 2, 256) +
                       align_up((size_t)M * F * 2, 256) + align_up((size_t)Hkv * dh * vt_total * 2, 256) +
                       align_up((size_t)(n_logit_rows + 1) * d * 2, 256) + align_up((size_t)(n_sum_rows + 1) * d * 6, 256) +
