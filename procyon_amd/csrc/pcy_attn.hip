@@ -878,10 +878,12 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
   }
   AB_T(4)
   {
+    // the Wo registers are free: the second 16 KB of this wave's gate/up rows while the residual stream is on its way
+    if (wave < 7) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, (int)gridDim.x * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d});
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
-    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 1, wa, wb, nullptr);
+    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr);
     AB_T(5)
   }
 #undef AB_T
