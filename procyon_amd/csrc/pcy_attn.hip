@@ -720,7 +720,7 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 // gemv_stream_kernel (RMSNorm statistics summed with the stand-alone launches' thread counts) and of attn_o_kernel.
 template <int DH, int G>
 __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
-                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int wo_delay, int vthr_gu) {
+                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
@@ -809,12 +809,9 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
   AB_T(1)
   // o rows [r0, r0 + 4) (the first d / 32 projection workgroups: 32 rows = ONE 128-byte line of the result per workgroup -- words
   // of a line stored one by one from several CUs took 3.6 us to become visible, a line written by one instruction ~1): into
-  // the same registers while the attention runs -- a little later, so that the attention workgroups' requests for the fresh
-  // q / k / v do not queue behind 33 MB of weight reads (the rows are needed ~12 us from now)
-  if (wo_delay > 0) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)wo_delay) __builtin_amdgcn_s_sleep(8);
-  }
+  // the same registers while the attention runs.  (While the q / k / v rows were stored word by word a 2 us pause in front of
+  // these 33 MB helped the attention workgroups' requests through -- 2.91 -> 2.83 ms/token; with one line per workgroup the
+  // pause no longer matters: 0 / 0.5 / 1 / 2 / 3 us = 2.64 / 2.63 / 2.64 / 2.65 / 2.67 ms.)
   const int r0 = gwo * 4;
   const bool active = r0 < d;                 // (workgroup-uniform: d % 32 == 0)
   uint4 wa[16], wb[16];
@@ -912,11 +909,8 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = smem;
   }
-  // Wo prefetch 2 us behind the qkv stores: decode step 2.91 (no delay) -> 2.83 (2 us) -> 2.83 (4 us) -> 2.85 ms (6 us) at t = 520..780
-  // (measured with the MLP as a second launch)
-  constexpr int wo_delay = 200;   // 10 ns ticks
   hipLaunchKernelGGL((decode_layer_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
-                     stage_off, wo_delay, pcy_gemv_rms_threads(mc.F));
+                     stage_off, pcy_gemv_rms_threads(mc.F));
   return true;
 }
 
