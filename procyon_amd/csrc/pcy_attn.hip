@@ -824,6 +824,13 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
       for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (c * 64 + lane) * 8);
       res[i] = bf2f(p.x[r]);
     }
+  } else if (wave < 7) {   // no o rows here: the SECOND 16 KB of the wave's gate/up rows wait in the Wo registers instead
+    const McRowG row_g{mc.F, mc.d};
+    const int gidx = (int)blockIdx.x * 7 + wave;
+#pragma unroll
+    for (int un = 0; un < 2; ++un)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[un * 8 + i] = ldg_nt(mc.wgu + row_g(gidx, i) + ((2 + un) * 64 + lane) * 8);
   }
   // gate/up rows of the MLP while the attention runs: 16 KB per wave beside the Wo rows (both batches: 256 VGPRs and spills)
   if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false);
@@ -876,7 +883,13 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
   AB_T(4)
   {
     // the Wo registers are free: the second 16 KB of this wave's gate/up rows while the residual stream is on its way
-    if (wave < 7) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, (int)gridDim.x * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d});
+    if (wave < 7) {
+      if (active) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, (int)gridDim.x * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d});
+      else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wb[i] = w[i];
+      }
+    }
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
