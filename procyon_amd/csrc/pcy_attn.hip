@@ -718,13 +718,15 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 // Attention workgroups have the lowest indices and wait only for projection workgroups, which wait for nobody before their
 // stores: no dead-lock whatever the residency.  Per-row arithmetic, accumulation order and rounding points are those of
 // gemv_stream_kernel (RMSNorm statistics summed with the stand-alone launches' thread counts) and of attn_o_kernel.
+// x_in_lines / x_out_lines (decode_step_kernel: all layers in one launch): the residual stream enters / leaves the layer as a
+// tagged vector with one line per producing workgroup (mc_fetch_vector_lines) instead of through p.x / mc.x_out.
 template <int DH, int G>
-__global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
-                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_attn,
+                                                  unsigned xepoch, int vthr_qkv, size_t stage_off, int vthr_gu, char* smem,
+                                                  const uint32_t* x_in_lines, uint32_t* x_out_lines, unsigned long long* tr_base) {
+  const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
-  unsigned long long* tr = p.trace ? p.trace + (size_t)blockIdx.x * 16 : nullptr;
+  unsigned long long* tr = tr_base ? tr_base + (size_t)blockIdx.x * 16 : nullptr;
 #define AB_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
   AB_T(0)
   if ((int)blockIdx.x < n_attn) {
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
     const int unit = blockIdx.x;
     const int bx = (unit / a.Hkv) % slices, kvh = unit % a.Hkv;   // kv head in the low digits: the slices of a head share an XCD's L2
     bf16_t* stage = reinterpret_cast<bf16_t*>(smem + stage_off);   // [G + 2][DH]
-    a.xepoch = *step_epoch;
+    a.xepoch = xepoch;
     a.xerr = p.err;
     a.staged = stage; a.o_tag = p.ao_tag; a.tag = tag;
     const uint32_t* qt = p.qkv_tag;
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
       bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
       mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);   // by the wave that has no gate/up rows (and nothing in flight)
       AB_T(3)
-      mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr);
+      mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines);
       AB_T(5)
     }
     return;
@@ -777,16 +779,26 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);             // [d]  RMSNorm(x) * ln1
   bf16_t* xa = xs + d;                                      // [K]  attention output
   float* red = reinterpret_cast<float*>(xa + K);
+  bf16_t* xin = reinterpret_cast<bf16_t*>(red + 64);        // [d]  the layer's input when it arrives as a tagged vector
   const int gwo = ((int)blockIdx.x - n_attn) * 8 + wave;
   uint4 w[32];
-  // qkv rows [rq0, rq0 + 4): all 32 KB of this wave requested right behind x
+  // qkv rows [rq0, rq0 + 4): all 32 KB of this wave requested right behind x (in front of the wait for a tagged x)
   const int rq0 = gwo * 4;
-  mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
+  auto load_wqkv = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + (it * 64 + lane) * 8);
-  });
+  };
+  const bf16_t* xsrc = p.x;
+  if (x_in_lines) {
+    load_wqkv();
+    mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u);
+    xsrc = xin;
+    mc_rms_stage(xin, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, []() __attribute__((always_inline)) {});
+  } else {
+    mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, load_wqkv);
+  }
   {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
       const int r = r0 + i;
 #pragma unroll
       for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (c * 64 + lane) * 8);
-      res[i] = bf2f(p.x[r]);
+      res[i] = bf2f(xsrc[r]);
     }
   } else if (wave < 7) {   // no o rows here: the SECOND 16 KB of the wave's gate/up rows wait in the Wo registers instead
     const McRowG row_g{mc.F, mc.d};
@@ -893,15 +905,48 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
-    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr);
+    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines);
     AB_T(5)
   }
 #undef AB_T
 }
 
 template <int DH, int G>
+__global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
+                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  decode_layer_body<DH, G>(a, p, mc, n_attn, *step_epoch, vthr_qkv, stage_off, vthr_gu, smem, nullptr, nullptr, p.trace);
+}
+
+// All decoder layers of a batch-1 decode step in ONE launch: workgroup b runs layer after layer; the residual stream crosses the
+// layer boundary as a tagged vector (one line per workgroup, pcy_handover.h) instead of a kernel boundary, so a workgroup that
+// has stored its down rows requests its next Wqkv rows (or cache rows) at once: no launch ramp, and the spread of the
+// workgroups' finishing times (6-8 us per layer) is absorbed by the next layer's prefetch instead of waited out.
+template <int DH, int G>
+__global__ __launch_bounds__(512) void decode_step_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, PcyDecodeStepArgs st, int n_attn,
+                                                          const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned xepoch = *step_epoch;
+  for (int l = 0; l < st.n_layers; ++l) {
+    const PcyLayerWeightsDev lw = st.layers[l];
+    p.ln1 = lw.ln1; p.wqkv = lw.wqkv; p.wo = lw.wo;
+    mc.ln2 = lw.ln2; mc.wgu = lw.wgu; mc.wdown = lw.wdown;
+    PcyDecAttnArgs al = a;
+    al.kcache = a.kcache + (size_t)l * st.kv_layer_stride; al.vcache = a.vcache + (size_t)l * st.kv_layer_stride;
+    al.xflags = a.xflags ? a.xflags + (size_t)l * st.xflags_stride : nullptr;
+    uint32_t* tags = st.tags + (size_t)l * st.tag_stride;
+    mc.act_tag = tags; p.qkv_tag = tags + mc.F; p.ao_tag = p.qkv_tag + p.Nq; p.xo_tag = p.ao_tag + a.H * DH;
+    const uint32_t* xin = l > 0 ? st.x_lines + (size_t)(l - 1) * st.x_lines_stride : nullptr;
+    uint32_t* xout = l + 1 < st.n_layers ? st.x_lines + (size_t)l * st.x_lines_stride : nullptr;
+    if (l > 0) __syncthreads();   // the previous layer's LDS is dead
+    decode_layer_body<DH, G>(al, p, mc, n_attn, xepoch, vthr_qkv, stage_off, vthr_gu, smem, xin, xout,
+                             p.trace ? p.trace + (size_t)l * 256 * 16 : nullptr);
+  }
+}
+
+template <int DH, int G>
 bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const unsigned* step_epoch,
-                         unsigned* xflags) {
+                         unsigned* xflags, const PcyDecodeStepArgs* st = nullptr) {
   const int n_attn = (DH / 16) * a.Hkv, n_o = 256 - n_attn;
   if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 4 || a.H * DH != 8 * 512 || p.d != 4096) return false;
   // the MLP body: same geometry conditions as pcy_launch_mlp_chain
@@ -913,17 +958,22 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
   a.xmin = xmin;
   a.unit_map = 1;
   const size_t stage_off = (attn_dec_smem_bytes(G, 16, DH, a.Tmax) + 15) & ~(size_t)15;
-  const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(p.d + a.H * DH) * 2 + 256;
+  const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_o = (size_t)(2 * p.d + a.H * DH) * 2 + 512;
   const size_t smem_mlp = (size_t)(2 * mc.d + mc.F) * 2 + 128;
   size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
   smem = smem > smem_mlp ? smem : smem_mlp;
-  static size_t configured = 0;
-  if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured = smem;
+  static size_t configured[2] = {0, 0};
+  if (smem > 65536 && smem > configured[st ? 1 : 0]) {
+    if (st) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_step_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured[st ? 1 : 0] = smem;
   }
-  hipLaunchKernelGGL((decode_layer_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
-                     stage_off, pcy_gemv_rms_threads(mc.F));
+  if (st)
+    hipLaunchKernelGGL((decode_step_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, *st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
+                       stage_off, pcy_gemv_rms_threads(mc.F));
+  else
+    hipLaunchKernelGGL((decode_layer_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
+                       stage_off, pcy_gemv_rms_threads(mc.F));
   return true;
 }
 
@@ -1018,6 +1068,20 @@ bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAt
     case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, xflags);
     case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, xflags);
     case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, xflags);
+  }
+  return false;
+}
+
+// All decoder layers of a batch-1 decode step in one launch (see decode_step_kernel); same coverage as pcy_launch_decode_layer.
+// a.xflags = base of the per-layer key-split flags (st.xflags_stride apart).
+bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
+                            int n_cu, const unsigned* step_epoch) {
+  if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256 || st.n_layers < 1) return false;
+  switch (a.H / a.Hkv) {
+    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, a.xflags, &st);
+    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, a.xflags, &st);
+    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, a.xflags, &st);
+    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, a.xflags, &st);
   }
   return false;
 }

@@ -110,7 +110,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
   float* sc = reinterpret_cast<float*>(smem + (G + 1) * DH * 2);       // [G][scld] scores, then probabilities
   float* red = sc + (size_t)G * scld;           // [NWV][G][DS]
   float* wred = red + NWV * G * DS;             // [NWV][G]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = pcy_tid(), lane = tid & 63, wave = tid >> 6;
   const int c0 = bx * DS;
   const int fr = lane & 15, fq = lane >> 4;
   const int t = a.t_plus1 ? a.t_plus1 - 1 : *a.pos_dev;

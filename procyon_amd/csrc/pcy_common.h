@@ -32,6 +32,13 @@ __device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16pair));
 }
 
+// threadIdx.x through an optimisation barrier: in a kernel that runs the same body once per layer (decode_step_kernel) the
+// compiler otherwise hoists every lane-derived address out of the layer loop and keeps it live (256 VGPRs + 86 spilled)
+__device__ __forceinline__ int pcy_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -55,6 +55,7 @@ struct pcy_ctx {
   const void* mc_tags_model = nullptr;
   size_t mc_tags_words = 0;
   int mc_tags_mode = -1;
+  PcyLayerWeightsDev* dev_layers = nullptr;   // device copy of the layers' weight pointers (decode_step_kernel)
   uint32_t* op_tags = nullptr;        // tagged `act` vector of pcy_decode_mlp ([ffn] words, its own counter)
   size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
@@ -136,7 +137,12 @@ bool decode_layer_enabled() {
   const char* e = getenv("PCY_DECODE_LAYER");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0); }
+// PCY_DECODE_STEP=0: one launch per decoder layer instead of one for all layers (decode_step_kernel); bit-identical
+bool decode_step_enabled() {
+  const char* e = getenv("PCY_DECODE_STEP");
+  return !e || atoi(e) != 0;
+}
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
@@ -169,7 +175,7 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
   // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
   // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
   // (a change of the launch mix as well: a slot the new mix reads may not have been rewritten for a while)
-  const size_t words = (size_t)m->n_layers * tag_words_per_layer(m);
+  const size_t words = (size_t)m->n_layers * (tag_words_per_layer(m) + 32 * 256);   // + the residual stream between the layers, one line per workgroup
   if (c->mc_tags_model != m || c->mc_tags_words != words || c->mc_tags_mode != decode_mode()) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->mc_tags) HIP_TRY(hipFree(c->mc_tags));
@@ -177,6 +183,15 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
     HIP_TRY(hipMemset(c->mc_tags, 0, words * 4));
     HIP_TRY(hipMemset(c->ao_sync + 1, 0, 4));
+    if (c->dev_layers) HIP_TRY(hipFree(c->dev_layers));
+    c->dev_layers = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dev_layers), (size_t)m->n_layers * sizeof(PcyLayerWeightsDev)));
+    std::vector<PcyLayerWeightsDev> lw(m->n_layers);
+    for (int l = 0; l < m->n_layers; ++l) {
+      const pcy_llama_layer& L = m->layers[l];
+      lw[l] = {(const bf16_t*)L.ln1, (const bf16_t*)L.wqkv, (const bf16_t*)L.wo, (const bf16_t*)L.ln2, (const bf16_t*)L.wgu, (const bf16_t*)L.wdown};
+    }
+    HIP_TRY(hipMemcpy(c->dev_layers, lw.data(), lw.size() * sizeof(PcyLayerWeightsDev), hipMemcpyHostToDevice));
     c->mc_tags_model = m; c->mc_tags_words = words; c->mc_tags_mode = decode_mode();
   }
   return 0;
@@ -218,8 +233,30 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   }
   const size_t tag_stride = tag_words_per_layer(m);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  bool step_done = false;
+  if (try_layer && decode_step_enabled() && c->dev_layers) {   // all layers in one launch
+    PcyDecAttnArgs t{};
+    t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k; t.vcache = (bf16_t*)kv->v;
+    t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
+    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
+    t.scale = 1.0f / sqrtf((float)dh);
+    t.xflags = c->ao_sync + 64 + AO_MAX_LAYERS * AO_FLAGS;
+    PcyAttnBlockArgs bp{};
+    bp.x = x; bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast; bp.epoch = c->ao_sync + 1; bp.err = c->xwg_err;
+    PcyMlpChainArgs mc{};
+    mc.x = x; mc.x_out = x; mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast; mc.epoch = c->ao_sync + 1; mc.err = c->xwg_err;
+    PcyDecodeStepArgs sa{};
+    sa.layers = c->dev_layers; sa.n_layers = m->n_layers; sa.kv_layer_stride = layer_stride;
+    sa.tags = c->mc_tags; sa.tag_stride = tag_stride; sa.xflags_stride = AO_FLAGS;
+    sa.x_lines = c->mc_tags + (size_t)m->n_layers * tag_stride; sa.x_lines_stride = 32 * 256;
+    if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode.py): in-kernel time stamps, [layer][workgroup][16]
+      if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
+      bp.trace = g_mc_trace + (size_t)128 * 256 * 16;
+    }
+    step_done = pcy_launch_decode_step(s, t, bp, mc, sa, c->n_cu, c->ao_sync);
+  }
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
-  for (int l = 0; l < m->n_layers; ++l) {
+  for (int l = 0; l < (step_done ? 0 : m->n_layers); ++l) {
     const pcy_llama_layer& L = m->layers[l];
     PcyGemvArgs g{};
     g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
@@ -411,6 +448,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->xwg_err) hipFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->mc_tags) hipFree(c->mc_tags);
+  if (c->dev_layers) hipFree(c->dev_layers);
   if (c->op_tags) hipFree(c->op_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int
 // A whole tagged vector of 8 x 512 words -> LDS: one wave watches a 1 KB sample until it is current (a workgroup then asks for
 // 1 KB per round trip instead of 16 KB while it waits), then every wave takes its 512 words.  All 512 threads; ends with a barrier.
 __device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   if (wave == watch_wave) {
     unsigned spins = 0;
     for (;;) {
@@ -65,12 +65,52 @@ __device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int 
   __syncthreads();
 }
 
+// The same for a vector stored SPARSELY: producer workgroup b owns the 128-byte line b of `src` and fills its first 16 words
+// (element 16 b + i at word 32 b + i), so that no line has two writers.  n = 16 x (number of producing workgroups) elements,
+// n % 512 == 0 and n <= 4096; dst [n] bf16.
+__device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+  const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int nlines = n >> 4;
+  auto word_of = [&](int line, int piece) __attribute__((always_inline)) { return line * 32 + piece * 4; };
+  if (wave == watch_wave) {   // the last 16 lines
+    unsigned spins = 0;
+    for (;;) {
+      const uint4 v = ld16_agent(src + word_of(nlines - 16 + (lane >> 2), lane & 3));
+      const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  if (wave * 512 < n) {   // this wave's 512 elements = 32 lines: two loads of 16 lines x 4 pieces
+    uint4 t[2];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        t[j] = ld16_agent(src + word_of(wave * 32 + j * 16 + (lane >> 2), lane & 3));
+        ok = ok && (t[j].x >> 16) == tag && (t[j].y >> 16) == tag && (t[j].z >> 16) == tag && (t[j].w >> 16) == tag;
+      }
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<uint2*>(dst + (wave * 32 + j * 16 + (lane >> 2)) * 16 + (lane & 3) * 4) =
+          make_uint2((t[j].x & 0xffffu) | (t[j].y << 16), (t[j].z & 0xffffu) | (t[j].w << 16));
+  }
+  __syncthreads();
+}
+
 // xs[0..K) = bf16( RMSNorm(x) * w ) with the statistic summed like gemv_stream_kernel launched with `vthr` threads.  x: global
 // (written before this launch) or LDS.  K <= 8 * MC_NT.  All threads; ends with a barrier.
 template <typename AfterLoads>
 __device__ __forceinline__ void mc_rms_stage(const bf16_t* x, const bf16_t* __restrict__ w, int K, int vthr, float eps, int cast,
                                              bf16_t* xs, float* red, AfterLoads after_loads) {
-  const int tid = threadIdx.x;
+  const int tid = pcy_tid();
   auto ldx = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const uint4*>(x + k); };
   // vector loads return in order: x (a few KiB, the head of the dependent chain) is requested BEFORE any weight batch
   uint4 xr[4], xv = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);

@@ -148,8 +148,21 @@ struct PcyAttnBlockArgs {
   unsigned* err;
   unsigned long long* trace;                // measurement aid: [grid][16] time stamps (nullptr: none)
 };
+// All layers in one launch (decode_step_kernel): device array of the layers' weights, per-layer strides of the cache / tag slots,
+// and the tagged vectors that carry the residual stream across the layer boundaries.
+struct PcyLayerWeightsDev { const bf16_t *ln1, *wqkv, *wo, *ln2, *wgu, *wdown; };
+struct PcyDecodeStepArgs {
+  const PcyLayerWeightsDev* layers; int n_layers;   // device memory
+  size_t kv_layer_stride;                           // elements between the K (V) caches of consecutive layers
+  uint32_t* tags; size_t tag_stride;                // per-layer hand-over slots: act [F] | qkv [Nq] | attention output [H dh] | x after o [d]
+  size_t xflags_stride;
+  uint32_t* x_lines; size_t x_lines_stride;         // [n_layers - 1][32 * 256] words: the residual stream behind layer l
+};
 // false = geometry not covered (nothing launched).  xflags / step_epoch: key-split exchange of the attention workgroups
 // (as pcy_launch_attn_o).  mc: the layer's MLP (mc.x unused).
+// p / mc: geometry and the per-step pointers (x, epoch, err); their per-layer fields are filled in by the kernel.
+bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
+                            int n_cu, const unsigned* step_epoch);
 bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
                              const unsigned* step_epoch, unsigned* xflags);
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)

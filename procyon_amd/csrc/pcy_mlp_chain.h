@@ -128,15 +128,17 @@ __device__ __forceinline__ void mc_prime_gate_up(const PcyMlpChainArgs& a, int l
 // XLDS: x is in LDS (fetched from a tagged vector by the caller) instead of global memory written before the launch.
 // primed (workgroup-uniform): bit 0 / 1 = the first / second batch of the wave's first gate/up unit is already in wa / wb
 // (mc_prime_gate_up).
+// x_out_lines != nullptr: the result is handed over as tagged words, workgroup wg's 16 rows in the first half of line wg
+// (mc_fetch_vector_lines), instead of being stored to a.x_out.
 template <bool XLDS>
 __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem, int vthr_gu, uint32_t tag, int G, int wg, int primed,
-                                            uint4 (&wa)[16], uint4 (&wb)[16], unsigned long long* tr) {
+                                            uint4 (&wa)[16], uint4 (&wb)[16], unsigned long long* tr, uint32_t* x_out_lines = nullptr) {
   const int d = a.d, F = a.F;
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* xa = xs + d;
   bf16_t* xr = xa + F;
   float* red = reinterpret_cast<float*>(xr + d);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = G * MC_WV, gw = wg * MC_WV + wave;
   uint4 tq[4];
 #define MC_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
@@ -198,7 +200,13 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
       v = rbf(v + bf2f(xin[r0 + i]));
       o[i] = f2bf(v);
     }
-    *reinterpret_cast<uint32_t*>(a.x_out + r0) = o[0] | (o[1] << 16);
+    if (x_out_lines) { red[2 * wave] = __uint_as_float(o[0]); red[2 * wave + 1] = __uint_as_float(o[1]); }
+    else *reinterpret_cast<uint32_t*>(a.x_out + r0) = o[0] | (o[1] << 16);
+  }
+  if (x_out_lines) {   // the workgroup's 16 rows as ONE 64-byte store into its own line
+    __syncthreads();
+    if (wave == 0 && lane < 16)
+      __hip_atomic_store(x_out_lines + wg * 32 + lane, (tag << 16) | __float_as_uint(red[lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #undef MC_T
 }

@@ -242,7 +242,8 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
 
 @pytest.mark.parametrize("T,N,n_layers,cap", [(300, 24, 3, 0), (40, 12, 2, 0), (1100, 6, 2, 0), (765, 8, 2, 4096)])
 def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
-    """The batch-1 decode step runs ONE launch per decoder layer (decode_layer_kernel; PCY_DECODE_LAYER=0: launch by launch): qkv
+    """The batch-1 decode step runs ALL decoder layers in one launch (decode_step_kernel; PCY_DECODE_STEP=0: one launch per layer,
+    decode_layer_kernel; PCY_DECODE_LAYER=0: launch by launch), the residual stream crossing the layer boundaries as tagged words: qkv
     projection, attention (cache rows requested before the new token's q / k / v arrive), o projection, gate/up + SwiGLU and down,
     the vectors between the stages as {tag : bf16} words inside the launch.  Same per-row arithmetic and the same order of the
     RMSNorm statistics as the stand-alone launches: logits, tokens, log-probabilities and the appended K/V must be BIT-identical
@@ -257,8 +258,9 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
-    def run(layer, attn_o, use_graph):
+    def run(layer, attn_o, use_graph, step=False):
         monkeypatch.setenv("PCY_DECODE_LAYER", "1" if layer else "0")
+        monkeypatch.setenv("PCY_DECODE_STEP", "1" if step else "0")
         monkeypatch.setenv("PCY_ATTN_O", "1" if attn_o else "0")
         cache = eng.new_cache(1, cap or T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
@@ -276,10 +278,11 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
                 cache.v[:, 0, :, T:T + N].cpu())
 
     ref = run(False, False, False)
-    for layer, attn_o, use_graph in ((False, True, False), (True, True, False), (True, True, True), (True, True, True)):
-        got = run(layer, attn_o, use_graph)
+    for layer, attn_o, use_graph, step in ((False, True, False, False), (True, True, False, False), (True, True, True, False),
+                                            (True, True, False, True), (True, True, True, True), (True, True, True, True)):
+        got = run(layer, attn_o, use_graph, step)
         for x, y in zip(got, ref):
-            assert torch.equal(x, y), (layer, attn_o, use_graph)
+            assert torch.equal(x, y), (layer, attn_o, use_graph, step)
 
 
 def test_decode_layers_only_entry_runs_the_layer_launches():

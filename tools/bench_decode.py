@@ -48,4 +48,7 @@ if os.environ.get("PCY_MC_TRACE"):
             print("  gap attention block end -> chain start: %.2f us ; chain end -> next block start: %.2f us" % (
                 (t[0, l, :, 0].min() - t[1, l, :, :5].max()) / 100.0, (t[1, l + 1, :, 0].min() - t[0, l, :, :5].max()) / 100.0))
         else:
-            print("  layer end -> next layer start: %.2f us" % ((t[1, l + 1, :, 0].min() - t[1, l, :, :6].max()) / 100.0))
+            print("  last layer end -> first next-layer start: %.2f us ; per workgroup, own layer end -> own next start: median %.2f us" % (
+                (t[1, l + 1, :, 0].min() - t[1, l, :, :6].max()) / 100.0, np.median(t[1, l + 1, :, 0] - t[1, l, :, 5]) / 100.0))
+            nx = (t[1, l + 1] - t[1, l, :, 0].min()) / 100.0
+            print("  next layer (same clock): qkv rows stored min/median/max %.2f %.2f %.2f" % (nx[64:, 1].min(), np.median(nx[64:, 1]), nx[64:, 1].max()))
