@@ -204,26 +204,31 @@ def main():
     # ---- roofline of the dominant kernel: the decode LAYER launch (qkv + attention + o + gate/up + down of one layer, one per layer per token)
     one_launch = (cfg.d == 4096 and cfg.ffn == 14336 and cfg.n_heads * cfg.head_dim == 4096 and
                   all(os.environ.get(k, "1") != "0" for k in ("PCY_DECODE_LAYER", "PCY_ATTN_O")))
+    all_layers = one_launch and os.environ.get("PCY_DECODE_STEP", "1") != "0"   # decode_step_kernel: the 32 layers in ONE launch
     t_mid = int(st.pos.item())                     # cache length of the measured launches (the timed decode ended here)
     reps = 8
     eng.decode_layers(cache, st, 1, 2)
     ctx.timer_start()
     eng.decode_layers(cache, st, 1, reps)          # reps x n_layers layer launches (+ 2 one-thread counter launches per pass)
-    k_ms = ctx.timer_stop() / (reps * cfg.n_layers)
+    k_ms = ctx.timer_stop() / (reps * (1 if all_layers else cfg.n_layers))
     qkvw = (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim
     # weight bytes of one layer per token (Wqkv, Wo, Wgu, Wdown, two norm vectors) + the cached K/V rows it reads
     k_bytes = 2 * (cfg.d * qkvw + cfg.n_heads * cfg.head_dim * cfg.d + 3 * cfg.d * cfg.ffn + 2 * cfg.d) + 2 * cfg.n_kv_heads * cfg.head_dim * 2 * t_mid
+    if all_layers:
+        k_bytes *= cfg.n_layers
     traffic, traffic_source = None, None
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_decode_layer.json")))["kernels"]
+        pname = "r02_pmc_decode_step.json" if all_layers else "r02_pmc_decode_layer.json"
+        pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
         if a.geometry == "full" and one_launch:
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
-            traffic_source = "profiles/r02_pmc_decode_layer.json (rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "decode_step_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
+            traffic_source = f"profiles/{pname} (rocprofv3 --pmc passes at t = 512..536, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": ("decode_layer_kernel<128,4> (one Llama decoder layer per launch: qkv, attention, o, gate/up, down; 32 launches/token)"
+    roofline = {"bound": "hbm", "kernel": ("decode_step_kernel<128,4> (all 32 Llama decoder layers of a decode step in one launch: per layer qkv, attention, o, gate/up, down)"
+                                           if all_layers else "decode_layer_kernel<128,4> (one Llama decoder layer per launch; 32 launches/token)"
                                            if one_launch else "decoder layer as separate launches (average per layer)"),
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
