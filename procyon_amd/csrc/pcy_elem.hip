@@ -509,19 +509,74 @@ __device__ __forceinline__ int block_excl_scan_i(int v, int* lds) {
   return base + inc - v;
 }
 
-// one workgroup per row.  hist: [B][65536] uint32 scratch, all zero on entry and on exit (nucleus only); probs_out optional [B,V]
+// bf16( softmax_fp32( logits / temperature ) ) of every token as bits ([B][V] uint16; >= +0, so the bits order like the values)
+// and, for the nucleus mask, the histogram over those bits: grid (PICK_NB, B) -- the 128k exponentials and divisions of a row
+// on 64 CUs instead of the one that runs the selection.
+__global__ __launch_bounds__(PICK_NT) void sample_probs_kernel(const bf16_t* __restrict__ logits, int V, const float4* __restrict__ part,
+                                                               float temperature, int nucleus, unsigned* __restrict__ hist,
+                                                               bf16_t* __restrict__ pbits) {
+  __shared__ float s_ml[2];
+  const int b = blockIdx.y, c = blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {   // merge the chunk partials (as sample_stage2_kernel does)
+    const float4 pp = part[b * PICK_NB + lane];
+    const float ms = wave_max(pp.z);
+    const float ss = wave_sum(pp.w * expf(pp.z - ms));
+    if (lane == 0) { s_ml[0] = ms; s_ml[1] = ss; }
+  }
+  __syncthreads();
+  const float m_s = s_ml[0], l_s = s_ml[1];
+  const int chunk = (V + PICK_NB - 1) / PICK_NB;
+  const int lo = c * chunk, hi = (lo + chunk) < V ? (lo + chunk) : V;
+  const bf16_t* lg = logits + (size_t)b * V;
+  const bool scaled = temperature != 1.0f;
+  unsigned* hrow = hist + (size_t)b * 65536;
+  for (int i = lo + threadIdx.x; i < hi; i += PICK_NT) {
+    const float v = bf2f(lg[i]);
+    const bf16_t pb = f2bf(expf((scaled ? rbf(v / temperature) : v) - m_s) / l_s);
+    pbits[(size_t)b * V + i] = pb;
+    if (nucleus) atomicAdd(&hrow[pb], 1u);
+  }
+}
+
+// wave-wide sum with four DPP row rotations + two cross-row exchanges (every lane gets the total)
+template <int CTRL>
+__device__ __forceinline__ float smp_dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float smp_wave_sum(float v) {
+  v = smp_dpp_add<0x128>(v); v = smp_dpp_add<0x124>(v); v = smp_dpp_add<0x122>(v); v = smp_dpp_add<0x121>(v);   // row_ror 8, 4, 2, 1
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// wave-wide inclusive prefix sum in lane order
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  return v;
+}
+
+// one workgroup per row.  hist: [B][65536] uint32 scratch, all zero on entry and on exit (nucleus only); probs_out optional [B,V].
+// Wave w owns the K * 64 consecutive vocabulary indices from w * K * 64 (K = ceil(V / 1024)); lane l handles index
+// base + k * 64 + l, k < K: every load is a coalesced 128-byte row, the probability bits of a lane's <= 128 elements stay
+// packed in 64 registers for all passes, and index order = (wave, k, lane) order, so ranks and the CDF are wave scans plus
+// one exchange of 16 per-wave totals.  (First version: a contiguous run of V / 1024 indices per THREAD -- 2-byte loads 252
+// bytes apart, three passes each recomputing exp and division: 60 us per sampling step, 290 with the nucleus mask.)
+constexpr int SMP_KMAX = 128;   // V <= SMP_NT * SMP_KMAX
 __global__ __launch_bounds__(SMP_NT) void sample_stage2_kernel(const bf16_t* __restrict__ logits, int V, const float4* __restrict__ part,
                                                                float temperature, float nucleus_p, const float* __restrict__ uniforms,
                                                                unsigned* __restrict__ hist, bf16_t* __restrict__ probs_out,
                                                                int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, int max_steps,
-                                                               float* __restrict__ logprob, const int32_t* __restrict__ step_dev, int B) {
-  __shared__ float fl[SMP_NT / 64];
-  __shared__ int il[SMP_NT / 64];
+                                                               float* __restrict__ logprob, const int32_t* __restrict__ step_dev, int B,
+                                                               const bf16_t* __restrict__ pbits) {
+  constexpr int NWV = SMP_NT / 64;
+  __shared__ float fl[NWV];
+  __shared__ int il[NWV];
   __shared__ float s_stat[4];
   __shared__ int s_first, s_kstar, s_jstar, s_tok, s_last;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* lg = logits + (size_t)b * V;
-  const bool scaled = temperature != 1.0f;
   const int step = *step_dev;
   if (tid < 64) {   // merge the chunk partials
     const float4 pp = part[b * PICK_NB + lane];
@@ -531,81 +586,147 @@ __global__ __launch_bounds__(SMP_NT) void sample_stage2_kernel(const bf16_t* __r
   }
   if (tid == 0) { s_first = 0x7fffffff; s_kstar = -1; s_jstar = 0; s_tok = -1; s_last = -1; }
   __syncthreads();
-  const float m_raw = s_stat[0], l_raw = s_stat[1], m_s = s_stat[2], l_s = s_stat[3];
-  auto prob_bits = [&](int i) -> int {   // bf16( softmax_fp32( logits / temperature ) ): >= +0, so the bits order like the values
-    const float v = bf2f(lg[i]);
-    return (int)f2bf(expf((scaled ? rbf(v / temperature) : v) - m_s) / l_s);
-  };
+  const float m_raw = s_stat[0], l_raw = s_stat[1];
+  const int K = (V + SMP_NT - 1) / SMP_NT;
+  const int wbase = wave * K * 64;
+  // the probability bits of this lane's elements (sample_probs_kernel)
+  const bf16_t* pbrow = pbits + (size_t)b * V;
+  unsigned pk[SMP_KMAX / 2];
+#pragma unroll
+  for (int kk = 0; kk < SMP_KMAX / 2; ++kk) {
+    unsigned w = 0;
+    if (2 * kk < K) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = wbase + (2 * kk + e) * 64 + lane;
+        if (2 * kk + e < K && i < V) w |= (unsigned)pbrow[i] << (16 * e);
+      }
+    }
+    pk[kk] = w;
+  }
+#define SMP_PB(k) ((int)((pk[(k) >> 1] >> (((k) & 1) * 16)) & 0xffffu))
   const bool nucleus = nucleus_p > 0.f;
   unsigned* hrow = hist + (size_t)b * 65536;
-  if (nucleus) {
-    for (int i = tid; i < V; i += SMP_NT) atomicAdd(&hrow[prob_bits(i)], 1u);
-    __threadfence();
+  if (nucleus) {   // (the histogram was filled by sample_probs_kernel)
+    // ascending cumulative sum over the 65536 values: wave w owns the values [4096 w, 4096 w + 4096), lane l value 4096 w + 64 k + l
+    const int vbase = wave * 4096;
+    float wsum = 0.f;
+    for (int k = 0; k < 64; ++k) {
+      const int val = vbase + k * 64 + lane;
+      const unsigned c = __hip_atomic_load(&hrow[val], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wsum += (float)c * bf2f((bf16_t)val);
+    }
+    wsum = wave_sum(wsum);
     __syncthreads();
-    // ascending cumulative sum over values: thread t owns the 64 values [64 t, 64 t + 64)
-    unsigned cnt[64];
-    float mine = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) { cnt[k] = __hip_atomic_load(&hrow[tid * 64 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mine += (float)cnt[k] * bf2f((bf16_t)(tid * 64 + k)); }
-    float total;
-    float run = block_excl_scan(mine, fl, &total);
+    if (lane == 0) fl[wave] = wsum;
+    __syncthreads();
+    float run = 0.f;
+    for (int i = 0; i < wave; ++i) run += fl[i];
     const float thr = 1.0f - nucleus_p;
     // the first element (ascending order) whose cumulative sum, as a bf16 value, has reached the threshold
     int my_k = -1, my_j = 0;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) {
-      if (my_k < 0 && cnt[k]) {
-        const float v = bf2f((bf16_t)(tid * 64 + k));
-        if (rbf(run + (float)cnt[k] * v) >= thr) {
-          int j = 1;
-          while (j < (int)cnt[k] && rbf(run + (float)j * v) < thr) ++j;
-          my_k = tid * 64 + k; my_j = j;
+    for (int k = 0; k < 64 && my_k < 0; ++k) {
+      const int val = vbase + k * 64 + lane;
+      const unsigned c = __hip_atomic_load(&hrow[val], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float v = bf2f((bf16_t)val);
+      const float mine = (float)c * v;
+      const float csum = smp_wave_sum(mine);
+      if (rbf(run + csum) >= thr || run + csum >= thr) {   // (wave-uniform) the threshold may fall inside these 64 values: scan them
+        const float incl = wave_incl_scan(mine, lane);
+        const float before = run + (incl - mine);
+        const bool hit = c != 0u && rbf(before + mine) >= thr;
+        const unsigned long long hm = __ballot(hit);
+        if (hm) {   // the lowest lane that reached it owns the threshold run
+          const int fl_lane = __ffsll((long long)hm) - 1;
+          if (lane == fl_lane) {
+            int j = 1;
+            while (j < (int)c && rbf(before + (float)j * v) < thr) ++j;
+            my_k = val; my_j = j;
+          }
+          my_k = __shfl(my_k, fl_lane, 64); my_j = __shfl(my_j, fl_lane, 64);
         }
       }
-      run += (float)cnt[k] * bf2f((bf16_t)(tid * 64 + k));
+      run += csum;
     }
-    if (my_k >= 0) atomicMin(&s_first, tid);
+    if (my_k >= 0 && lane == 0) atomicMin(&s_first, wave);
     __syncthreads();
-    if (tid == s_first) { s_kstar = my_k; s_jstar = my_j; }
+    if (wave == s_first && lane == 0) { s_kstar = my_k; s_jstar = my_j; }
     // leave the histogram zeroed for the next call
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) if (cnt[k]) hrow[tid * 64 + k] = 0u;
+    for (int k = 0; k < 64; ++k) hrow[vbase + k * 64 + lane] = 0u;
     __syncthreads();
   }
   const int kstar = nucleus ? s_kstar : -1, jstar = s_jstar;   // kstar < 0: keep everything (no nucleus, or nothing reached 1 - p)
-  // every thread owns a contiguous run of the vocabulary: index-order ranks inside the threshold run, then the masked CDF
-  const int seg = (V + SMP_NT - 1) / SMP_NT;
-  const int lo = tid * seg, hi = (lo + seg) < V ? (lo + seg) : V;
-  int ties = 0;
-  if (kstar >= 0)
-    for (int i = lo; i < hi; ++i) ties += prob_bits(i) == kstar;
-  int rank = (kstar >= 0 ? block_excl_scan_i(ties, il) : 0) + 1;   // rank (1-based, index order) of this thread's first tie
-  float segsum = 0.f;
-  int r = rank, last_kept = -1;
-  for (int i = lo; i < hi; ++i) {
-    const int pb = prob_bits(i);
-    bool keep = true;
-    if (kstar >= 0) { keep = pb > kstar || (pb == kstar && r >= jstar); r += pb == kstar; }
-    const float pv = keep ? bf2f((bf16_t)pb) : 0.f;
-    if (probs_out) probs_out[(size_t)b * V + i] = f2bf(pv);
-    if (pv > 0.f) last_kept = i;
-    segsum += pv;
+  // index-order ranks inside the threshold run: ties of this wave, then the exclusive prefix over the waves
+  int wties = 0;
+  if (kstar >= 0) {
+#pragma unroll
+    for (int k = 0; k < SMP_KMAX; ++k)
+      if (k < K) wties += __popcll(__ballot(SMP_PB(k) == kstar && wbase + k * 64 + lane < V));
+    __syncthreads();
+    if (lane == 0) il[wave] = wties;
+    __syncthreads();
   }
-  float total;
-  const float excl = block_excl_scan(segsum, fl, &total);
-  const float target = uniforms[(size_t)step * B + b] * total;
-  if (last_kept >= 0) atomicMax(&s_last, last_kept);
-  if (target >= excl && target < excl + segsum) {   // this thread's run holds the draw
-    float cum = excl;
-    int r2 = rank, tok = -1;
-    for (int i = lo; i < hi && tok < 0; ++i) {
-      const int pb = prob_bits(i);
-      bool keep = true;
-      if (kstar >= 0) { keep = pb > kstar || (pb == kstar && r2 >= jstar); r2 += pb == kstar; }
-      if (keep) { cum += bf2f((bf16_t)pb); if (cum > target) tok = i; }
+  int rank0 = 1;   // rank (1-based, index order) of the first tie of this wave
+  if (kstar >= 0) for (int i = 0; i < wave; ++i) rank0 += il[i];
+  // the masked probabilities (pk is overwritten with them: 0 where masked) and the wave's sum
+  float wsum = 0.f;
+  int last_kept = -1;
+  {
+    int r = rank0;
+#pragma unroll
+    for (int kk = 0; kk < SMP_KMAX / 2; ++kk) {
+      unsigned w = pk[kk], wn = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * kk + e;
+        if (k < K) {
+          const int i = wbase + k * 64 + lane;
+          const int pb = (int)((w >> (16 * e)) & 0xffffu);
+          bool keep = i < V;
+          if (kstar >= 0) {
+            const bool tie = pb == kstar && i < V;
+            const unsigned long long tm = __ballot(tie);
+            const int myrank = r + __popcll(tm & ((1ull << lane) - 1ull));
+            keep = keep && (pb > kstar || (tie && myrank >= jstar));
+            r += __popcll(tm);
+          }
+          const int kept = keep ? pb : 0;
+          wn |= (unsigned)kept << (16 * e);
+          const float pv = bf2f((bf16_t)kept);
+          if (probs_out && i < V) probs_out[(size_t)b * V + i] = (bf16_t)kept;
+          if (pv > 0.f) last_kept = i;
+          wsum += pv;
+        }
+      }
+      pk[kk] = wn;
     }
-    if (tok < 0) tok = last_kept;      // rounding at the end of the run
-    atomicMax(&s_tok, tok);
+  }
+  wsum = wave_sum(wsum);
+  last_kept = (int)wave_max((float)last_kept);   // indices < 2^24: exact in fp32
+  __syncthreads();
+  if (lane == 0) { fl[wave] = wsum; if (last_kept >= 0) atomicMax(&s_last, last_kept); }
+  __syncthreads();
+  float excl = 0.f, total = 0.f;
+  for (int i = 0; i < NWV; ++i) { const float x = fl[i]; if (i < wave) excl += x; total += x; }
+  const float target = uniforms[(size_t)step * B + b] * total;
+  if (target >= excl && target < excl + wsum) {   // (wave-uniform) this wave's range holds the draw
+    float cum = excl;
+    int tok = -1;
+#pragma unroll
+    for (int k = 0; k < SMP_KMAX; ++k) {
+      if (k < K && tok < 0) {
+        const float pv = bf2f((bf16_t)SMP_PB(k));
+        const float csum = smp_wave_sum(pv);
+        if (cum + csum > target) {   // (wave-uniform) the draw may fall inside these 64 tokens: scan them
+          const float incl = wave_incl_scan(pv, lane);
+          const unsigned long long hm = __ballot(pv > 0.f && cum + incl > target);
+          if (hm) tok = wbase + k * 64 + (__ffsll((long long)hm) - 1);
+        }
+        cum += csum;
+      }
+    }
+    if (tok < 0) tok = last_kept;      // rounding at the end of the range
+    if (lane == 0) atomicMax(&s_tok, tok);
   }
   __syncthreads();
   if (tid == 0) {
@@ -616,6 +737,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_stage2_kernel(const bf16_t* __r
     next_tok[b] = tok;
     tokens_out[(size_t)b * max_steps + step] = tok;
   }
+#undef SMP_PB
 }
 // after every row has read *step_dev
 __global__ void sample_advance_kernel(int32_t* pos_dev, int32_t* step_dev, int advance_pos) {
@@ -1129,10 +1251,12 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 }
 void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
                             unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
-                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials) {
+                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials, bf16_t* pbits) {
   hipLaunchKernelGGL(sample_stage1_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, temperature, reinterpret_cast<float4*>(partials));
+  hipLaunchKernelGGL(sample_probs_kernel, dim3(PICK_NB, B), dim3(PICK_NT), 0, s, logits, V, reinterpret_cast<const float4*>(partials), temperature,
+                     nucleus_p > 0.f ? 1 : 0, hist, pbits);
   hipLaunchKernelGGL(sample_stage2_kernel, dim3(B), dim3(SMP_NT), 0, s, logits, V, reinterpret_cast<const float4*>(partials), temperature,
-                     nucleus_p, uniforms, hist, probs_out, next_tok, tokens_out, max_steps, logprob, step_dev, B);
+                     nucleus_p, uniforms, hist, probs_out, next_tok, tokens_out, max_steps, logprob, step_dev, B, pbits);
   hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(64), 0, s, pos_dev, step_dev, advance_pos);
 }
 void pcy_launch_copy_rows(hipStream_t s, const bf16_t* src, int lds_, bf16_t* dst, int ldd, const int32_t* rows, int nrows, int d) {

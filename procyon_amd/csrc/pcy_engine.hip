@@ -60,6 +60,8 @@ struct pcy_ctx {
   size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
   int smp_hist_rows = 0;
+  bf16_t* smp_pbits = nullptr;        // [rows][vocab] bits of the probabilities of the sampling step
+  size_t smp_pbits_elems = 0;
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
   size_t beam_ws_bytes = 0;
 
@@ -382,9 +384,14 @@ void enqueue_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st
   cv.take<bf16_t>((size_t)B * m->ffn); cv.take<float>((size_t)B * m->n_heads * (Tmax + 1));
   void* partials = cv.take<char>((size_t)B * 64 * 16);
   pcy_launch_sample_step(s, (const bf16_t*)st->logits, B, m->vocab, temperature, nucleus_p, uniforms, c->smp_hist, probs_out, st->next_tok,
-                         st->tokens_out, st->max_steps, st->logprob, st->pos, st->step, advance_pos, partials);
+                         st->tokens_out, st->max_steps, st->logprob, st->pos, st->step, advance_pos, partials, c->smp_pbits);
 }
-int ensure_sample_state(pcy_ctx* c, int B) {
+int ensure_sample_state(pcy_ctx* c, int B, int V) {
+  if ((size_t)B * V > c->smp_pbits_elems) {
+    if (c->smp_pbits) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->smp_pbits)); c->smp_pbits = nullptr; c->smp_pbits_elems = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->smp_pbits), (size_t)B * V * 2));
+    c->smp_pbits_elems = (size_t)B * V;
+  }
   if (B <= c->smp_hist_rows) return 0;
   if (c->smp_hist) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->smp_hist)); c->smp_hist = nullptr; }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->smp_hist), (size_t)B * 65536 * sizeof(unsigned)));
@@ -452,6 +459,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->op_tags) hipFree(c->op_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);
+  if (c->smp_pbits) hipFree(c->smp_pbits);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->cap_stream) hipStreamDestroy(c->cap_stream);
@@ -972,7 +980,7 @@ int pcy_sample_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   if (nucleus_prob >= 1.f) return fail(1, "pcy_sample_pick: nucleus_prob must be < 1 (<= 0 switches the nucleus mask off)");
   if (m->vocab > 65536 * 4) return fail(1, "pcy_sample_pick: vocabulary %d unsupported", m->vocab);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_sample_state(c, B)) return r;
+  if (int r = ensure_sample_state(c, B, m->vocab)) return r;
   enqueue_sample(c, m, st, B, advance_pos, kv->Tmax, temperature, nucleus_prob, uniforms, (bf16_t*)probs_out);
   return check_launch("pcy_sample_pick");
 }
@@ -983,7 +991,7 @@ int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (!(temperature > 0.f) || nucleus_prob >= 1.f) return fail(1, "pcy_llama_sample: temperature > 0 and nucleus_prob < 1 required");
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
-  if (int r = ensure_sample_state(c, B)) return r;
+  if (int r = ensure_sample_state(c, B, m->vocab)) return r;
   for (int i = 0; i < n_steps; ++i) {
     enqueue_decode(c, m, kv, st, B);
     enqueue_sample(c, m, st, B, 1, kv->Tmax, temperature, nucleus_prob, uniforms, nullptr);

@@ -183,7 +183,8 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 // partials: B * 64 * 16 bytes; probs_out: optional [B,V] record of the pre-sampling probability vector
 void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
                             unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
-                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials);
+                            int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials /* 64 x float4 per row */,
+                            bf16_t* pbits /* [B][V] scratch: the probabilities' bits */);
 // device-side state of the diverse beam search (pcy_beam_step); every pointer is device memory, BB = B * beam rows
 struct PcyBeamState {
   int32_t* out; int32_t max_len;   // [2][BB][max_len] token histories, buffer (step & 1) is current
