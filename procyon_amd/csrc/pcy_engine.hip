@@ -102,8 +102,11 @@ int check_launch(const char* what) {
 }
 
 // GEMM for any M: MFMA tiles when M is large enough to fill them, the streaming GEMV otherwise
+// next_w / next_xn / fused (optional): RMSNorm(C) * next_w -> next_xn inside the projection's finish launch where that exists
+// (*fused = 1), see PcyGemmArgs
 void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16_t* bias, const bf16_t* resid, int ldr,
-            bf16_t* C, int ldc, int M, int N, int K, int epi, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0) {
+            bf16_t* C, int ldc, int M, int N, int K, int epi, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0,
+            const bf16_t* next_w = nullptr, bf16_t* next_xn = nullptr, int* fused = nullptr, float rms_eps = 0.f, int rms_cast = 0) {
   if (M <= 8 && epi != EPI_SWIGLU && (resid == nullptr || ldr == ldc)) {
     PcyGemvArgs g{};
     g.W = W; g.x = A; g.y = C; g.bias = bias; g.resid = resid; g.rms_w = nullptr;
@@ -115,6 +118,7 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
   a.splitk_ws = splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+  a.next_rms_w = next_w; a.next_xn = next_xn; a.fused_next = fused; a.rms_eps = rms_eps; a.rms_cast = rms_cast;
   pcy_launch_gemm(s, a);
 }
 
@@ -840,13 +844,15 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
   // hidden_states = (embeddings, output of layers 0..L-2, final-normed output of layer L-1)  [HF LlamaModel.forward]
   pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 1);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
+  int xn_ready = 0;   // xn = RMSNorm(x) of the next projection already written by a K-split finish launch
   for (int l = 0; l < m->n_layers; ++l) {
     const pcy_llama_layer& L = m->layers[l];
     const pcy_llama_layer_fp8* L8 = m->layers_fp8 ? &m->layers_fp8[l] : nullptr;
     if (L8) {
       linear8(x, d, L8->wqkv, L8->sqkv, nullptr, qkv, qkvw, qkvw, EPI_STORE, (const bf16_t*)L.ln1);
     } else {
-      pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
+      if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, M, d, m->rms_eps, m->rms_cast);
+      xn_ready = 0;
       linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
     }
     pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
@@ -859,8 +865,10 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     t.causal = 1; t.scale = 1.0f / sqrtf((float)dh);
     pcy_launch_attn(s, t);
     if (L8) linear8(ao, H * dh, L8->wo, L8->so, x, x, d, d, EPI_RESID);
-    else linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes);
-    if (!L8) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
+    else linear(s, ao, H * dh, (const bf16_t*)L.wo, nullptr, x, d, x, d, M, d, H * dh, EPI_RESID, sk_ws, sk_bytes,
+                (const bf16_t*)L.ln2, xn, &xn_ready, m->rms_eps, m->rms_cast);   // (M <= 1024: the K-split finish also writes RMSNorm(x) * ln2)
+    if (!L8 && !xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, M, d, m->rms_eps, m->rms_cast);
+    xn_ready = 0;
     if (L8) {
       linear8(x, d, L8->wgu, L8->sgu, nullptr, act, F, 2 * F, EPI_SWIGLU, (const bf16_t*)L.ln2);
       linear8(act, F, L8->wdown, L8->sdown, x, x, d, d, EPI_RESID);
@@ -874,7 +882,10 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     } else {
       linear(s, xn, d, (const bf16_t*)L.wgu, nullptr, nullptr, 0, act, F, M, 2 * F, d, EPI_SWIGLU);
     }
-    linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID, sk_ws, sk_bytes);
+    if (l + 1 < m->n_layers && !m->layers_fp8)   // ... and the next layer's input norm
+      linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID, sk_ws, sk_bytes,
+             (const bf16_t*)m->layers[l + 1].ln1, xn, &xn_ready, m->rms_eps, m->rms_cast);
+    else linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID, sk_ws, sk_bytes);
     if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
   }
   if (hidden_out) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, (bf16_t*)hidden_out, M, d, m->rms_eps, m->rms_cast);

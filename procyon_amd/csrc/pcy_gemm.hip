@@ -911,6 +911,14 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_SPLITK];
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
+      // residual epilogue + the RMSNorm that follows in ONE finish launch (one workgroup per row) where the caller asks for it
+      const char* fn_env = getenv("PCY_FINISH_NORM");   // read per call: tests compare both paths in one process
+      if (a.epi == EPI_RESID && a.next_rms_w && a.next_xn && a.fused_next && a.bias == nullptr && a.ldc == a.N && a.ldr == a.N &&
+          !(fn_env && atoi(fn_env) == 0) &&
+          pcy_launch_splitk_finish_norm(s, a.splitk_ws, splits, a.M, a.N, a.resid, a.C, a.next_rms_w, a.next_xn, a.rms_eps, a.rms_cast)) {
+        *a.fused_next = 1;
+        return;
+      }
       if (a.epi == EPI_RESID) hipLaunchKernelGGL(gemm_splitk_epilogue<EPI_RESID>, dim3(eb < 2048 ? eb : 2048), dim3(256), 0, s, a, splits);
       else hipLaunchKernelGGL(gemm_splitk_epilogue<EPI_STORE>, dim3(eb < 2048 ? eb : 2048), dim3(256), 0, s, a, splits);
       return;

@@ -901,6 +901,16 @@ __global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, 
 
 }  // namespace
 
+bool pcy_launch_splitk_finish_norm(hipStream_t s, const float* ws, int splits, int rows, int N, const bf16_t* resid, bf16_t* y,
+                                   const bf16_t* next_rms_w, bf16_t* next_xn, float rms_eps, int rms_cast) {
+  if (N % 8 || N > 8192 || rows <= 0 || splits < 1) return false;
+  PcyGemvArgs a{};
+  a.splitk_ws = const_cast<float*>(ws); a.B = rows; a.N = N; a.resid = resid; a.y = y; a.ldy = N;
+  a.next_rms_w = next_rms_w; a.next_xn = next_xn; a.rms_eps = rms_eps; a.rms_cast = rms_cast;
+  hipLaunchKernelGGL(gemv_splitk_finish_norm_kernel, dim3(rows), dim3(256), 0, s, a, splits);
+  return true;
+}
+
 // threads of the stand-alone RMS-fused launch (launch_nb / pick_grid) for N output rows: the order of its statistic
 int pcy_gemv_rms_threads(int N) {
   const int R = ((N + 3) / 4 < GEMV_MAX_WAVES) ? 2 : 4;

@@ -21,7 +21,11 @@ struct PcyGemvArgs {
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
-int pcy_mfma_min_batch();   // smallest batch that takes the MFMA GEMVs
+int pcy_mfma_min_batch();
+// finish of a K-split projection with the residual epilogue + RMSNorm of the result (gemv_splitk_finish_norm_kernel): partial sums
+// ws [splits][rows][N] fp32; y = bf16(bf16(sum) + resid) (ldy == N), xn = RMSNorm(y) * w.  false = shape not covered.
+bool pcy_launch_splitk_finish_norm(hipStream_t s, const float* ws, int splits, int rows, int N, const bf16_t* resid, bf16_t* y,
+                                   const bf16_t* next_rms_w, bf16_t* next_xn, float rms_eps, int rms_cast);   // smallest batch that takes the MFMA GEMVs
 
 // Batch-1 decode, the MLP of a layer in ONE launch (pcy_gemv.hip, mlp_chain_kernel; the body also runs inside the decode layer launch):
 //   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) ;  x_out = x + act . Wdown^T
@@ -58,6 +62,9 @@ struct PcyGemmArgs {
   // fp8 path (BASELINE configs[4]): A and W point to OCP e4m3 bytes ([M,K] lda bytes / [N,K]), K % 128 == 0;
   // C = epi( bf16-rounding chain of ((acc * sa[m]) * sw[n]) ), sa / sw = per-token / per-output-row dequantisation scales
   int fp8; const float* sa; const float* sw;
+  // optional (split-K path with the residual epilogue only): the finish kernel also writes next_xn = RMSNorm(C) * next_rms_w and
+  // sets *fused_next = 1; otherwise *fused_next stays 0 and the caller launches the norm itself.  Same bits as the two launches.
+  const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next; float rms_eps; int rms_cast;
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)

@@ -316,6 +316,29 @@ def test_decode_layers_only_entry_runs_the_layer_launches():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
+    """Single-prompt prefill (M <= 1024: the o and down projections run K-split): the finish launch of the residual epilogue also
+    writes the RMSNorm of its result (PCY_FINISH_NORM=0: residual finish + rmsnorm as two launches).  Same element assignment,
+    accumulation order and block reduction: last-row logits, final hidden state and the K/V cache must be bit-identical."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, LlamaConfig, LlamaEngine
+    kw = dict(vocab=2048, d=4096, n_layers=3, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=1024))
+    torch.manual_seed(6)
+    outs = []
+    for T in (512, 200):
+        emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
+        res = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("PCY_FINISH_NORM", fused)
+            cache = eng.new_cache(1, T + 4)
+            logits, hidden = eng.prefill(emb, None, cache, "last", want_hidden=True)
+            Context.get().sync()
+            res.append((logits.cpu().clone(), hidden.cpu().clone(), cache.k[:, 0, :, :T].cpu().clone(), cache.v[:, 0, :, :T].cpu().clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b), T
+
+
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
     """Batched decode (B > 4, skinny-MFMA GEMVs with K split): the finish kernel of the o / down projections also writes the
     RMSNorm that follows (PCY_FINISH_NORM, default on).  Same element assignment and reduction order as the two separate
