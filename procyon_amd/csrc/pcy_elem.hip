@@ -183,14 +183,12 @@ __global__ __launch_bounds__(NT) void esm_embed_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------ rotary on a token-major buffer
 // one block per token; a thread handles 8 consecutive elements i..i+7 of the low half of a head and their partners
 // i+dh/2.. (16-byte loads/stores)
-__global__ __launch_bounds__(NT) void rope_kernel(bf16_t* __restrict__ buf, int ld, int col0, int nh, int dh,
-                                                  const int32_t* __restrict__ pos, const bf16_t* __restrict__ cos_t,
-                                                  const bf16_t* __restrict__ sin_t, int mode, float prescale) {
-  const int tok = blockIdx.x;
-  const int p = pos[tok];
+// rope of token `tok` over heads [0, nh) of `row` (in place); heads >= kh0 (the key heads) are also copied, roped, to kdst_row
+// (cache row of the token: kdst_row + (h - kh0) * kstride_h), nullptr = no copy
+__device__ __forceinline__ void rope_row(bf16_t* row, int nh, int dh, int p, const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t,
+                                         int mode, float prescale, int kh0, bf16_t* kdst_row, size_t kstride_h) {
   const int half = dh >> 1;
   const int cph = half >> 3;  // 8-element chunks per half head
-  bf16_t* row = buf + (size_t)tok * ld + col0;
   const bf16_t* c = cos_t + (size_t)p * dh;
   const bf16_t* s = sin_t + (size_t)p * dh;
   for (int e = threadIdx.x; e < nh * cph; e += NT) {
@@ -223,9 +221,21 @@ __global__ __launch_bounds__(NT) void rope_kernel(bf16_t* __restrict__ buf, int 
       O1[w] = pack_bf(o1[0], o1[1]);
       O2[w] = pack_bf(o2[0], o2[1]);
     }
-    *reinterpret_cast<uint4*>(x + i) = make_uint4(O1[0], O1[1], O1[2], O1[3]);
-    *reinterpret_cast<uint4*>(x + i + half) = make_uint4(O2[0], O2[1], O2[2], O2[3]);
+    const uint4 r1 = make_uint4(O1[0], O1[1], O1[2], O1[3]), r2 = make_uint4(O2[0], O2[1], O2[2], O2[3]);
+    *reinterpret_cast<uint4*>(x + i) = r1;
+    *reinterpret_cast<uint4*>(x + i + half) = r2;
+    if (kdst_row && h >= kh0) {
+      bf16_t* kd = kdst_row + (size_t)(h - kh0) * kstride_h;
+      *reinterpret_cast<uint4*>(kd + i) = r1;
+      *reinterpret_cast<uint4*>(kd + i + half) = r2;
+    }
   }
+}
+__global__ __launch_bounds__(NT) void rope_kernel(bf16_t* __restrict__ buf, int ld, int col0, int nh, int dh,
+                                                  const int32_t* __restrict__ pos, const bf16_t* __restrict__ cos_t,
+                                                  const bf16_t* __restrict__ sin_t, int mode, float prescale) {
+  const int tok = blockIdx.x;
+  rope_row(buf + (size_t)tok * ld + col0, nh, dh, pos[tok], cos_t, sin_t, mode, prescale, nh, nullptr, 0);
 }
 
 // ------------------------------------------------------------------ K/V scatter into the [B,Hkv,Tmax,dh] cache
@@ -247,17 +257,18 @@ __global__ __launch_bounds__(NT) void kv_scatter_kernel(const bf16_t* __restrict
 
 // ------------------------------------------------------------------ V transpose: token-major -> Vt[nh][dh][vt_total]
 // grid (tiles of 64 tokens, nh*dh/64, nseq); 64x64 tile through LDS
-__global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restrict__ buf, int ld, int vcol0, int dh,
-                                                         const int32_t* __restrict__ cu, const int32_t* __restrict__ vt_cu,
-                                                         bf16_t* __restrict__ vt, int vt_total) {
+// vc != nullptr (rectangular batches of T tokens per sequence): the V rows are also copied into the [B,Hkv,Tmax,dh] cache
+__device__ __forceinline__ void transpose_v_tile(const bf16_t* __restrict__ buf, int ld, int vcol0, int dh,
+                                                 const int32_t* __restrict__ cu, const int32_t* __restrict__ vt_cu,
+                                                 bf16_t* __restrict__ vt, int vt_total, int bx, int by, int q,
+                                                 bf16_t* __restrict__ vc, int Hkv, int Tmax) {
   // 16-byte global loads (8 features of a token) and 16-byte global stores (8 tokens of a feature); the 64 x 64 tile
   // turns in LDS (row stride 72 elements = 144 B keeps the 16-byte rows aligned and spreads the column reads over banks)
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
-  const int q = blockIdx.z;
   const int t0 = cu[q], len = cu[q + 1] - t0;
-  const int j0 = blockIdx.x * 64;
+  const int j0 = bx * 64;
   if (j0 >= len) return;
-  const int f0 = blockIdx.y * 64;  // feature (h*dh + e) tile
+  const int f0 = by * 64;  // feature (h*dh + e) tile
   const int padlen = vt_cu[q + 1] - vt_cu[q];
   const bool vec = ((ld | vcol0) % 8 == 0) && (vt_total % 8 == 0);
   if (!vec) {
@@ -275,7 +286,10 @@ __global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restric
   for (int e = threadIdx.x; e < 64 * 8; e += NT) {
     const int j = e >> 3, fc = (e & 7) * 8;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (j0 + j < len) v = *reinterpret_cast<const uint4*>(buf + (size_t)(t0 + j0 + j) * ld + vcol0 + f0 + fc);
+    if (j0 + j < len) {
+      v = *reinterpret_cast<const uint4*>(buf + (size_t)(t0 + j0 + j) * ld + vcol0 + f0 + fc);
+      if (vc) { const int f = f0 + fc, h = f / dh; *reinterpret_cast<uint4*>(vc + (((size_t)q * Hkv + h) * Tmax + j0 + j) * dh + (f - h * dh)) = v; }
+    }
     *reinterpret_cast<uint4*>(&tile[j][fc]) = v;
   }
   __syncthreads();
@@ -287,6 +301,32 @@ __global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restric
     for (int k = 0; k < 4; ++k) w[k] = (uint32_t)tile[jc + 2 * k][f] | ((uint32_t)tile[jc + 2 * k + 1][f] << 16);
     *reinterpret_cast<uint4*>(vt + (size_t)(f0 + f) * vt_total + vt_cu[q] + j0 + jc) = make_uint4(w[0], w[1], w[2], w[3]);
   }
+}
+__global__ __launch_bounds__(NT) void transpose_v_kernel(const bf16_t* __restrict__ buf, int ld, int vcol0, int dh,
+                                                         const int32_t* __restrict__ cu, const int32_t* __restrict__ vt_cu,
+                                                         bf16_t* __restrict__ vt, int vt_total) {
+  transpose_v_tile(buf, ld, vcol0, dh, cu, vt_cu, vt, vt_total, blockIdx.x, blockIdx.y, blockIdx.z, nullptr, 0, 0);
+}
+
+// Llama prefill, everything between the qkv projection and the attention in ONE launch (was rope, kv_scatter, transpose_v):
+//   blocks [0, B*T):  rope of the token's q and k heads in place; the roped k heads also go to the K cache
+//   the rest:         64 x 64 tiles of V -> Vt (the attention's B operand) and -> the V cache
+// Rectangular batch: token b*T + t, cu[q] = q*T.  Same arithmetic and the same bytes as the three launches.
+__global__ __launch_bounds__(NT) void prefill_post_qkv_kernel(bf16_t* __restrict__ qkv, int ld, int H, int Hkv, int dh,
+                                                              const int32_t* __restrict__ pos, const bf16_t* __restrict__ cos_t,
+                                                              const bf16_t* __restrict__ sin_t, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                              int B, int T, int Tmax, const int32_t* __restrict__ cu,
+                                                              const int32_t* __restrict__ vt_cu, bf16_t* __restrict__ vt, int vt_total,
+                                                              int tiles_x, int tiles_y) {
+  const int ntok = B * T;
+  if ((int)blockIdx.x < ntok) {
+    const int tok = blockIdx.x, b = tok / T, t = tok - b * T;
+    rope_row(qkv + (size_t)tok * ld, H + Hkv, dh, pos[tok], cos_t, sin_t, 0, 0.f, H, kc + ((size_t)b * Hkv * Tmax + t) * dh, (size_t)Tmax * dh);
+    return;
+  }
+  const int r = blockIdx.x - ntok;
+  const int bx = r % tiles_x, by = (r / tiles_x) % tiles_y, q = r / (tiles_x * tiles_y);
+  transpose_v_tile(qkv, ld, (H + Hkv) * dh, dh, cu, vt_cu, vt, vt_total, bx, by, q, vc, Hkv, Tmax);
 }
 
 // ------------------------------------------------------------------ ProteinPooler (A3)
@@ -1223,6 +1263,16 @@ void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* tok
 void pcy_launch_rope(hipStream_t s, bf16_t* buf, int ld, int col0, int nh, int dh, const int32_t* pos,
                      const bf16_t* cos_t, const bf16_t* sin_t, int ntok, int mode, float prescale) {
   if (ntok > 0) hipLaunchKernelGGL(rope_kernel, dim3(ntok), dim3(NT), 0, s, buf, ld, col0, nh, dh, pos, cos_t, sin_t, mode, prescale);
+}
+bool pcy_launch_prefill_post_qkv(hipStream_t s, bf16_t* qkv, int ld, int H, int Hkv, int dh, const int32_t* pos, const bf16_t* cos_t,
+                                 const bf16_t* sin_t, bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax, const int32_t* cu,
+                                 const int32_t* vt_cu, bf16_t* vt, int vt_total) {
+  if (B * T <= 0 || (Hkv * dh) % 64 || dh % 16 || ld % 8 || ((H + Hkv) * dh) % 8 || vt_total % 8) return false;
+  const int maxpad = (T + 31) / 32 * 32;
+  const int tx = (maxpad + 63) / 64, ty = Hkv * dh / 64;
+  hipLaunchKernelGGL(prefill_post_qkv_kernel, dim3(B * T + tx * ty * B), dim3(NT), 0, s, qkv, ld, H, Hkv, dh, pos, cos_t, sin_t, kcache, vcache,
+                     B, T, Tmax, cu, vt_cu, vt, vt_total, tx, ty);
+  return true;
 }
 void pcy_launch_kv_scatter(hipStream_t s, const bf16_t* qkv, int ld, int kcol0, int vcol0, int Hkv, int dh,
                            bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax) {

@@ -855,10 +855,15 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
       xn_ready = 0;
       linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
     }
-    pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
-    pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
-                          (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
-    pcy_launch_transpose_v(s, qkv, qkvw, (H + Hkv) * dh, Hkv, dh, cu, vt_cu, B, T, vt, vt_total);
+    const char* pq = getenv("PCY_PREFILL_POST_QKV");   // =0: the three launches (read per call: the test compares both)
+    if ((pq && atoi(pq) == 0) ||
+        !pcy_launch_prefill_post_qkv(s, qkv, qkvw, H, Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin,
+                                     (bf16_t*)kv->k + l * layer_stride, (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax, cu, vt_cu, vt, vt_total)) {
+      pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);
+      pcy_launch_kv_scatter(s, qkv, qkvw, H * dh, (H + Hkv) * dh, Hkv, dh, (bf16_t*)kv->k + l * layer_stride,
+                            (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax);
+      pcy_launch_transpose_v(s, qkv, qkvw, (H + Hkv) * dh, Hkv, dh, cu, vt_cu, B, T, vt, vt_total);
+    }
     PcyAttnArgs t{};
     t.q = qkv; t.ldq = qkvw; t.qcol0 = 0; t.k = qkv; t.ldk = qkvw; t.kcol0 = H * dh; t.vt = vt; t.vt_total = vt_total;
     t.o = ao; t.ldo = H * dh; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = B; t.max_len = T; t.H = H; t.Hkv = Hkv; t.dh = dh;

@@ -92,6 +92,10 @@ void pcy_launch_esm_embed(hipStream_t s, const bf16_t* table, const int32_t* tok
 void pcy_launch_rope(hipStream_t s, bf16_t* buf, int ld, int col0, int nh, int dh, const int32_t* pos,
                      const bf16_t* cos_t, const bf16_t* sin_t, int ntok, int mode, float prescale);
 // scatter roped K and V of a token-major qkv buffer into the [B,Hkv,Tmax,dh] cache at slots [0,T)
+// rope (q, k in place) + K/V cache scatter + V transpose of a rectangular prefill batch in ONE launch; false = shape not covered
+bool pcy_launch_prefill_post_qkv(hipStream_t s, bf16_t* qkv, int ld, int H, int Hkv, int dh, const int32_t* pos, const bf16_t* cos_t,
+                                 const bf16_t* sin_t, bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax, const int32_t* cu,
+                                 const int32_t* vt_cu, bf16_t* vt, int vt_total);
 void pcy_launch_kv_scatter(hipStream_t s, const bf16_t* qkv, int ld, int kcol0, int vcol0, int Hkv, int dh,
                            bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax);
 // V (token-major, column vcol0, nh heads) -> Vt[nh][dh][vt_total], sequence q occupies columns vt_cu[q]+j

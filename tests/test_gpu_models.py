@@ -318,8 +318,9 @@ def test_decode_layers_only_entry_runs_the_layer_launches():
 
 def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
     """Single-prompt prefill (M <= 1024: the o and down projections run K-split): the finish launch of the residual epilogue also
-    writes the RMSNorm of its result (PCY_FINISH_NORM=0: residual finish + rmsnorm as two launches).  Same element assignment,
-    accumulation order and block reduction: last-row logits, final hidden state and the K/V cache must be bit-identical."""
+    writes the RMSNorm of its result (PCY_FINISH_NORM=0: residual finish + rmsnorm as two launches), and rope, K/V cache scatter
+    and V transpose run as one launch (PCY_PREFILL_POST_QKV=0: three).  Same element assignment, accumulation order and block
+    reduction: last-row logits, final hidden state and the K/V cache must be bit-identical."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, LlamaConfig, LlamaEngine
     kw = dict(vocab=2048, d=4096, n_layers=3, n_heads=32, n_kv_heads=8, ffn=14336)
@@ -331,6 +332,7 @@ def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
         res = []
         for fused in ("1", "0"):
             monkeypatch.setenv("PCY_FINISH_NORM", fused)
+            monkeypatch.setenv("PCY_PREFILL_POST_QKV", fused)   # rope + K/V scatter + V transpose as one launch / three
             cache = eng.new_cache(1, T + 4)
             logits, hidden = eng.prefill(emb, None, cache, "last", want_hidden=True)
             Context.get().sync()
