@@ -210,6 +210,10 @@ typedef struct {
 } pcy_gen_state;
 /* one decode step: next_tok -> logits (and K/V appended at slot *pos); does not pick or advance */
 int pcy_llama_decode(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B);
+/* Measurement aid (tools/bench_decode.py with PCY_MC_TRACE=1 in the environment): copies the in-kernel time stamps of the last
+ * fused decode launches ([2][128 layers][256 workgroups][16] ticks of 10 ns) to `out` (n words); returns n, or 0 when no stamps
+ * were taken. */
+int pcy_debug_mc_trace(unsigned long long* out, int n);
 /* Measurement aid (bench.py roofline leg): `reps` passes over the decoder layers of a decode step -- no token embedding (the
  * residual stream is whatever the workspace holds), no lm_head, no pick; K/V of slot *pos are rewritten each pass.  With HIP
  * events around it: time per layer launch = elapsed / (reps * n_layers). */
