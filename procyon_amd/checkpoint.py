@@ -70,12 +70,33 @@ def split_state_dict(sd):
     return dict(llama=llama, esm=esm, esm_fair=esm_fair, projectors=projectors, tables=tables)
 
 
-def merge_lora(sd, lora_alpha=None):
+TEXT_LORA_ALPHA = 8.0   # pmc_llama.py:430-431: `UnifiedProCyon` never forwards lora_r / lora_alpha to LlamaPostTokenization
+                        # (model_unified.py:147-158), so every text adapter was trained and runs with r = 16, alpha = 8 (scale 0.5)
+
+
+def lora_alpha_for(key_prefix, config=None):
+    """LoRA alpha of the adapter whose base weight lives under `key_prefix` (PEFT scale = alpha / r, r read from the tensors).
+
+    text_encoder.*        -> 8 (the constructor default above; the reference has no way to set another value)
+    protein_seq_encoder.* -> config.aaseq_lora_alpha (model_unified.py:226-228; esm.py:436-437)
+    anything else / missing config field -> ValueError: an unknown alpha must never silently become scale 1."""
+    if key_prefix.startswith("text_encoder."):
+        return TEXT_LORA_ALPHA
+    if key_prefix.startswith("protein_seq_encoder."):
+        a = getattr(config, "aaseq_lora_alpha", None) if config is not None else None
+        if a is None:
+            raise ValueError(f"LoRA adapter under {key_prefix}: the checkpoint's model_args carry no aaseq_lora_alpha; pass lora_alpha=")
+        return float(a)
+    raise ValueError(f"LoRA adapter under {key_prefix}: no rule for its alpha; pass lora_alpha=")
+
+
+def merge_lora(sd, lora_alpha=None, config=None):
     """Checkpoints trained with `use_lora` carry PEFT names (peft 0.5.0): `<prefix>.base_model.model.<hf key>` for the frozen
     weights (a Linear that holds an adapter: `...<name>.weight` stays under that name in 0.5.0, `base_layer.weight` in later
     versions) and `...<name>.lora_A.<adapter>.weight` [r, in], `...lora_B.<adapter>.weight` [out, r].  The reference loads them
     into a PEFT-wrapped module; the engine packs plain matrices, so the delta is folded in: W += (alpha / r) * B @ A.
-    `lora_alpha` defaults to r (scale 1) when the checkpoint does not say; pass the training value."""
+    alpha: `lora_alpha` when given (one value for every adapter), otherwise per adapter by `lora_alpha_for` (text adapters 8,
+    protein-encoder adapters config.aaseq_lora_alpha); an adapter whose alpha cannot be determined raises."""
     if not any(".lora_A." in k or ".base_model.model." in k for k in sd):
         return sd
     out, lora = {}, {}
@@ -93,7 +114,8 @@ def merge_lora(sd, lora_alpha=None):
         if wkey not in out:
             raise KeyError(f"LoRA adapter for {base} but no base weight {wkey} in the checkpoint")
         r = ab["A"].shape[0]
-        scale = (lora_alpha if lora_alpha is not None else r) / r
+        alpha = float(lora_alpha) if lora_alpha is not None else lora_alpha_for(base, config)
+        scale = alpha / r
         out[wkey] = (out[wkey].float() + scale * (ab["B"].float() @ ab["A"].float())).to(out[wkey].dtype)
     return out
 
@@ -341,7 +363,7 @@ def from_pretrained(*, pretrained_weights_dir=None, checkpoint_dir=None, model=N
         sd = torch.load(sd_path, map_location="cpu", weights_only=False, pickle_module=_ShellPickle)
     else:                                                        # DeepSpeed ZeRO shards (:1380-1382)
         sd = get_fp32_state_dict_from_zero_checkpoint(checkpoint_dir)
-    sd = merge_lora(sd)
+    sd = merge_lora(sd, config=config_checkpoint)   # text adapters: alpha 8; protein-encoder adapters: aaseq_lora_alpha / aaseq_lora_r
     if not any(k.startswith("protein_seq_encoder.model.") for k in sd) and not getattr(config, "use_aaseq_embeddings", False):
         # frozen encoder loaded from the fair-esm release file next to the other pretrained weights (esm.py:378-398)
         name = {"650m": "esm2_t33_650M_UR50D.pt", "3b": "esm2_t36_3B_UR50D.pt", "35m": "esm2_t12_35M_UR50D.pt",

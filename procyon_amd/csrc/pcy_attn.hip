@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
         ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 18)) { if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (pcy_wait_give_up(spins, 1u << 18, err, 2u, lane)) break;
     }
   }
   __syncthreads();
@@ -685,6 +685,11 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
       configured = smem;                                                                                            \
     }                                                                                                               \
+    static int resident = -1; static size_t resident_smem = 0;                                                      \
+    if (resident < 0 || resident_smem != smem) {                                                                    \
+      resident = pcy_all_resident(attn_o_kernel<DH, G, RWV>, 512, smem, (int)grid.x, n_cu) ? 1 : 0; resident_smem = smem; \
+    }                                                                                                               \
+    if (!resident) return false;                                                                                    \
     hipLaunchKernelGGL((attn_o_kernel<DH, G, RWV>), grid, block, smem, s, a, o, n_attn, epoch, flags, err, dbg, delay); \
   } while (0)
   switch (rw) {
@@ -752,7 +757,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
           if (mine) v = ld16_agent(qt + w0);
           const bool ok = !mine || ((v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag);
           if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-          if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if (pcy_wait_give_up(spins, 1u << 19, err, 9u, lane)) break;
           __builtin_amdgcn_s_sleep(8);
         }
         if (mine) *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
@@ -854,7 +859,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
       const uint4 v = ld16_agent(p.ao_tag + lane * 4);
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-      if (++spins > (1u << 19)) { if (lane == 0 && p.err) __hip_atomic_store(p.err, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (pcy_wait_give_up(spins, 1u << 19, p.err, 10u, lane)) break;
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(512) void decode_step_kernel(PcyDecAttnArgs a, PcyA
 
 template <int DH, int G>
 bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const unsigned* step_epoch,
-                         unsigned* xflags, const PcyDecodeStepArgs* st = nullptr) {
+                         unsigned* xflags, int n_cu, const PcyDecodeStepArgs* st = nullptr) {
   const int n_attn = (DH / 16) * a.Hkv, n_o = 256 - n_attn;
   if (n_o < 64 || p.Nq != n_o * 8 * 4 || p.d > n_o * 8 * 4 || a.H * DH != 8 * 512 || p.d != 4096) return false;
   // the MLP body: same geometry conditions as pcy_launch_mlp_chain
@@ -968,6 +973,15 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
     else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured[st ? 1 : 0] = smem;
   }
+  // every workgroup waits for words the others write: all 256 must be resident at once (occupancy query, cached per kernel / LDS size)
+  static int resident[2] = {-1, -1}; static size_t resident_smem[2] = {0, 0};
+  const int ri = st ? 1 : 0;
+  if (resident[ri] < 0 || resident_smem[ri] != smem) {
+    resident[ri] = (st ? pcy_all_resident(decode_step_kernel<DH, G>, 512, smem, 256, n_cu)
+                       : pcy_all_resident(decode_layer_kernel<DH, G>, 512, smem, 256, n_cu)) ? 1 : 0;
+    resident_smem[ri] = smem;
+  }
+  if (!resident[ri]) return false;
   if (st)
     hipLaunchKernelGGL((decode_step_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, *st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
                        stage_off, pcy_gemv_rms_threads(mc.F));
@@ -1064,10 +1078,10 @@ bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAt
                              const unsigned* step_epoch, unsigned* xflags) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256) return false;
   switch (a.H / a.Hkv) {
-    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, xflags);
-    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, xflags);
-    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, xflags);
-    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, xflags);
+    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, xflags, n_cu);
+    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, xflags, n_cu);
+    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, xflags, n_cu);
+    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, xflags, n_cu);
   }
   return false;
 }
@@ -1078,10 +1092,10 @@ bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAtt
                             int n_cu, const unsigned* step_epoch) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256 || st.n_layers < 1) return false;
   switch (a.H / a.Hkv) {
-    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, a.xflags, &st);
-    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, a.xflags, &st);
-    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, a.xflags, &st);
-    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, a.xflags, &st);
+    case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);
+    case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);
+    case 4: return launch_decode_layer<128, 4>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);
+    case 8: return launch_decode_layer<128, 8>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);
   }
   return false;
 }

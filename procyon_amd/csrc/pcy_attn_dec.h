@@ -272,7 +272,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
         const bool ok = lane >= SLICES || __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.xepoch;
         if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 18)) { if (lane == 0 && a.xerr) __hip_atomic_store(a.xerr, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (pcy_wait_give_up(spins, 1u << 18, a.xerr, 3u, lane)) break;
       }
     }
     __syncthreads();

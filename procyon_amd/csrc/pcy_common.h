@@ -157,6 +157,21 @@ __device__ __forceinline__ uint4 ld16_agent(const void* p) {
 }
 __device__ __forceinline__ void st_bf16_agent(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Watchdog of the in-launch cross-workgroup waits (hand-overs, flags): give up after `limit` polls and record `code` in the
+// context's sticky error word -- and give up at once when ANY wait of the launch has already done so (otherwise a launch whose
+// workgroups are not all resident, e.g. beside a competing kernel, would sit out the full limit at every one of its ~200
+// waits).  The host reads the word at the next ABI call (pinned, host-visible memory) and fails that call.
+__device__ __forceinline__ bool pcy_wait_give_up(unsigned& spins, unsigned limit, unsigned* err, unsigned code, int lane) {
+  ++spins;
+  if (err && (spins & 255u) == 0u &&
+      __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0) return true;
+  if (spins > limit) {
+    if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  }
+  return false;
+}
+
 // Epilogue selectors shared by the GEMM (prefill / encoder) and GEMV (decode) kernels.
 enum PcyEpi : int {
   EPI_STORE = 0,      // y = bf16(acc [+ bias])

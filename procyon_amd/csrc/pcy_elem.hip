@@ -1299,6 +1299,7 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
   hipLaunchKernelGGL(pick_stage2_kernel, dim3(1), dim3(256), 0, s, logits, V, reinterpret_cast<const PickPartial*>(partials), next_tok,
                      tokens_out, max_steps, logprob, step_dev, pos_dev, advance_pos, B);
 }
+int pcy_sample_max_vocab() { return SMP_NT * SMP_KMAX; }
 void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
                             unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
                             int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials, bf16_t* pbits) {

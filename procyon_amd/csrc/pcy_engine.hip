@@ -41,13 +41,15 @@ struct pcy_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // captured decode step
   hipGraphExec_t graph = nullptr;
-  static constexpr int GRAPH_KEY_N = 16;
+  static constexpr int GRAPH_KEY_N = 19;
   const void* graph_key[GRAPH_KEY_N] = {};
   int graph_B = 0;
   int graph_mode = 0;
   int graph_kind = 0;                 // 0: decode + greedy pick (pcy_llama_greedy), 1: decode only (pcy_llama_decode_graph)
   int n_cu = 0;
-  unsigned* xwg_err = nullptr;        // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog
+  // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog.  PINNED HOST memory (device-visible): the
+  // kernels store it with system scope, every ABI entry looks at it without touching the stream (take_sticky_error below)
+  unsigned* xwg_err = nullptr;
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
   // tagged hand-over vectors of the MLP chain launches: [layer][ffn + d] words, owned by one model geometry at a time
@@ -55,6 +57,7 @@ struct pcy_ctx {
   const void* mc_tags_model = nullptr;
   size_t mc_tags_words = 0;
   int mc_tags_mode = -1;
+  uint64_t layers_fp = 0;              // fingerprint of the weight pointers dev_layers was built from
   PcyLayerWeightsDev* dev_layers = nullptr;   // device copy of the layers' weight pointers (decode_step_kernel)
   uint32_t* op_tags = nullptr;        // tagged `act` vector of pcy_decode_mlp ([ffn] words, its own counter)
   size_t op_tags_words = 0;
@@ -94,6 +97,21 @@ struct Carver {
     return r;
   }
 };
+
+// A watchdog of an in-launch wait has fired since the last look (results of that launch and of everything that consumed them are
+// invalid): report it ONCE, from whichever ABI call comes next -- no stream synchronisation, the word lives in host memory.
+int take_sticky_error(pcy_ctx* c) {
+  if (!c->xwg_err) return 0;
+  const unsigned code = *reinterpret_cast<volatile unsigned*>(c->xwg_err);
+  if (!code) return 0;
+  *reinterpret_cast<volatile unsigned*>(c->xwg_err) = 0;
+  return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (code %u): its workgroups were not all resident -- is "
+                 "another kernel running on this device? -- results since the last successful pcy_ctx_sync are invalid", code);
+}
+#define PCY_STICKY(c)                                 \
+  do {                                                \
+    if (int r_ = take_sticky_error(c)) return r_;     \
+  } while (0)
 
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -164,8 +182,8 @@ int ensure_sync_words(pcy_ctx* c) {
     c->n_cu = prop.multiProcessorCount;
   }
   if (!c->xwg_err) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->xwg_err), 64));
-    HIP_TRY(hipMemset(c->xwg_err, 0, 64));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->xwg_err), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->xwg_err, 0, 64);
   }
   if (!c->ao_sync) {
     // [0] step epoch, [1] tag counter of the decode step's fused launches, [2] tag counter of pcy_decode_mlp, attention->o flags,
@@ -176,14 +194,28 @@ int ensure_sync_words(pcy_ctx* c) {
   }
   return 0;
 }
+uint64_t layers_fingerprint(const pcy_llama_desc* m) {   // FNV-1a over every weight pointer the fused decode launches read
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p) { h = (h ^ (uint64_t)(uintptr_t)p) * 1099511628211ull; };
+  mix(m->layers);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const pcy_llama_layer& L = m->layers[l];
+    mix(L.ln1); mix(L.wqkv); mix(L.wo); mix(L.ln2); mix(L.wgu); mix(L.wdown);
+  }
+  return h;
+}
 int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
   if (int r = ensure_sync_words(c)) return r;
   // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
   // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
   // (a change of the launch mix as well: a slot the new mix reads may not have been rewritten for a while)
+  // "Another model" is decided on the weight POINTERS, not on the descriptor's address: a new engine of the same geometry may
+  // get the address of a freed descriptor, and a descriptor may be mutated in place -- either would leave dev_layers stale.
   const size_t words = (size_t)m->n_layers * (tag_words_per_layer(m) + 32 * 256);   // + the residual stream between the layers, one line per workgroup
-  if (c->mc_tags_model != m || c->mc_tags_words != words || c->mc_tags_mode != decode_mode()) {
+  const uint64_t fp = layers_fingerprint(m);
+  if (c->mc_tags_model != m || c->mc_tags_words != words || c->mc_tags_mode != decode_mode() || c->layers_fp != fp) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->drop_graph();   // a captured step holds mc_tags / dev_layers as kernel arguments
     if (c->mc_tags) HIP_TRY(hipFree(c->mc_tags));
     c->mc_tags = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
@@ -198,7 +230,7 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
       lw[l] = {(const bf16_t*)L.ln1, (const bf16_t*)L.wqkv, (const bf16_t*)L.wo, (const bf16_t*)L.ln2, (const bf16_t*)L.wgu, (const bf16_t*)L.wdown};
     }
     HIP_TRY(hipMemcpy(c->dev_layers, lw.data(), lw.size() * sizeof(PcyLayerWeightsDev), hipMemcpyHostToDevice));
-    c->mc_tags_model = m; c->mc_tags_words = words; c->mc_tags_mode = decode_mode();
+    c->mc_tags_model = m; c->mc_tags_words = words; c->mc_tags_mode = decode_mode(); c->layers_fp = fp;
   }
   return 0;
 }
@@ -379,6 +411,8 @@ void enqueue_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, 
 void enqueue_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_gen_state* st, int B, int advance_pos, int Tmax, float temperature,
                     float nucleus_p, const float* uniforms, bf16_t* probs_out) {
   hipStream_t s = c->stream;
+  // the nucleus branch of the reference is softmax(logits) * mask -- the temperature is not applied there (model_unified.py:899-901)
+  if (nucleus_p > 0.f) temperature = 1.0f;
   if (st->logits_all)
     hipLaunchKernelGGL(store_logits_kernel, dim3(B >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits,
                        (bf16_t*)st->logits_all, st->step, B, m->vocab, st->logits_all_ld > 0 ? st->logits_all_ld : m->vocab);
@@ -456,7 +490,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   hipStreamSynchronize(c->stream);
   c->drop_graph();
   if (c->ws) hipFree(c->ws);
-  if (c->xwg_err) hipFree(c->xwg_err);
+  if (c->xwg_err) hipHostFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->mc_tags) hipFree(c->mc_tags);
   if (c->dev_layers) hipFree(c->dev_layers);
@@ -471,15 +505,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
 }
 int pcy_ctx_sync(pcy_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->xwg_err) {
-    unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, c->xwg_err, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) {
-      HIP_TRY(hipMemset(c->xwg_err, 0, sizeof(err)));
-      return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (results invalid)");
-    }
-  }
-  return 0;
+  return take_sticky_error(c);
 }
 int pcy_timer_start(pcy_ctx* c) { HIP_TRY(hipEventRecord(c->ev0, c->stream)); return 0; }
 int pcy_timer_stop(pcy_ctx* c, float* ms) {
@@ -514,6 +540,7 @@ int pcy_gemv(pcy_ctx* c, const void* W, const void* x, int ldx, const void* bias
 }
 
 int pcy_decode_mlp(pcy_ctx* c, void* x, const void* ln2, const void* wgu, const void* wdown, int d, int ffn, float rms_eps, int rms_cast) {
+  PCY_STICKY(c);
   if (d % 8 || ffn % 8 || (size_t)d * 2 > 65536) return fail(1, "pcy_decode_mlp: d=%d ffn=%d not covered", d, ffn);
   if (int r = ensure_sync_words(c)) return r;
   const size_t words = (size_t)ffn;
@@ -687,6 +714,7 @@ int pcy_allgather(pcy_ctx* c, void* comm, const void* sendbuf, void* recvbuf, si
 }
 
 int pcy_retrieval_topk(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, int k, int32_t* idx_out, void* score_out) {
+  PCY_STICKY(c);
   if (D % 64) return fail(1, "pcy_retrieval_topk: D=%d must be a multiple of 64", D);
   if (k < 1 || k > N) return fail(1, "pcy_retrieval_topk: k=%d must be in [1, N=%d]", k, N);
   const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256), sb = align_up((size_t)Q * N * 2, 256);
@@ -701,6 +729,7 @@ int pcy_retrieval_topk(pcy_ctx* c, const void* query, int Q, const void* targets
   return check_launch("pcy_retrieval_topk");
 }
 int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targets, int N, int D, void* sims_out) {
+  PCY_STICKY(c);
   if (D % 64) return fail(1, "pcy_retrieval_scores: D=%d must be a multiple of 64", D);
   const size_t qb = align_up((size_t)Q * D * 2, 256), tb = align_up((size_t)N * D * 2, 256);
   if (int r = c->reserve(qb + tb + 4096)) return r;
@@ -713,6 +742,7 @@ int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targe
 }
 
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
+  PCY_STICKY(c);
   if (m->n_layers < 1 || m->n_layers > 8) return fail(1, "pcy_mlp_forward: n_layers %d", m->n_layers);
   int maxw = 0;
   for (int i = 0; i <= m->n_layers; ++i) {
@@ -737,6 +767,7 @@ int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, voi
 
 int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                    const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {
+  PCY_STICKY(c);
   const int d = m->d, H = m->n_heads, F = m->ffn;
   if (d % H) return fail(1, "pcy_esm_encode: d %% heads");
   const int dh = d / H;
@@ -791,6 +822,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
                       const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
                       int n_logit_rows, void* logits_out, void* hidden_out, const int32_t* sum_rows, int n_sum_rows,
                       void* hidden_sum_out) {
+  PCY_STICKY(c);
   const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
   if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_llama_prefill: head_dim %d unsupported (32/64/128)", dh);
   if (d % 64 || F % 64 || (H * dh) % 64 || (Hkv * dh) % 64) return fail(1, "pcy_llama_prefill: d, ffn, H*dh, Hkv*dh must be multiples of 64");
@@ -911,6 +943,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
 }
 
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+  PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
@@ -919,6 +952,7 @@ int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
 }
 
 int pcy_llama_decode_layers(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int reps) {
+  PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode_layers: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
@@ -927,6 +961,7 @@ int pcy_llama_decode_layers(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_ca
 }
 
 int pcy_greedy_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int advance_pos) {
+  PCY_STICKY(c);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   enqueue_pick(c, m, st, B, advance_pos, kv->Tmax);
   return check_launch("pcy_greedy_pick");
@@ -941,7 +976,8 @@ int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache*
   const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, st->tokens_out, st->logprob,
                                            st->logits, st->logits_all, st->keep, c->ws,
                                            (const void*)(intptr_t)(((int64_t)st->logits_all_ld << 32) ^ kv->Tmax),
-                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ st->max_steps)};
+                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ st->max_steps),
+                                           c->mc_tags, c->dev_layers, (const void*)(uintptr_t)c->layers_fp};
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 ||
       c->graph_B != B || c->graph_mode != decode_mode() || c->graph_kind != kind) {
     c->drop_graph();
@@ -970,6 +1006,7 @@ int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache*
 
 int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
                      int use_graph) {
+  PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
@@ -984,6 +1021,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
 }
 
 int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {
+  PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode_graph: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
@@ -992,9 +1030,10 @@ int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cac
 
 int pcy_sample_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int advance_pos,
                     float temperature, float nucleus_prob, const float* uniforms, void* probs_out) {
+  PCY_STICKY(c);
   if (!(temperature > 0.f)) return fail(1, "pcy_sample_pick: temperature must be > 0 (greedy: pcy_greedy_pick)");
   if (nucleus_prob >= 1.f) return fail(1, "pcy_sample_pick: nucleus_prob must be < 1 (<= 0 switches the nucleus mask off)");
-  if (m->vocab > 65536 * 4) return fail(1, "pcy_sample_pick: vocabulary %d unsupported", m->vocab);
+  if (m->vocab > pcy_sample_max_vocab()) return fail(1, "pcy_sample_pick: vocabulary %d unsupported (<= %d)", m->vocab, pcy_sample_max_vocab());
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_sample_state(c, B, m->vocab)) return r;
   enqueue_sample(c, m, st, B, advance_pos, kv->Tmax, temperature, nucleus_prob, uniforms, (bf16_t*)probs_out);
@@ -1003,8 +1042,10 @@ int pcy_sample_pick(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
 
 int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int n_steps,
                      float temperature, float nucleus_prob, const float* uniforms) {
+  PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_sample: B=%d exceeds cache rows %d", B, kv->B);
   if (!(temperature > 0.f) || nucleus_prob >= 1.f) return fail(1, "pcy_llama_sample: temperature > 0 and nucleus_prob < 1 required");
+  if (m->vocab > pcy_sample_max_vocab()) return fail(1, "pcy_llama_sample: vocabulary %d unsupported (<= %d)", m->vocab, pcy_sample_max_vocab());
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
   if (int r = ensure_decode_state(c, m)) return r;
   if (int r = ensure_sample_state(c, B, m->vocab)) return r;
@@ -1017,6 +1058,7 @@ int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
 
 int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, int group_size, float diversity_penalty,
                   const pcy_beam_state* st) {
+  PCY_STICKY(c);
   if (B <= 0 || beam <= 0 || beam > 32 || group_size <= 0 || beam % group_size)
     return fail(1, "pcy_beam_step: beam=%d (1..32) must be a multiple of group_size=%d", beam, group_size);
   if (vocab <= 0 || vocab > 163840) return fail(1, "pcy_beam_step: vocab %d unsupported (<= 163840)", vocab);
@@ -1038,6 +1080,7 @@ int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, in
 }
 
 int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t) {
+  PCY_STICKY(c);
   const int Hkv = m->n_kv_heads, dh = m->head_dim, L = m->n_layers;
   if (t <= 0) return 0;
   if ((t * dh) % 8) return fail(1, "pcy_kv_reorder: t * head_dim must be a multiple of 8");

@@ -926,6 +926,9 @@ bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
   if (n_cu < GEMV_CUS || a.d != 2 * NW || a.d != MC_WV * 512 || a.F != 2 * 7 * 1024 || a.F % (2 * 512 * MC_UNB_D)) return false;
   const size_t smem = (size_t)(2 * a.d + a.F) * 2 + 128;
   if (smem > 64 * 1024) return false;
+  static int resident = -1; static size_t resident_smem = 0;
+  if (resident < 0 || resident_smem != smem) { resident = pcy_all_resident(mlp_chain_kernel, MC_NT, smem, GEMV_CUS, n_cu) ? 1 : 0; resident_smem = smem; }
+  if (!resident) return false;
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, pcy_gemv_rms_threads(a.F));
   return true;
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int
     for (int j = 0; j < NV; ++j)
       ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
     if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-    if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
     __builtin_amdgcn_s_sleep(16);
     mc_fetch_issue<NV>(src, w0, lane, pre);
   }
@@ -54,7 +54,7 @@ __device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int 
       const uint4 v = ld16_agent(src + n - 256 + lane * 4);
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -78,7 +78,7 @@ __device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n
       const uint4 v = ld16_agent(src + word_of(nlines - 16 + (lane >> 2), lane & 3));
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n
         ok = ok && (t[j].x >> 16) == tag && (t[j].y >> 16) == tag && (t[j].z >> 16) == tag && (t[j].w >> 16) == tag;
       }
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-      if (++spins > (1u << 19)) { if (lane == 0 && err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
       __builtin_amdgcn_s_sleep(8);
     }
 #pragma unroll

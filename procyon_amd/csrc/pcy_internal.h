@@ -21,6 +21,15 @@ struct PcyGemvArgs {
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
+// Launches whose workgroups wait for each other INSIDE the launch need every workgroup resident at once: true when the occupancy
+// query says `grid` workgroups of `block` threads with `smem` bytes of dynamic LDS fit on `n_cu` compute units at the same time
+// (the check a cooperative launch would make, without its +15-19 us per launch; MI355X_MICROARCH.md, coop-launch row).
+template <typename Kernel>
+inline bool pcy_all_resident(Kernel kernel, int block, size_t smem, int grid, int n_cu) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, smem) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return nb >= 1 && (long)nb * n_cu >= (long)grid;
+}
 int pcy_mfma_min_batch();
 // finish of a K-split projection with the residual epilogue + RMSNorm of the result (gemv_splitk_finish_norm_kernel): partial sums
 // ws [splits][rows][N] fp32; y = bf16(bf16(sum) + resid) (ldy == N), xn = RMSNorm(y) * w.  false = shape not covered.
@@ -192,6 +201,7 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 // sampling / nucleus selection of one step (model_unified.py:896-906): token ~ multinomial(probs) by inverse CDF with the caller's
 // uniform variate uniforms[step * B + b]; nucleus_p <= 0: plain temperature sampling.  hist: [B][65536] uint32, zero on entry / exit;
 // partials: B * 64 * 16 bytes; probs_out: optional [B,V] record of the pre-sampling probability vector
+int pcy_sample_max_vocab();   // largest vocabulary the selection workgroup of the sampling step covers (SMP_NT * SMP_KMAX)
 void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
                             unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,
                             int32_t* pos_dev, int32_t* step_dev, int advance_pos, void* partials /* 64 x float4 per row */,

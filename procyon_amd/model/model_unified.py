@@ -90,6 +90,7 @@ class UnifiedProCyon:
         self.input_embeddings = SimpleNamespace(weight=text_encoder.get_input_embeddings())
         self.device = text_encoder.engine.device
         self.training = False
+        self.dtype = torch.float32     # until the caller asks for bf16 (see `bfloat16` below)
         self.use_llama_tokenizer = True
         self.train_qa_full_lm = False
         self.struct_dropout_prob = config.protein_struct_dropout
@@ -108,15 +109,53 @@ class UnifiedProCyon:
             self.yes_token = t.encode("yes", add_special_tokens=False)[0]
             self.no_token = t.encode("no", add_special_tokens=False)[0]
 
-    # nn.Module protocol used by the callers (retrieval_utils.py:90-101, procyon.py:64-67)
+    # nn.Module protocol used by the callers (retrieval_utils.py:90-101, procyon.py:64-67).  The reference model is built in the
+    # checkpoint's dtype (fp32) and every shipped entry point calls `.bfloat16()` before the first forward -- except
+    # examples/paper_analyses/protpep_qa_scores.py:55-58, which runs fp32.  The engine computes in bf16 only, so the model tracks
+    # the dtype its caller has asked for and REFUSES to run as anything but bf16 (never silently different arithmetic).
     def eval(self):
+        self.training = False
         return self
 
-    def to(self, *a, **k):
-        return self
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training is outside the engine's scope (inference / generation only)")
+        return self.eval()
 
     def bfloat16(self):
+        self.dtype = BF16
         return self
+
+    def float(self):
+        self.dtype = torch.float32
+        return self
+
+    def half(self):
+        self.dtype = torch.float16
+        return self
+
+    def to(self, *args, **kwargs):
+        """`nn.Module.to`: a dtype argument is recorded (see `_require_bf16`); a device must be the engine's device."""
+        cand = list(args) + [kwargs.get("dtype"), kwargs.get("device")]
+        for a in cand:
+            if isinstance(a, torch.dtype):
+                if not a.is_floating_point:
+                    raise TypeError(f"nn.Module.to only accepts floating point dtypes, but got desired dtype={a}")
+                self.dtype = a
+            elif isinstance(a, (str, torch.device, int)) and a is not None:
+                dev = torch.device("cuda", a) if isinstance(a, int) else torch.device(a)
+                mine = torch.device(self.device)
+                if dev.type != mine.type or (dev.index is not None and mine.index is not None and dev.index != mine.index):
+                    raise RuntimeError(f"the engine's weights live on {mine}; cannot move the model to {dev} "
+                                       "(build it with device=... instead)")
+        return self
+
+    def _require_bf16(self, what):
+        if self.dtype != BF16:
+            raise RuntimeError(
+                f"UnifiedProCyon.{what}: the model is in {self.dtype} (as constructed / loaded) but the MI355X engine computes in "
+                "bfloat16 only -- call model.bfloat16() first, as the reference's entry points do (evaluate/framework/procyon.py:64-65, "
+                "inference/retrieval_utils.py:90-101).  An fp32 weight path (examples/paper_analyses/protpep_qa_scores.py:55-58) is not built.")
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
@@ -266,6 +305,7 @@ class UnifiedProCyon:
         out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D]."""
         if return_mlm:
             raise NotImplementedError("return_mlm is a training path (model_unified.py:505-509)")
+        self._require_bf16("forward")
         input_embeds, input_ids, attn_masks, ret_idx, tok_emb, ret_emb = self._preprocessing(
             inputs, aaseq_type=aaseq_type, crop_off=crop_off, retrieval=retrieval, exclude_protein_structure=False)
         full_labels = None
@@ -332,6 +372,7 @@ class UnifiedProCyon:
 
     def forward_sequences(self, seq_input, get_soft_tokens=False, aaseq_type="protein"):
         """`forward_sequences` (model_unified.py:1029-1086)."""
+        self._require_bf16("forward_sequences")
         if isinstance(seq_input, dict):
             seq_input = seq_input["data"]
         z = self._encode_aaseq(seq_input, aaseq_type)
@@ -476,6 +517,7 @@ class UnifiedProCyon:
         means `nucleus_prob` (default 0.9) reaches `_generate_sampling` for every non-beam method, as written there;
         pass nucleus_prob=None for plain temperature sampling."""
         assert method in ["sampling", "temperature", "greedy", "beam", "nucleus"]
+        self._require_bf16("generate")
         if method == "beam":
             num_text_per_instance = beam_size
         elif method == "greedy":

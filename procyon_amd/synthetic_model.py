@@ -45,6 +45,7 @@ def build(geometry="full", device="cuda", pooling="mean", max_new_tokens=256, ll
     cfg = ProCyonConfig(protein_pooling_opt=pooling, use_aaseq_embeddings=False)
     model = UnifiedProCyon(cfg, text_encoder, tok, protein_seq_encoder=plm, token_projectors={"aaseq": mk(projs["aaseq"])},
                            aaseq_shared_projector=mk(projs["shared"]), aaseq_lm_projector=mk(projs["lm"]))
+    model.eval().bfloat16()      # what every shipped caller of the reference does after construction (procyon.py:64-65)
     if return_weights:
         return model, dict(llama=lsd, esm=esd, projs=projs, geom=g)
     return model

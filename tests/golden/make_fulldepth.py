@@ -9,11 +9,11 @@ seeded synthetic weights of procyon_amd/synth.py, twice:
   * fp32  -- the same weights (bf16 values, upcast) with every op in fp32: the "truth" both bf16 pipelines
              approximate.
 
-Llama-3-8B, 32 layers, prompts of T = 64 and T = 512 ids: last-row logits of the prefill + 8 cached decode steps,
+Llama-3-8B, 32 layers, prompts of T = 64 and T = 512 ids: last-row logits of the prefill + 64 cached decode steps,
 teacher-forced on the bf16 oracle's greedy tokens.  ESM2-650M, 33 layers, one 1024-residue protein: pooled
 embedding, shared-space embedding and the soft token of the 3-layer projectors.
 
-A logits vector has 128263 entries; the fixture keeps a column subset (every 61st column + the top-32 columns of
+A logits vector has 128263 entries; the fixture keeps a column subset (every 127th column + the top-8 columns of
 either run at every step) plus full-vector statistics (norms, argmax, top-8, bf16-vs-fp32 error over ALL columns),
 so the files stay a few hundred KB.  The -m gpu test (tests/test_gpu_fulldepth.py) regenerates the same weights
 from the same seeds and asserts  err(HIP, fp32) <= 1.25 x err(oracle_bf16, fp32).
@@ -41,7 +41,7 @@ from procyon_amd import synth  # noqa: E402
 
 LLAMA = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
 ESM = dict(d=1280, n_layers=33, n_heads=20, ffn=5120)
-NDEC = 8
+NDEC = 64   # teacher-forced cached decode steps (round 3: 8 -> 64, so that argmax agreement is a rate)
 
 
 def np_(t):
@@ -97,6 +97,26 @@ def llama_run(sd, geom, ids, dtype, forced=None):
     return torch.stack(logits_all), torch.stack(hid_all), torch.tensor(toks)
 
 
+@torch.no_grad()
+def llama_truth(sd, geom, ids, toks):
+    """fp32 truth of the same NDEC+1 positions in ONE causal pass over ids ++ toks[:-1] (teacher forcing makes every input
+    known up front; a causal prefill and an incremental decode are the same function, and in fp32 their difference
+    (~1e-6) is far below what the comparison resolves).  Returns logits [NDEC+1, V], hidden rows [NDEC+1, d]."""
+    dtype = torch.float32
+    c = lambda t: t.to(dtype)
+    full = torch.cat([ids, toks[None, :-1]], dim=1)
+    T0, Tq = ids.shape[1], full.shape[1]
+    h = c(F.embedding(full, sd["model.embed_tokens.weight"]))
+    cos_t, sin_t = LR.rope_tables(geom, dtype, Tq)
+    cos, sin = cos_t[None, :Tq], sin_t[None, :Tq]
+    add_mask = LR.build_additive_mask(None, 1, Tq, 0, dtype)
+    for i in range(geom.n_layers):
+        lw = {k: c(v) for k, v in LR._layer_weights(sd, i).items()}
+        h, _ = LR.layer_forward(h, lw, geom, cos, sin, add_mask, None)
+    h = LR.rms_norm(h[:, T0 - 1:], c(sd["model.norm.weight"]), geom.rms_eps, geom.rms_cast)[0]
+    return F.linear(h, c(sd["lm_head.weight"])), h
+
+
 def make_llama():
     t0 = time.time()
     sd = synth.llama_state_dict(**LLAMA)
@@ -109,12 +129,12 @@ def make_llama():
         lb, hb, toks = llama_run(sd, geom, ids, torch.bfloat16)
         print(f"  T={T} bf16 oracle {time.time() - t0:.0f}s", flush=True)
         t0 = time.time()
-        lf, hf, _ = llama_run(sd, geom, ids, torch.float32, forced=toks)
+        lf, hf = llama_truth(sd, geom, ids, toks)
         print(f"  T={T} fp32 truth {time.time() - t0:.0f}s", flush=True)
         V = lb.shape[1]
-        cols = set(range(0, V, 61))
+        cols = set(range(0, V, 127))
         for s in range(NDEC + 1):
-            cols |= set(lf[s].topk(32).indices.tolist()) | set(lb[s].float().topk(32).indices.tolist())
+            cols |= set(lf[s].topk(8).indices.tolist()) | set(lb[s].float().topk(8).indices.tolist())
         cols = torch.tensor(sorted(cols))
         top_f = lf.topk(8, dim=-1)
         top_b = lb.float().topk(8, dim=-1)
@@ -124,7 +144,7 @@ def make_llama():
         print(f"         argmax agree {(lb.float().argmax(-1) == lf.argmax(-1)).tolist()} "
               f"fp32 top-2 margin {(top_f.values[:, 0] - top_f.values[:, 1]).tolist()}")
         save(f"f1_llama8b_T{T}", ids=ids.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
-             logits_bf16=lb[:, cols], logits_fp32=lf[:, cols], hidden_bf16=hb, hidden_fp32=hf,
+             logits_bf16=lb[:, cols], logits_fp32=lf[:, cols], hidden_bf16=hb[:1], hidden_fp32=hf[:1],
              norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
              top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values,
              top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)

@@ -212,6 +212,14 @@ def test_checkpoint_ingest_builds_identical_model(env):
             sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = wt, b
     m2 = build_model(sd, ProCyonConfig(protein_pooling_opt="mean"), m.tokenizer, device="cuda", max_new_tokens=16, esm_heads=2, head_dim=64, max_pos=4096,
                      esm_rope_math="fp32_once")      # (fair-esm names select the fair-esm rotary arithmetic by default)
+    # a freshly built / loaded model is "fp32" like the reference's; the engine is bf16-only and must refuse, not run silently
+    with pytest.raises(RuntimeError, match="bfloat16"):
+        m2.forward_sequences(env["prot"])
+    with pytest.raises(RuntimeError, match="bfloat16"):
+        m2.generate(_inputs(m2, env["prot"], ["w5 <|protein|> [ANSWER]"], [[0]], text_slots=[[]]), max_len=2, method="greedy")
+    assert m2.eval().bfloat16().to("cuda") is m2 and m2.dtype == torch.bfloat16
+    with pytest.raises(RuntimeError):
+        m2.to("cpu")
     a, b = m.forward_sequences(env["prot"], get_soft_tokens=True), m2.forward_sequences(env["prot"], get_soft_tokens=True)
     for k in ("original", "shared", "token"):
         assert torch.equal(a[k], b[k]), k
@@ -233,6 +241,9 @@ def test_checkpoint_ingest_builds_identical_model(env):
         m3, cfg = UnifiedProCyon.from_pretrained(pretrained_weights_dir=d, checkpoint_dir=d, tokenizer=m.tokenizer, max_new_tokens=16,
                                                  esm_heads=2, head_dim=64, max_pos=4096, esm_rope_math="fp32_once")
     assert cfg.protein_pooling_opt == "mean" and cfg.n_model_pieces == 1
+    assert m3.dtype == torch.float32
+    m3.eval()
+    m3.bfloat16()
     c = m3.forward_sequences(env["prot"], get_soft_tokens=True)
     for k in ("original", "shared", "token"):
         assert torch.equal(a[k], c[k]), k

@@ -231,3 +231,78 @@ def test_zero2_shard_merge_and_lora_fold(tmp_path):
                       "text_encoder.model.base_model.model.model.norm.weight": torch.ones(4)}, lora_alpha=4)
     assert set(out) == {"text_encoder.model.model.layers.0.self_attn.q_proj.weight", "text_encoder.model.model.norm.weight"}
     assert torch.allclose(out["text_encoder.model.model.layers.0.self_attn.q_proj.weight"], W + 2.0 * (B @ A))
+
+
+def test_lora_alpha_defaults_follow_the_reference_constructors():
+    """the DEFAULT path of merge_lora.  Text adapters always run with alpha = 8 (pmc_llama.py:430-431; model_unified.py:147-158
+    never forwards another value), protein-encoder adapters with config.aaseq_lora_alpha (model_unified.py:226-228); an adapter
+    whose alpha is unknown raises instead of silently folding with scale 1."""
+    from types import SimpleNamespace
+    from procyon_amd.checkpoint import merge_lora
+    g = torch.Generator().manual_seed(1)
+    r = 16
+    Wt, At, Bt = torch.randn(8, 6, generator=g), torch.randn(r, 6, generator=g), torch.randn(8, r, generator=g)
+    We, Ae, Be = torch.randn(5, 5, generator=g), torch.randn(4, 5, generator=g), torch.randn(5, 4, generator=g)
+    tk = "text_encoder.model.base_model.model.model.layers.0.self_attn.v_proj"
+    ek = "protein_seq_encoder.model.base_model.model.layers.0.self_attn.q_proj"
+    sd = {tk + ".weight": Wt, tk + ".lora_A.default.weight": At, tk + ".lora_B.default.weight": Bt,
+          ek + ".weight": We, ek + ".lora_A.default.weight": Ae, ek + ".lora_B.default.weight": Be}
+    out = merge_lora(dict(sd), config=SimpleNamespace(aaseq_lora_alpha=6.0, aaseq_lora_r=4))
+    assert torch.allclose(out["text_encoder.model.model.layers.0.self_attn.v_proj.weight"], Wt + (8.0 / r) * (Bt @ At))
+    assert torch.allclose(out["protein_seq_encoder.model.layers.0.self_attn.q_proj.weight"], We + (6.0 / 4) * (Be @ Ae))
+    with pytest.raises(ValueError):          # protein-encoder adapter, no alpha in the config
+        merge_lora(dict(sd), config=SimpleNamespace())
+    with pytest.raises(ValueError):          # adapter under an unknown prefix
+        merge_lora({"foo.bar.weight": We, "foo.bar.lora_A.default.weight": Ae, "foo.bar.lora_B.default.weight": Be})
+
+
+def test_eval_plugins_follow_the_registry_constructor_contract(monkeypatch, capsys):
+    """`model_zoo[task][model_type](model_config, eval_args, model_args, device)` (core.py:210-216): every plugin loads
+    `model_config["checkpoint_dir"]` through `UnifiedProCyon.from_pretrained`, compares ModelArgs, then eval() / bfloat16() /
+    to(device) (procyon.py:49-77,114-140,208-240).  The loader is stubbed here (no GPU); tests/test_gpu_evaluate.py runs the real one."""
+    from types import SimpleNamespace
+    from procyon.evaluate.framework.args import EvalArgs
+    from procyon.evaluate.framework.procyon import ProcyonCaptionEval, ProcyonQAEval, ProcyonRetrievalEval
+    from procyon.evaluate.framework.utils import compare_and_warn_model_args
+    from procyon.training.training_args_IT import ModelArgs
+    import procyon_amd.model as M
+    calls = []
+
+    class FakeModel:
+        device = torch.device("cpu")
+        yes_token, no_token = 11, 12
+        config = SimpleNamespace(use_aaseq_embeddings=False)
+
+        def __init__(self):
+            self.log = []
+
+        def eval(self):
+            self.log.append("eval"); return self
+
+        def bfloat16(self):
+            self.log.append("bf16"); return self
+
+        def to(self, dev):
+            self.log.append(("to", str(dev))); return self
+
+    def fake_from_pretrained(**kw):
+        calls.append(kw)
+        return FakeModel(), ModelArgs(protein_pooling_opt="mean", n_model_pieces=1) if False else SimpleNamespace(**{**vars(ModelArgs(protein_pooling_opt="mean")), "n_model_pieces": 1})
+
+    monkeypatch.setattr(M.UnifiedProCyon, "from_pretrained", staticmethod(fake_from_pretrained))
+    margs = ModelArgs(protein_pooling_opt="max")
+    cfg = {"model_type": "ProCyon", "checkpoint_dir": "/ckpt/x", "num_captions": 3}
+    ea = EvalArgs(caption_max_len=7, qa_num_samples=5, seed=3, batch_size=4)
+    for cls in (ProcyonCaptionEval, ProcyonQAEval, ProcyonRetrievalEval):
+        ev = cls(cfg, ea, margs, torch.device("cpu"))
+        assert ev.model.log == ["eval", "bf16", ("to", "cpu")] and ev.checkpoint_dir == "/ckpt/x" and ev.model_args is margs
+        assert "protein_pooling_opt: max != mean" in capsys.readouterr().out
+    assert [c["checkpoint_dir"] for c in calls] == ["/ckpt/x"] * 3
+    assert "strict_load" not in calls[0] and calls[2]["strict_load"] is False
+    cap, qa, ret = ProcyonCaptionEval(cfg, ea, margs, "cpu"), ProcyonQAEval(cfg, ea, margs, "cpu"), ProcyonRetrievalEval(cfg, ea, margs, "cpu")
+    assert (cap.max_len, cap.method, cap.num_captions, cap.beam_group_size, cap.beam_size) == (7, "beam", 3, 2, 6)
+    assert (qa.num_samples, qa.yes_token, qa.no_token) == (5, 11, 12)
+    assert ret.batch_size == 4 and ret.use_cached_target_embeddings
+    # ignored fields: *path, n_model_pieces, model_splitting
+    a, b = ModelArgs(protein_seq_embeddings_path="/a"), ModelArgs(protein_seq_embeddings_path="/b")
+    assert compare_and_warn_model_args(a, b) == []
