@@ -107,6 +107,15 @@ int pcy_allgather(pcy_ctx*, void* comm, const void* sendbuf, void* recvbuf, size
  * int32, score_out [Q,k] bf16.  1 <= k <= N; k == N is the full ranking (top_k=None). */
 int pcy_retrieval_topk(pcy_ctx*, const void* query, int Q, const void* targets, int N, int D, int k, int32_t* idx_out, void* score_out);
 
+/* The same two operations with fp32 similarities (the shim's `get_proteins_from_embedding` / `get_proteins_from_batched_embeddings`,
+ * data/inference_utils.py:921-999: cached target matrices are fp32 and the batched form returns `.float()` scores):
+ * sims[q][n] = (q / max(|q|, 1e-12)) . (t_n / max(|t_n|, 1e-12)), fp32 accumulation, fp32 result; query [Q,D] fp32, targets [N,D]
+ * fp32 (targets_bf16 = 0) or bf16 (1); D % 4 == 0.  topk: idx_out [Q,k] int32, score_out [Q,k] fp32, stable descending order
+ * (ties, incl. -0.0 vs +0.0: the lower index first). */
+int pcy_retrieval_scores_f32(pcy_ctx*, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, float* sims_out);
+int pcy_retrieval_topk_f32(pcy_ctx*, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, int k, int32_t* idx_out,
+                           float* score_out);
+
 /* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path"; the reference has no fp8 counterpart) ----
  * Per-row symmetric OCP e4m3 quantisation of a bf16 matrix x[rows,K] (ldx elements between rows, K % 8 == 0):
  * scale_out[r] = the smallest power of two >= 2^-126 with amax|x[r,:]| / scale <= 448 (1 for an all-zero row),

@@ -302,14 +302,13 @@ class ProCyonQAInference:
 
 # ---------------------------------------------------------------------------------------------- retrieval ranking
 def _rank(query, targets, k):
-    """(indices [Q,k], scores [Q,k]) of the k most similar rows of `targets` per query, best first; k None = all: bf16 normalise +
-    GEMM + ranking in the engine's HIP kernels (no CPU path: `Context.get()` raises without a device, like the reference's
-    hard-coded `.cuda()`)."""
+    """(indices [Q,k], scores [Q,k]) of the k most similar rows of `targets` per query, best first; k None = all.  fp32 similarities
+    (fp32 accumulation and result, `pcy_retrieval_topk_f32`) ranked on the device in a stable descending order -- the reference
+    computes in the embeddings' dtype and its cached target matrix is fp32; bf16 cosines would tie by the hundred among 18k
+    proteins.  No CPU path: `Context.get()` raises without a device, like the reference's hard-coded `.cuda()`."""
     from procyon_amd.engine import Context
-    ctx = Context.get()
-    dev = ctx.device
-    idx, sc = ctx.retrieval_topk(query.to(dev, torch.bfloat16).contiguous(), targets.to(dev, torch.bfloat16).contiguous(), k)
-    return idx.cpu(), sc.float().cpu()
+    idx, sc = Context.get().retrieval_topk_f32(query, targets, k)
+    return idx.cpu(), sc.cpu()
 
 
 def get_proteins_from_embedding(protein_embeds: torch.Tensor, model_out: Optional[Dict] = None,
@@ -335,9 +334,7 @@ def get_proteins_from_batched_embeddings(protein_embeds: torch.Tensor, query_emb
     """[Q, N] fp32 cosine similarities on the CPU (inference_utils.py:981-999)."""
     assert query_embeddings is not None
     from procyon_amd.engine import Context
-    ctx = Context.get()
-    sims = ctx.retrieval_scores(query_embeddings.to(ctx.device, torch.bfloat16).contiguous(),
-                                protein_embeds.to(ctx.device, torch.bfloat16).contiguous())
+    sims = Context.get().retrieval_scores_f32(query_embeddings if query_embeddings.dim() == 2 else query_embeddings[None], protein_embeds)
     return sims.squeeze().detach().cpu().float()
 
 

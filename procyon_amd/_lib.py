@@ -88,6 +88,8 @@ SIGNATURES = {
     "pcy_comm_destroy": (None, [vp]),
     "pcy_allgather": (ci, [vp, vp, vp, vp, C.c_size_t]),
     "pcy_retrieval_topk": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp]),
+    "pcy_retrieval_scores_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, vp]),
+    "pcy_retrieval_topk_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
     "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),

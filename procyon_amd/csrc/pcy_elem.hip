@@ -816,7 +816,8 @@ __global__ __launch_bounds__(NT) void l2norm_rows_kernel(const bf16_t* __restric
 // `rank` if rank < k.  N^2 comparisons of 16-bit keys from LDS tiles: 18174 targets (the reference's cached matrix) = 3.3e8,
 // 100k targets = 1e10 (< 1 ms of VALU), no sort, no atomics, k up to N (top_k=None: the full ranking).
 // Order-preserving key of a bf16: flip all bits of negatives, the sign bit of positives; NaNs land at the extremes like in torch.
-__device__ __forceinline__ uint32_t bf16_order_key(bf16_t b) { return (b & 0x8000u) ? (uint32_t)(b ^ 0xffffu) & 0xffffu : (uint32_t)(b | 0x8000u); }
+// (-0.0 and +0.0 compare equal in torch: both get the key of +0.0 and the index decides)
+__device__ __forceinline__ uint32_t bf16_order_key(bf16_t b) { if (b == 0x8000u) b = 0; return (b & 0x8000u) ? (uint32_t)(b ^ 0xffffu) & 0xffffu : (uint32_t)(b | 0x8000u); }
 constexpr int RANK_TILE = 4096;
 __global__ __launch_bounds__(NT) void retrieval_rank_kernel(const bf16_t* __restrict__ sims, int N, int k, int32_t* __restrict__ idx_out,
                                                             bf16_t* __restrict__ score_out) {
@@ -835,6 +836,95 @@ __global__ __launch_bounds__(NT) void retrieval_rank_kernel(const bf16_t* __rest
     if (t0 + tn <= i0) {                       // every j of the tile lies before every i of this block: ties count
       for (int j = 0; j < tn; ++j) rank += keys[j] >= ki;
     } else if (t0 >= i0 + NT) {                // every j lies behind: ties do not count
+      for (int j = 0; j < tn; ++j) rank += keys[j] > ki;
+    } else {
+      for (int j = 0; j < tn; ++j) rank += (keys[j] > ki) | ((keys[j] == ki) & (t0 + j < i));
+    }
+  }
+  if (i < N && rank < k) {
+    idx_out[(size_t)q * k + rank] = i;
+    score_out[(size_t)q * k + rank] = mine;
+  }
+}
+
+// ---- fp32 scoring for the shim's retrieval entry points (data/inference_utils.py:921-999: `get_proteins_from_batched_embeddings`
+// works on `.float()` similarities, and a cached target matrix is fp32): cosine similarities with fp32 accumulation AND an
+// fp32 result -- bf16 cosines keep ~3 digits, so among 18k-100k targets many scores would tie and be ordered by index.
+//   sims[q][n] = (q / max(|q|, eps)) . (t_n / max(|t_n|, eps))
+// One wave per target row (16-byte loads along the row), RET_QT queries per pass staged pre-normalised in LDS; the row's own
+// squared norm rides along in the same pass.  HBM-bound: the target matrix is read once per RET_QT queries.
+constexpr int RET_QT = 8;
+template <bool TBF16>
+__global__ __launch_bounds__(NT) void retrieval_dot_f32_kernel(const float* __restrict__ query, int Q, const void* __restrict__ targets, int N, int D,
+                                                               float eps, float* __restrict__ sims) {
+  extern __shared__ float qs[];                 // [RET_QT][D], normalised
+  __shared__ float red[NT / 64];
+  const int q0 = blockIdx.y * RET_QT;
+  const int nq = (Q - q0) < RET_QT ? (Q - q0) : RET_QT;
+  for (int qi = 0; qi < nq; ++qi) {             // stage + normalise (block-wide reduction per query)
+    const float* qr = query + (size_t)(q0 + qi) * D;
+    float ss = 0.f;
+    for (int k = threadIdx.x; k < D; k += NT) { const float v = qr[k]; ss += v * v; }
+    ss = block_sum<NT>(ss, red);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+    for (int k = threadIdx.x; k < D; k += NT) qs[qi * D + k] = qr[k] * inv;
+  }
+  for (int qi = nq; qi < RET_QT; ++qi)
+    for (int k = threadIdx.x; k < D; k += NT) qs[qi * D + k] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = blockIdx.x * (NT / 64) + wave; n < N; n += gridDim.x * (NT / 64)) {
+    float acc[RET_QT], ss = 0.f;
+#pragma unroll
+    for (int qi = 0; qi < RET_QT; ++qi) acc[qi] = 0.f;
+    for (int k = lane * 4; k < D; k += 64 * 4) {
+      float t[4];
+      if (TBF16) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(targets) + (size_t)n * D + k);
+        t[0] = lo_bf(v.x); t[1] = hi_bf(v.x); t[2] = lo_bf(v.y); t[3] = hi_bf(v.y);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(targets) + (size_t)n * D + k);
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+      }
+      ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+#pragma unroll
+      for (int qi = 0; qi < RET_QT; ++qi) {
+        const float4 qv = *reinterpret_cast<const float4*>(qs + qi * D + k);
+        acc[qi] += t[0] * qv.x + t[1] * qv.y + t[2] * qv.z + t[3] * qv.w;
+      }
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+#pragma unroll
+    for (int qi = 0; qi < RET_QT; ++qi) {
+      const float v = wave_sum(acc[qi]);
+      if (lane == 0 && qi < nq) sims[(size_t)(q0 + qi) * N + n] = v * inv;
+    }
+  }
+}
+// order-preserving key of an fp32 (-0.0 == +0.0, NaN at the extremes like torch's sort)
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+  uint32_t b = __float_as_uint(f);
+  if (b == 0x80000000u) b = 0;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(NT) void retrieval_rank_f32_kernel(const float* __restrict__ sims, int N, int k, int32_t* __restrict__ idx_out,
+                                                                float* __restrict__ score_out) {
+  __shared__ uint32_t keys[RANK_TILE];
+  const int q = blockIdx.y;
+  const float* row = sims + (size_t)q * N;
+  const int i0 = blockIdx.x * NT, i = i0 + threadIdx.x;
+  const float mine = i < N ? row[i] : 0.f;
+  const uint32_t ki = f32_order_key(mine);
+  int rank = 0;
+  for (int t0 = 0; t0 < N; t0 += RANK_TILE) {
+    const int tn = (N - t0) < RANK_TILE ? (N - t0) : RANK_TILE;
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += NT) keys[j] = f32_order_key(row[t0 + j]);
+    __syncthreads();
+    if (t0 + tn <= i0) {
+      for (int j = 0; j < tn; ++j) rank += keys[j] >= ki;
+    } else if (t0 >= i0 + NT) {
       for (int j = 0; j < tn; ++j) rank += keys[j] > ki;
     } else {
       for (int j = 0; j < tn; ++j) rank += (keys[j] > ki) | ((keys[j] == ki) & (t0 + j < i));
@@ -1319,6 +1409,25 @@ void pcy_launch_l2norm_rows(hipStream_t s, const bf16_t* x, bf16_t* y, int rows,
 void pcy_launch_retrieval_rank(hipStream_t s, const bf16_t* sims, int Q, int N, int k, int32_t* idx_out, bf16_t* score_out) {
   if (Q > 0 && N > 0 && k > 0)
     hipLaunchKernelGGL(retrieval_rank_kernel, dim3((N + NT - 1) / NT, Q), dim3(NT), 0, s, sims, N, k, idx_out, score_out);
+}
+void pcy_launch_retrieval_dot_f32(hipStream_t s, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, float eps, float* sims) {
+  if (Q <= 0 || N <= 0) return;
+  const size_t smem = (size_t)RET_QT * D * sizeof(float);
+  const dim3 grid((unsigned)((N + NT / 64 - 1) / (NT / 64) < 2048 ? (N + NT / 64 - 1) / (NT / 64) : 2048), (Q + RET_QT - 1) / RET_QT);
+  if (targets_bf16) {
+    static bool conf = false;
+    if (!conf && smem > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&retrieval_dot_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); conf = true; }
+    hipLaunchKernelGGL(retrieval_dot_f32_kernel<true>, grid, dim3(NT), smem, s, query, Q, targets, N, D, eps, sims);
+  } else {
+    static bool conf = false;
+    if (!conf && smem > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&retrieval_dot_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); conf = true; }
+    hipLaunchKernelGGL(retrieval_dot_f32_kernel<false>, grid, dim3(NT), smem, s, query, Q, targets, N, D, eps, sims);
+  }
+}
+size_t pcy_retrieval_dot_smem(int D) { return (size_t)RET_QT * D * sizeof(float); }
+void pcy_launch_retrieval_rank_f32(hipStream_t s, const float* sims, int Q, int N, int k, int32_t* idx_out, float* score_out) {
+  if (Q > 0 && N > 0 && k > 0)
+    hipLaunchKernelGGL(retrieval_rank_f32_kernel, dim3((N + NT - 1) / NT, Q), dim3(NT), 0, s, sims, N, k, idx_out, score_out);
 }
 size_t pcy_beam_ws_bytes(int B, int beam) {
   return (size_t)B * beam * BEAM_NCH * sizeof(float2) + 256 + (size_t)B * beam * BEAM_NCH * beam * sizeof(BeamCand);

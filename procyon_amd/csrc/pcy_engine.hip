@@ -741,6 +741,26 @@ int pcy_retrieval_scores(pcy_ctx* c, const void* query, int Q, const void* targe
   return check_launch("pcy_retrieval_scores");
 }
 
+int pcy_retrieval_scores_f32(pcy_ctx* c, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, float* sims_out) {
+  PCY_STICKY(c);
+  if (D % 4 || D <= 0) return fail(1, "pcy_retrieval_scores_f32: D=%d must be a positive multiple of 4", D);
+  if (pcy_retrieval_dot_smem(D) > 159 * 1024) return fail(1, "pcy_retrieval_scores_f32: D=%d does not fit the query tile in LDS", D);
+  pcy_launch_retrieval_dot_f32(c->stream, query, Q, targets, targets_bf16, N, D, 1e-12f, sims_out);
+  return check_launch("pcy_retrieval_scores_f32");
+}
+int pcy_retrieval_topk_f32(pcy_ctx* c, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, int k, int32_t* idx_out,
+                           float* score_out) {
+  PCY_STICKY(c);
+  if (D % 4 || D <= 0) return fail(1, "pcy_retrieval_topk_f32: D=%d must be a positive multiple of 4", D);
+  if (pcy_retrieval_dot_smem(D) > 159 * 1024) return fail(1, "pcy_retrieval_topk_f32: D=%d does not fit the query tile in LDS", D);
+  if (k < 1 || k > N) return fail(1, "pcy_retrieval_topk_f32: k=%d must be in [1, N=%d]", k, N);
+  if (int r = c->reserve(align_up((size_t)Q * N * 4, 256) + 4096)) return r;
+  float* sims = reinterpret_cast<float*>(c->ws);
+  pcy_launch_retrieval_dot_f32(c->stream, query, Q, targets, targets_bf16, N, D, 1e-12f, sims);
+  pcy_launch_retrieval_rank_f32(c->stream, sims, Q, N, k, idx_out, score_out);
+  return check_launch("pcy_retrieval_topk_f32");
+}
+
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
   PCY_STICKY(c);
   if (m->n_layers < 1 || m->n_layers > 8) return fail(1, "pcy_mlp_forward: n_layers %d", m->n_layers);

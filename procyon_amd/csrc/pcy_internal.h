@@ -201,6 +201,9 @@ void pcy_launch_greedy_pick(hipStream_t s, const bf16_t* logits, int B, int V, i
 // sampling / nucleus selection of one step (model_unified.py:896-906): token ~ multinomial(probs) by inverse CDF with the caller's
 // uniform variate uniforms[step * B + b]; nucleus_p <= 0: plain temperature sampling.  hist: [B][65536] uint32, zero on entry / exit;
 // partials: B * 64 * 16 bytes; probs_out: optional [B,V] record of the pre-sampling probability vector
+void pcy_launch_retrieval_dot_f32(hipStream_t s, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, float eps, float* sims);
+size_t pcy_retrieval_dot_smem(int D);
+void pcy_launch_retrieval_rank_f32(hipStream_t s, const float* sims, int Q, int N, int k, int32_t* idx_out, float* score_out);
 int pcy_sample_max_vocab();   // largest vocabulary the selection workgroup of the sampling step covers (SMP_NT * SMP_KMAX)
 void pcy_launch_sample_step(hipStream_t s, const bf16_t* logits, int B, int V, float temperature, float nucleus_p, const float* uniforms,
                             unsigned* hist, bf16_t* probs_out, int32_t* next_tok, int32_t* tokens_out, int max_steps, float* logprob,

@@ -181,6 +181,34 @@ class Context:
         L.check(self.lib.pcy_retrieval_topk(self.h, _p(query), Q, _p(targets), N, D, k, _p(idx), _p(sc)), "pcy_retrieval_topk")
         return idx.long(), sc
 
+    def _ret_f32_args(self, query, targets):
+        q = query.to(self.device, torch.float32).contiguous()
+        t = targets.to(self.device)
+        if t.dtype != BF16:
+            t = t.to(torch.float32)
+        t = t.contiguous()
+        assert q.dim() == 2 and t.dim() == 2 and q.shape[1] == t.shape[1], (q.shape, t.shape)
+        return q, t, int(t.dtype == BF16)
+
+    def retrieval_scores_f32(self, query, targets):
+        """fp32 cosine similarities [Q,N] (fp32 accumulation, fp32 result); query any float dtype, targets fp32 or bf16 -- the
+        scoring of `get_proteins_from_batched_embeddings` (data/inference_utils.py:981-999)."""
+        q, t, tb = self._ret_f32_args(query, targets)
+        out = torch.empty(q.shape[0], t.shape[0], dtype=torch.float32, device=self.device)
+        L.check(self.lib.pcy_retrieval_scores_f32(self.h, _p(q), q.shape[0], _p(t), tb, t.shape[0], q.shape[1], _p(out)), "pcy_retrieval_scores_f32")
+        return out
+
+    def retrieval_topk_f32(self, query, targets, k=None):
+        """(indices int64 [Q,k], scores fp32 [Q,k]) ranked on fp32 similarities, best first, ties by lower index
+        (`get_proteins_from_embedding`, data/inference_utils.py:921-978); k=None ranks all N targets."""
+        q, t, tb = self._ret_f32_args(query, targets)
+        N = t.shape[0]
+        k = N if k is None else min(int(k), N)
+        idx = torch.empty(q.shape[0], k, dtype=torch.int32, device=self.device)
+        sc = torch.empty(q.shape[0], k, dtype=torch.float32, device=self.device)
+        L.check(self.lib.pcy_retrieval_topk_f32(self.h, _p(q), q.shape[0], _p(t), tb, N, q.shape[1], k, _p(idx), _p(sc)), "pcy_retrieval_topk_f32")
+        return idx.long(), sc
+
     def pool(self, hidden, seg, rng, nprot, mode):
         _chk_bf16(hidden)
         d = hidden.shape[-1]
@@ -535,8 +563,7 @@ class LlamaEngine:
         self.sample_pick(cache, st, B, False, u, temperature, nucleus_prob)
         if max_len > 1:
             self.sample_steps(cache, st, B, max_len - 1, u, temperature, nucleus_prob)
-        if st._logits_host is not None:
-            torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.sync()       # the record may live in host memory; and a watchdog of the fused decode launches must fail THIS call
         la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
         return st.tokens_out.long(), st.logprob, la, (st, cache, u)
 
@@ -561,8 +588,9 @@ class LlamaEngine:
         self.pick(cache, st, B, advance_pos=False)
         if max_len > 1:
             self.greedy_steps(cache, st, B, max_len - 1, use_graph)
-        if st._logits_host is not None:
-            torch.cuda.current_stream(self.device).synchronize()      # the record lives in host memory: complete before it is handed out
+        # complete before anything is handed out: the logits record may live in host memory, and a watchdog that fired inside a
+        # fused decode launch (workgroups not all resident) must fail THIS call, not a later one (pcy_ctx_sync reads the sticky word)
+        self.ctx.sync()
         la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
         return st.tokens_out.long(), st.logprob, la, (st, cache)
 

@@ -505,7 +505,7 @@ class UnifiedProCyon:
         full = torch.zeros(BB, max_len, dtype=torch.int64)
         full[:, :steps] = out.cpu()
         out, cur = full, bs.cur.cpu()
-        torch.cuda.current_stream(dev).synchronize()
+        eng.ctx.sync()      # stream complete + the sticky watchdog word of the fused launches checked (raises PcyError)
         return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
 
     @torch.no_grad()

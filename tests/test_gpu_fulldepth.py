@@ -10,7 +10,8 @@ reference's own bf16 path,
 
     err(HIP, fp32) <= 1.25 x err(oracle_bf16, fp32),
 
-on the prefill's last-row logits and on 8 teacher-forced cached decode steps (Llama) and on the pooled / shared / soft-token
+on the prefill's last-row logits and on 64 teacher-forced cached decode steps (Llama; argmax agreement with the truth is
+asserted as a rate: agree(HIP, fp32) >= agree(oracle_bf16, fp32) - 2 of 65) and on the pooled / shared / soft-token
 embeddings (ESM + projectors).  err(HIP, oracle_bf16), argmax agreement and a near-tie histogram are printed.
 """
 import pytest
@@ -39,7 +40,7 @@ def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
     from procyon_amd.engine import GenState
     g = golden(f"f1_llama8b_T{T}")
     ids, toks, cols = g["ids"].long(), g["tokens"].long(), g["cols"].long()
-    nstep = toks.numel()                          # prefill + 8 decode steps
+    nstep = toks.numel()                          # prefill + 64 decode steps
     cache = llama.new_cache(1, T + nstep + 1)
     logits, hidden = llama.prefill(llama.embed_tokens(ids), None, cache, "last", want_hidden=True)
     got = [logits[0].cpu()]
@@ -49,10 +50,10 @@ def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
         st.next_tok.copy_(toks[s - 1:s].to(torch.int32))
         llama.decode(cache, st, 1)
         got.append(st.logits[0].cpu())
-    got = torch.stack(got).float()                # [9, V]
+    got = torch.stack(got).float()                # [65, V]
     truth, ref = g["logits_fp32"], g["logits_bf16"].float()
-    hist = {"<1ulp": 0, "<4 noise": 0, "clear": 0}
     worst = 0.0
+    agree_hip_truth = agree_ref_truth = agree_hip_ref = 0
     for s in range(nstep):
         e_hip = rel_err(got[s, cols], truth[s])
         e_ref = rel_err(ref[s], truth[s])
@@ -60,17 +61,22 @@ def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
         worst = max(worst, e_hip / e_ref)
         am = int(got[s].argmax())
         am_t, am_r = int(g["top_ids_fp32"][s, 0]), int(g["top_ids_bf16"][s, 0])
+        agree_hip_truth += am == am_t
+        agree_ref_truth += am_r == am_t
+        agree_hip_ref += am == am_r
         margin = float(g["top_vals_fp32"][s, 0] - g["top_vals_fp32"][s, 1])
-        noise = float((got[s, cols] - truth[s]).abs().max())
-        key = "<1ulp" if margin < 2.0 ** -8 * abs(float(g["top_vals_fp32"][s, 0])) else ("<4 noise" if margin <= 4 * noise else "clear")
-        hist[key] += 1
-        print(f"T={T} step {s}: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e} (all {LLAMA['vocab']} columns: "
-              f"{float(g['err_bf16_full'][s]):.3e})  err(HIP,oracle_bf16) {e_hr:.3e}  argmax HIP {am} / fp32 {am_t} / oracle {am_r}  "
-              f"fp32 top-2 margin {margin:.3e}  max|HIP-fp32| {noise:.3e}")
+        if s < 4 or s % 16 == 0 or am != am_t:
+            print(f"T={T} step {s}: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e} (all {LLAMA['vocab']} columns: "
+                  f"{float(g['err_bf16_full'][s]):.3e})  err(HIP,oracle_bf16) {e_hr:.3e}  argmax HIP {am} / fp32 {am_t} / oracle {am_r}  "
+                  f"fp32 top-2 margin {margin:.3e}")
         assert e_hip <= SLACK * e_ref, (s, e_hip, e_ref)
-        if am != am_t:      # an argmax that differs from the truth must be a near-tie of the truth (the oracle's own bf16 path flips there too)
-            assert margin <= 4 * noise, (s, am, am_t, margin, noise)
-    print(f"T={T}: worst err(HIP,fp32)/err(oracle_bf16,fp32) = {worst:.3f}; truth top-2 margin histogram {hist}")
+    # argmax agreement as a RATE over the prefill + 64 teacher-forced decode steps: the HIP path must agree with the fp32 truth as
+    # often as the reference's own bf16 arithmetic does, within two steps (round-2 review: the per-step near-tie assertion could
+    # not fail -- every fp32 top-2 margin of an untrained model lies inside the bf16 logits noise)
+    print(f"T={T}: worst err(HIP,fp32)/err(oracle_bf16,fp32) = {worst:.3f}; argmax agreement over {nstep} steps: "
+          f"HIP vs fp32 {agree_hip_truth}/{nstep}, oracle_bf16 vs fp32 {agree_ref_truth}/{nstep}, HIP vs oracle_bf16 {agree_hip_ref}/{nstep}")
+    assert nstep >= 65
+    assert agree_hip_truth >= agree_ref_truth - 2, (agree_hip_truth, agree_ref_truth)
     # final-normed hidden row of the prefill: all 4096 entries are in the fixture
     h_hip = hidden[0, -1].cpu().float()
     e_hip, e_ref = rel_err(h_hip, g["hidden_fp32"][0]), rel_err(g["hidden_bf16"][0].float(), g["hidden_fp32"][0])
