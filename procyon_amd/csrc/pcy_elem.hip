@@ -1368,10 +1368,20 @@ void pcy_launch_kv_scatter(hipStream_t s, const bf16_t* qkv, int ld, int kcol0, 
                            bf16_t* kcache, bf16_t* vcache, int B, int T, int Tmax) {
   if (B * T > 0) hipLaunchKernelGGL(kv_scatter_kernel, dim3(B * T), dim3(NT), 0, s, qkv, ld, kcol0, vcol0, Hkv, dh, kcache, vcache, T, Tmax);
 }
+__global__ void vt_offsets_kernel(const int32_t* __restrict__ cu, int nseq, int pad, int32_t* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int q = 0; q < nseq; ++q) { out[q] = acc; acc += (cu[q + 1] - cu[q] + pad - 1) / pad * pad; }
+    out[nseq] = acc;
+  }
+}
+void pcy_launch_vt_offsets(hipStream_t s, const int32_t* cu, int nseq, int pad, int32_t* vt_cu_out) {
+  hipLaunchKernelGGL(vt_offsets_kernel, dim3(1), dim3(64), 0, s, cu, nseq, pad, vt_cu_out);
+}
 void pcy_launch_transpose_v(hipStream_t s, const bf16_t* buf, int ld, int vcol0, int nh, int dh, const int32_t* cu,
                             const int32_t* vt_cu, int nseq, int max_len, bf16_t* vt, int vt_total) {
   if (nseq <= 0) return;
-  const int maxpad = (max_len + 31) / 32 * 32;
+  const int maxpad = (max_len + 63) / 64 * 64;   // (tiles past a sequence's padded length return at once)
   hipLaunchKernelGGL(transpose_v_kernel, dim3((maxpad + 63) / 64, nh * dh / 64, nseq), dim3(NT), 0, s, buf, ld, vcol0, dh, cu, vt_cu, vt, vt_total);
 }
 size_t pcy_pool_ws_bytes(int nprot, int d) { return (size_t)nprot * POOL_CH * d * 8; }

@@ -609,13 +609,27 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
                   int max_len, int vt_total, int H, int Hkv, int dh, int causal, float scale) {
   if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_attention: head_dim %d unsupported (32/64/128)", dh);
   if ((Hkv * dh) % 64 || H % Hkv) return fail(1, "pcy_attention: Hkv*dh must be a multiple of 64 and Hkv | H");
-  if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + 4096)) return r;
+  // the single-pass kernel wants every sequence's Vt slice zero-padded to a multiple of 64 keys: it lays Vt out itself (offsets
+  // computed on the device from cu), whatever vt_cu / vt_total the caller passed
+  const bool fast = pcy_attn_fast_eligible(dh, causal, keep != nullptr, scale, H, Hkv);
+  int32_t* vt_cu64 = nullptr;
+  if (fast) {
+    int ntok_ub = 0;   // upper bound of the token count: nseq * max_len
+    ntok_ub = nseq * max_len;
+    vt_total = (int)align_up((size_t)ntok_ub + 64 * (size_t)nseq, 8);
+  }
+  if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096)) return r;
   bf16_t* vt = reinterpret_cast<bf16_t*>(c->ws);
+  if (fast) {
+    vt_cu64 = reinterpret_cast<int32_t*>(c->ws + align_up((size_t)Hkv * dh * vt_total * 2, 256));
+    pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
+    vt_cu = vt_cu64;
+  }
   pcy_launch_transpose_v(c->stream, (const bf16_t*)v, ldv, vcol0, Hkv, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
   PcyAttnArgs t{};
   t.q = (const bf16_t*)q; t.ldq = ldq; t.qcol0 = qcol0; t.k = (const bf16_t*)k; t.ldk = ldk; t.kcol0 = kcol0; t.vt = vt;
   t.vt_total = vt_total; t.o = (bf16_t*)o; t.ldo = ldo; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = nseq; t.max_len = max_len;
-  t.H = H; t.Hkv = Hkv; t.dh = dh; t.causal = causal; t.scale = scale;
+  t.H = H; t.Hkv = Hkv; t.dh = dh; t.causal = causal; t.scale = scale; t.vt_pad64 = fast ? 1 : 0;
   pcy_launch_attn(c->stream, t);
   return check_launch("pcy_attention");
 }
@@ -794,8 +808,11 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_esm_encode: head_dim %d unsupported (32/64/128)", dh);
   if (d % 64 || F % 64) return fail(1, "pcy_esm_encode: d and ffn must be multiples of 64");
   if (ntok <= 0) return 0;
+  // single-pass attention (default at head_dim 64): Vt slices zero-padded to 64 keys, laid out by the engine itself
+  const bool fast = pcy_attn_fast_eligible(dh, 0, false, 1.0f, H, H);
+  if (fast) vt_total = (int)align_up((size_t)ntok + 64 * (size_t)nseq, 8);
   const size_t need = align_up((size_t)ntok * d * 2, 256) * 3 + align_up((size_t)ntok * 3 * d * 2, 256) +
-                      align_up((size_t)ntok * F * 2, 256) + align_up((size_t)d * vt_total * 2, 256) + 4096;
+                      align_up((size_t)ntok * F * 2, 256) + align_up((size_t)d * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096;
   if (int r = c->reserve(need)) return r;
   Carver cv(c->ws);
   bf16_t* x = cv.take<bf16_t>((size_t)ntok * d);
@@ -804,6 +821,11 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   bf16_t* qkv = cv.take<bf16_t>((size_t)ntok * 3 * d);
   bf16_t* act = cv.take<bf16_t>((size_t)ntok * F);
   bf16_t* vt = cv.take<bf16_t>((size_t)d * vt_total);
+  int32_t* vt_cu64 = cv.take<int32_t>((size_t)nseq + 1);
+  if (fast) {
+    pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
+    vt_cu = vt_cu64;
+  }
   hipStream_t s = c->stream;
   pcy_launch_esm_embed(s, (const bf16_t*)m->embed, tokens, cu, nseq, max_len, x, d, mask_pads);
   const float qscale = 1.0f / sqrtf((float)dh);
@@ -827,7 +849,7 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
     PcyAttnArgs t{};
     t.q = qkv; t.ldq = 3 * d; t.qcol0 = 0; t.k = qkv; t.ldk = 3 * d; t.kcol0 = d; t.vt = vt; t.vt_total = vt_total;
     t.o = ao; t.ldo = d; t.cu = cu; t.vt_cu = vt_cu; t.keep = nullptr; t.nseq = nseq; t.max_len = max_len; t.H = H; t.Hkv = H;
-    t.dh = dh; t.causal = 0; t.scale = 1.0f;
+    t.dh = dh; t.causal = 0; t.scale = 1.0f; t.vt_pad64 = fast ? 1 : 0;
     pcy_launch_attn(s, t);
     linear(s, ao, d, (const bf16_t*)L.wo, (const bf16_t*)L.bo, x, d, x, d, ntok, d, d, EPI_RESID);
     pcy_launch_layernorm(s, x, (const bf16_t*)L.ln2_w, (const bf16_t*)L.ln2_b, xn, ntok, d, m->ln_eps);

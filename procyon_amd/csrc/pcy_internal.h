@@ -78,7 +78,7 @@ struct PcyGemmArgs {
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)
 enum { PCY_DISPATCH_GEMM_128 = 0, PCY_DISPATCH_GEMM_64 = 1, PCY_DISPATCH_GEMM_BIG = 2, PCY_DISPATCH_GEMM_BIG_PERSIST = 3,
-       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_N = 8 };
+       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_N = 8 };
 extern unsigned long long g_pcy_dispatch[PCY_DISPATCH_N];
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)
@@ -120,8 +120,13 @@ struct PcyAttnArgs {
   const uint8_t* keep;                   // per token key-keep flag (attention_mask) or null
   int nseq, max_len, H, Hkv, dh, causal;
   float scale;                           // multiplied into bf16 scores, then rounded (1.0 = none)
+  int vt_pad64;                          // every sequence's Vt slice starts at a multiple of 8 and is zero-padded to a multiple of 64 keys
 };
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a);
+// the single-pass kernel (pcy_attn_fast.h) covers this call unless PCY_ESM_ATTN=exact asks for the reference's rounding points
+bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv);
+// vt_cu_out[q] = sum over earlier sequences of their length rounded up to `pad` (vt_cu_out[nseq] = total), on the device
+void pcy_launch_vt_offsets(hipStream_t s, const int32_t* cu, int nseq, int pad, int32_t* vt_cu_out);
 
 struct PcyDecAttnArgs {
   bf16_t* qkv; int ld;            // [B, (H+2Hkv)*dh] un-roped projections of the new token

@@ -238,3 +238,83 @@ def test_nucleus_ignores_temperature():
     d = eng.generate_sampling(emb, None, 12, temperature=1.0, nucleus_prob=None, uniforms=u)[0].cpu()
     assert torch.equal(a, b)
     assert not torch.equal(c, d)          # ... while plain sampling does depend on it
+
+
+# ---------------------------------------------------------------------------------------------- single-pass ESM attention
+def _attn_fp64(q, k, v, lens, H, dh):
+    outs, t0 = [], 0
+    for n in lens:
+        qs, ks, vs = (x[t0:t0 + n].double().view(n, H, dh).transpose(0, 1) for x in (q, k, v))
+        p = torch.softmax(qs @ ks.transpose(1, 2), dim=-1)
+        outs.append((p @ vs).transpose(0, 1).reshape(n, H * dh))
+        t0 += n
+    return torch.cat(outs)
+
+
+def _dispatch(kind):
+    from procyon_amd import _lib as L
+    return L.load().pcy_debug_dispatch_count(kind)
+
+
+@pytest.mark.parametrize("lens", [[1026], [64, 1, 33, 700, 257, 1026, 63, 65, 128]])
+def test_attention_single_pass_vs_fp64(ctx, monkeypatch, lens):
+    """`attn_fast64_kernel` (head_dim 64, bidirectional, varlen): against an fp64 evaluation of the same bf16 inputs it must be at
+    least as close as the exact-rounding two-pass kernel (which reproduces the reference's bf16 rounding points), on ragged
+    lengths incl. 1, 63/64/65 (tile edges) and 1026 (the ESM chunk size)."""
+    from procyon_amd import _lib as L
+    H, dh = 3, 64
+    n = sum(lens)
+    q, k, v = rnd(n, H * dh, seed=1, std=0.35), rnd(n, H * dh, seed=2), rnd(n, H * dh, seed=3)
+    ref = _attn_fp64(q, k, v, lens, H, dh)
+    monkeypatch.setenv("PCY_ESM_ATTN", "exact")
+    n0 = _dispatch(L.DISPATCH_ATTN_FAST)
+    exact = ctx.attention(q.cuda(), k.cuda(), v.cuda(), lens, H, H, dh, False, 1.0).cpu()
+    assert _dispatch(L.DISPATCH_ATTN_FAST) == n0
+    monkeypatch.setenv("PCY_ESM_ATTN", "fast")
+    fast = ctx.attention(q.cuda(), k.cuda(), v.cuda(), lens, H, H, dh, False, 1.0).cpu()
+    assert _dispatch(L.DISPATCH_ATTN_FAST) == n0 + 1
+    e_exact, e_fast = rel_err(exact.double(), ref), rel_err(fast.double(), ref)
+    worst = float((fast.double() - ref).abs().max())
+    print(f"lens {lens[:3]}..: err(exact, fp64) {e_exact:.3e}  err(fast, fp64) {e_fast:.3e}  max|fast - fp64| {worst:.3e}  err(fast, exact) {rel_err(fast.double(), exact.double()):.3e}")
+    assert e_fast <= 1.1 * e_exact and e_fast < 4e-3
+    assert worst < 0.05
+
+
+def test_attention_single_pass_forced_rescale_and_outliers(ctx, monkeypatch):
+    """The deferred-maximum branch is data dependent and rare on random data (CDNA4 guide, rule 26): spike single keys against
+    single queries so that a row's maximum jumps by far more than the 2^10 threshold in a chosen LATE tile (and in the first
+    one, and twice in a row), and compare the full tensor with fp64."""
+    H, dh, n = 2, 64, 1026
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(n, H * dh, generator=g) * 0.3
+    k, v = torch.randn(n, H * dh, generator=g), torch.randn(n, H * dh, generator=g)
+    for (qi, ki, gain) in [(5, 700, 40.0), (5, 900, 90.0), (37, 3, 60.0), (64, 64, 50.0), (1025, 1024, 45.0), (300, 1025, 70.0), (301, 31, 55.0)]:
+        k[ki, :dh] = q[qi, :dh] * gain / float(q[qi, :dh].norm() ** 2) * 8.0       # q.k = 8 * gain / ... : a score far above the rest of the row
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    ref = _attn_fp64(q, k, v, [n], H, dh)
+    monkeypatch.setenv("PCY_ESM_ATTN", "fast")
+    out = ctx.attention(q.cuda(), k.cuda(), v.cuda(), [n], H, H, dh, False, 1.0).cpu()
+    assert torch.isfinite(out.float()).all()
+    err = rel_err(out.double(), ref)
+    worst = float((out.double() - ref).abs().max())
+    print(f"spiked keys: err(fast, fp64) {err:.3e}  max abs {worst:.3e}")
+    assert err < 4e-3 and worst < 0.06
+    # rows dominated by one key: the output is that key's V row
+    assert rel_err(out[5, :dh].double(), ref[5, :dh]) < 4e-3
+
+
+def test_esm_layer_stack_fast_vs_exact_attention(monkeypatch):
+    """encoder level: the single-pass attention moves a 4-layer ESM2-650M-width stack by no more than the reference's own bf16
+    reproducibility floor (two CPU evaluations with different accumulation orders differ by as much)"""
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig, EsmEngine
+    kw = dict(d=1280, n_layers=4, n_heads=20, ffn=5120)
+    eng = EsmEngine(synth.esm_state_dict(**kw, device="cuda"), EsmConfig(**kw))
+    toks = synth.protein_tokens([1024, 300, 77], seed=4)
+    monkeypatch.setenv("PCY_ESM_ATTN", "exact")
+    a = eng.hidden_states(toks).float()
+    monkeypatch.setenv("PCY_ESM_ATTN", "fast")
+    b = eng.hidden_states(toks).float()
+    e = rel_err(b, a)
+    print(f"4-layer ESM2-650M-width stack: err(fast attention, exact attention) {e:.3e}")
+    assert e < 8e-3
