@@ -11,8 +11,8 @@
 //
 // gfx950 design
 //   * workgroup = 4 waves, each wave 64 queries (two 32-query groups), all four share the K / Vt tiles of one (sequence, head):
-//     64 keys per tile, K [64 keys][64 dh] and Vt [64 dh][64 keys] = 8 KiB each, double buffered (32 KiB of LDS), brought in by
-//     LDS-DMA (global_load_lds, 16 B per lane, no staging registers) one tile ahead.  128-byte rows: the 16-byte chunk c of row
+//     64 keys per tile, K [64 keys][64 dh] and Vt [64 dh][64 keys] = 8 KiB each, three buffers (48 KiB of LDS), brought in by
+//     LDS-DMA (global_load_lds, 16 B per lane, no staging registers) one tile ahead, one barrier per tile.  128-byte rows: the 16-byte chunk c of row
 //     r sits at position c ^ ((r >> 1) & 7) (applied on the SOURCE address and on the read), which makes every ds_read_b128
 //     lane group hit 16 distinct 16-byte slots.
 //   * 32x32x16 MFMAs.  S^T = K.Q^T with the key rows of a 32-key block PERMUTED over the MFMA's A rows
@@ -20,10 +20,8 @@
 //     chunk, 8 CONSECUTIVE keys of one query: after exp + bf16 packing they are that lane's B-operand fragment of
 //     O^T = Vt.P^T as they stand (no LDS round trip, no shuffles), and the matching A operand is one 16-byte read of a Vt row.
 //     A lane owns one query column of S^T and O^T: the row maximum needs the other half-wave only when the maximum grows.
-//   * deferred maximum: the running maximum m of a row is only raised when a block's maximum exceeds it by more than 2^10 (in
-//     the exp2 domain) -- P then stays <= 1024, harmless for bf16's 8-bit exponent and the fp32 accumulators -- so the
-//     O / l rescale (32 multiplies per lane) sits in a branch that random and real score distributions take in the first
-//     blocks only.  Exactness does not depend on it: m cancels in O / l.
+//   * branch-free online softmax: the row maximum of a block needs the other half-wave once (v_permlane32_swap), O and l are
+//     rescaled by exp2(m_old - m_new) in every block (see fa_softmax_block for why not behind a branch).
 //   * 1-D grid, XCD-aware: the q chunks of one (sequence, head) get consecutive logical ids on ONE XCD, so K / Vt (262 KB per
 //     head at 1026 tokens) are fetched into one L2 instead of five.
 #pragma once
@@ -33,10 +31,15 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Online softmax of one 32-key block of one 32-query group: s = this lane's 16 scores (query = lane & 31, keys per the permuted
+// row map), m / l = running maximum (exp2 domain) / this lane's partial row sum, o = the group's O^T accumulators.
+// Branch-free: the rescale factor alpha = exp2(m_old - m_new) multiplies O and l in EVERY block (16 v_pk_mul_f32).  A rescale
+// behind a wave-uniform "maximum grew" branch is cheaper in instructions, but hipcc then renames the 32 accumulator registers
+// across the branch and pays ~100 v_mov per block on the path that does not rescale (measured in the ISA); straight-line code
+// also lets the scheduler run this VALU work under the neighbouring blocks' MFMAs.
 template <bool MASKED>
 __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[2], int key0, int half, int len) {
   constexpr float LOG2E = 1.4426950408889634f;
-  constexpr float THR = 10.0f;   // exp2 domain
   float v[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -51,26 +54,21 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
 #pragma unroll
   for (int e = 3; e < 15; e += 2) bm = fmaxf(fmaxf(bm, v[e]), v[e + 1]);
   bm = fmaxf(bm, v[15]);
-  const float bm2 = bm * LOG2E;
-  if (__builtin_expect(__any(bm2 > m + THR), 0)) {
-    // raise the maximum of EVERY row of the group to its true running maximum (rows that did not grow get alpha = 1)
-    const float other = __shfl_xor(bm2, 32, 64);
-    const float mn = fmaxf(m, fmaxf(bm2, other));
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);   // m = -inf (first block): 0
-    l *= alpha;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
-    m = mn;
-  }
+  // the other half-wave holds the other 16 keys of the same query
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bm), __float_as_uint(bm), false, false);
+  const float row = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  const float mn = fmaxf(m, row * LOG2E);            // never -inf after the first block (key 0 is always valid)
+  const float alpha = __builtin_amdgcn_exp2f(m - mn); // m = -inf (first block): 0
+  m = mn;
   float p[16], sum = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    p[e] = __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -m));
+    p[e] = __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -mn));
     sum += p[e];
   }
-  l += sum;
+  l = fmaf(l, alpha, sum);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) o[t] *= alpha;
   // chunk c (16 keys): registers i in {2c, 2c+1}  ->  slots j = 4 (i & 1) + r  <->  keys 16 c + 8 half + j
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -81,9 +79,9 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fast64_kernel(PcyAttnArgs a, int nchunk) {
-  constexpr int DH = 64, KT = 64, QW = 64, QB = 4 * QW;
+  constexpr int DH = 64, KT = 64, QW = 64, QB = 4 * QW, NBUF = 3;
   constexpr int TILE = KT * DH * 2;                     // 8 KiB: K tile, then Vt tile
-  __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * TILE];
+  __shared__ __attribute__((aligned(1024))) char smem[NBUF * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   // XCD-aware logical id: consecutive logical ids run on one XCD
@@ -136,63 +134,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     return *reinterpret_cast<const bf16x8*>(buf + TILE + row * 128 + (((4 * sub + 2 * c + half) ^ ((row >> 1) & 7)) << 4));
   };
 
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-  f32x16 o[2][2];
+  float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+  f32x16 o0[2], o1[2];   // O^T of query group 0 / 1: [dh tile]
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[g][t][e] = 0.f;
+    for (int e = 0; e < 16; ++e) { o0[t][e] = 0.f; o1[t][e] = 0.f; }
+
+  // Software pipeline INSIDE a wave (the matrix pipe runs asynchronously to the wave's VALU stream): the two query groups
+  // alternate -- while the exponentials of one group's block run on the VALU, the S^T MFMAs of the other group and the P.V MFMAs
+  // of the previous step are in flight:
+  //   A(n): QK(n, g1) -> s1 | softmax(s0 = (n, g0)) | PV(n, g0)        B(n): QK(n+1, g0) -> s0 | softmax(s1 = (n, g1)) | PV(n, g1)
+  // The K fragments of a block are read once and serve both groups; statically named score registers (s0 / s1).
+  f32x16 s0, s1;
+  bf16x8 kf[4];
+#define FA_LOAD_K(BUF, SUB)                                                    \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) kf[ks] = kfrag(BUF, SUB, ks);
+#define FA_QK(S, G)                                                            \
+  do {                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) S[e] = 0.f;                 \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[G][ks], S, 0, 0, 0); \
+  } while (0)
+#define FA_SM_PV(BUF, KT_, SUB, S, M, L, O, TAIL)                                                        \
+  do {                                                                                                   \
+    bf16x8 pf[2];                                                                                        \
+    fa_softmax_block<TAIL>(S, M, L, O, pf, (KT_) * KT + 32 * (SUB), half, len);                          \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                        \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                      \
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(BUF, t, SUB, c), pf[c], O[t], 0, 0, 0);     \
+  } while (0)
 
   const int ntiles = (len + KT - 1) / KT;
+  const int nfull = len / KT;                           // tiles without keys beyond the sequence: the pipelined, mask-free loop
+  // Three tile buffers, ONE barrier per tile: the barrier at the end of tile u (before the first S^T of tile u+1) finds tile u+1
+  // landed (its DMA was issued a whole tile earlier; the barrier's vmcnt(0) covers it) and every wave done with tile u-1, whose
+  // buffer the DMA of tile u+2 then overwrites.
   stage(0, smem);
+  if (ntiles > 1) stage(1, smem + 2 * TILE);
   __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* buf = smem + (kt & 1) * 2 * TILE;
-    if (kt + 1 < ntiles) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * TILE);
+  if (active && nfull > 0) { FA_LOAD_K(smem, 0); FA_QK(s0, 0); }
+  for (int u = 0; u < nfull; ++u) {
+    const char* buf = smem + (u % NBUF) * 2 * TILE;
     if (active) {
-      const bool tail = (kt + 1) * KT > len;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        bf16x8 kf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[ks] = kfrag(buf, sub, ks);
-        f32x16 s[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[g][e] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) s[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[g][ks], s[g], 0, 0, 0);
-        }
-        bf16x8 pf[2][2];
-        const int key0 = kt * KT + 32 * sub;
-        if (tail) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) fa_softmax_block<true>(s[g], m[g], l[g], o[g], pf[g], key0, half, len);
-        } else {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) fa_softmax_block<false>(s[g], m[g], l[g], o[g], pf[g], key0, half, len);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const bf16x8 vf = vfrag(buf, t, sub, c);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][c], o[g][t], 0, 0, 0);
-          }
-      }
+      FA_QK(s1, 1);                                      // (u.a, g1), K fragments of u.a still in kf
+      FA_SM_PV(buf, u, 0, s0, m0, l0, o0, false);
+      FA_LOAD_K(buf, 1);
+      FA_QK(s0, 0);                                      // (u.b, g0)
+      FA_SM_PV(buf, u, 0, s1, m1, l1, o1, false);
+      FA_QK(s1, 1);                                      // (u.b, g1)
+      FA_SM_PV(buf, u, 1, s0, m0, l0, o0, false);
     }
-    __syncthreads();   // the next tile has landed (vmcnt drained) and every wave has left this one
+    if (u + 1 < ntiles) {
+      __syncthreads();
+      if (u + 2 < ntiles) stage(u + 2, smem + ((u + 2) % NBUF) * 2 * TILE);
+      if (active && u + 1 < nfull) { FA_LOAD_K(smem + ((u + 1) % NBUF) * 2 * TILE, 0); FA_QK(s0, 0); }   // ((u+1).a, g0)
+    }
+    if (active) FA_SM_PV(buf, u, 1, s1, m1, l1, o1, false);
   }
+  if (active && nfull < ntiles) {                        // the ragged last tile: masked, not pipelined (one tile of ~17)
+    const char* buf = smem + (nfull % NBUF) * 2 * TILE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (nfull * KT + 32 * sub >= len) break;           // a block entirely beyond the sequence
+      FA_LOAD_K(buf, sub);
+      FA_QK(s0, 0);
+      FA_QK(s1, 1);
+      FA_SM_PV(buf, nfull, sub, s0, m0, l0, o0, true);
+      FA_SM_PV(buf, nfull, sub, s1, m1, l1, o1, true);
+    }
+  }
+#undef FA_LOAD_K
+#undef FA_QK
+#undef FA_SM_PV
   if (!active) return;
   // O^T: lane (query col, half) holds dh = 32 t + 8 i + 4 half + r  ->  four consecutive features per (t, i)
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int qq = qr0 + g * 32 + col;
-    const float lt = l[g] + __shfl_xor(l[g], 32, 64);
+    const float lg = g ? l1 : l0;
+    const float lt = lg + __shfl_xor(lg, 32, 64);
     const float inv = 1.0f / lt;
     if (qq >= len) continue;
     bf16_t* op = a.o + (size_t)(t0 + qq) * a.ldo + h * DH + 4 * half;
@@ -200,8 +220,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const uint32_t w0 = pack_bf(o[g][t][4 * i + 0] * inv, o[g][t][4 * i + 1] * inv);
-        const uint32_t w1 = pack_bf(o[g][t][4 * i + 2] * inv, o[g][t][4 * i + 3] * inv);
+        const f32x16& ot = g ? o1[t] : o0[t];
+        const uint32_t w0 = pack_bf(ot[4 * i + 0] * inv, ot[4 * i + 1] * inv);
+        const uint32_t w1 = pack_bf(ot[4 * i + 2] * inv, ot[4 * i + 3] * inv);
         *reinterpret_cast<uint2*>(op + 32 * t + 8 * i) = make_uint2(w0, w1);
       }
   }

@@ -94,3 +94,14 @@ def parity_bar(floor, base=5e-3, k=2.0):
     and stacks of a few layers sit at 2-6e-3 between exact-class CPU implementations.  Single ops use the strict
     elementwise bar instead (assert_bf16_close)."""
     return max(base, k * floor)
+
+
+def assert_no_further_from_truth(out, oracle_bf16, truth_fp32, what="", slack=1.25, floor=2e-3):
+    """The bar for paths that do NOT reproduce the reference's bf16 rounding points op for op (the single-pass ESM attention):
+    no further from an fp32 evaluation of the same weights than the reference's own bf16 arithmetic is,
+        err(HIP, fp32) <= slack x max(err(oracle_bf16, fp32), floor)
+    (`floor`: on tiny models the oracle's own error can be a handful of ulp flips).  Returns (err_hip, err_ref)."""
+    e_hip, e_ref = rel_err(out, truth_fp32), rel_err(oracle_bf16, truth_fp32)
+    print(f"{what}: err(HIP, fp32) {e_hip:.3e}  err(oracle_bf16, fp32) {e_ref:.3e}  err(HIP, oracle_bf16) {rel_err(out, oracle_bf16):.3e}")
+    assert e_hip <= slack * max(e_ref, floor), (what, e_hip, e_ref)
+    return e_hip, e_ref

@@ -12,21 +12,30 @@ SM_LLAMA = dict(vocab=320, d=256, n_layers=2, n_heads=4, n_kv_heads=2, ffn=512)
 SM_ESM = dict(d=128, n_layers=2, n_heads=2, ffn=256)
 
 
-def test_esm_shortest_and_longest_sequence_in_one_batch():
+@pytest.mark.parametrize("attn", ["exact", "fast"])
+def test_esm_shortest_and_longest_sequence_in_one_batch(attn, monkeypatch):
     from oracle import esm_ref as ER
     from oracle import procyon_ref as PR
     from procyon_amd import synth
     from procyon_amd.engine import EsmConfig, EsmEngine
+    from conftest import assert_no_further_from_truth
+    monkeypatch.setenv("PCY_ESM_ATTN", attn)
     sd = synth.esm_state_dict(**SM_ESM)
     eng = EsmEngine(sd, EsmConfig(**SM_ESM))
     toks = synth.protein_tokens([1, 1024, 2, 1025], seed=3)            # 1 residue ... 1025 residues (split into 1024 + 1)
     z_ref = PR.esm_plm_forward(sd, ER.EsmGeom(**SM_ESM), toks)
     z = eng.forward(toks).cpu()
     assert z.shape == z_ref.shape == (4, 128)
+    one = synth.protein_tokens([1], seed=4)
+    z1, z1_ref = eng.forward(one).cpu(), PR.esm_plm_forward(sd, ER.EsmGeom(**SM_ESM), one)
+    if attn == "fast":      # single-pass attention: held to the fp32 evaluation (conftest.assert_no_further_from_truth)
+        sd32 = {k: v.float() for k, v in sd.items()}
+        assert_no_further_from_truth(z, z_ref, PR.esm_plm_forward(sd32, ER.EsmGeom(**SM_ESM), toks), "shortest + longest")
+        assert_no_further_from_truth(z1, z1_ref, PR.esm_plm_forward(sd32, ER.EsmGeom(**SM_ESM), one), "one residue")
+        return
     assert rel_err(z, z_ref) < 5e-3
     # a batch of one one-residue protein
-    one = synth.protein_tokens([1], seed=4)
-    assert rel_err(eng.forward(one).cpu(), PR.esm_plm_forward(sd, ER.EsmGeom(**SM_ESM), one)) < 5e-3
+    assert rel_err(z1, z1_ref) < 5e-3
 
 
 def test_llama_single_token_prompt_and_single_token_generation():

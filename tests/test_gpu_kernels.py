@@ -209,8 +209,9 @@ def _eager_attention(q, k, v, H, Hkv, dh, lens, causal, scale, keep=None):
                                                   (4, 4, 64, False, [1026, 191, 192, 193]), (2, 2, 128, True, [515]),
                                                   (8, 2, 128, True, [45, 200]), (4, 1, 64, True, [64, 65]), (8, 2, 128, True, [1200, 700]),
                                                   (2, 2, 32, True, [50])])
-def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens):
-    n = sum(lens)
+def test_attention_exact_rounding(ctx, H, Hkv, dh, causal, lens, monkeypatch):
+    monkeypatch.setenv("PCY_ESM_ATTN", "exact")     # the two-pass kernels with the reference's rounding points (the single-pass ESM
+    n = sum(lens)                                   # kernel has its own tests: tests/test_gpu_round3.py)
     q, k, v = rnd(n, H * dh, seed=1), rnd(n, Hkv * dh, seed=2), rnd(n, Hkv * dh, seed=3)
     scale = dh ** -0.5 if causal else 1.0
     if not causal:
