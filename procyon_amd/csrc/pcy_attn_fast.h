@@ -20,8 +20,8 @@
 //     chunk, 8 CONSECUTIVE keys of one query: after exp + bf16 packing they are that lane's B-operand fragment of
 //     O^T = Vt.P^T as they stand (no LDS round trip, no shuffles), and the matching A operand is one 16-byte read of a Vt row.
 //     A lane owns one query column of S^T and O^T: the row maximum needs the other half-wave only when the maximum grows.
-//   * branch-free online softmax: the row maximum of a block needs the other half-wave once (v_permlane32_swap), O and l are
-//     rescaled by exp2(m_old - m_new) in every block (see fa_softmax_block for why not behind a branch).
+//   * deferred maximum: O and l are rescaled only when a block's maximum exceeds the running one by more than 2^8 (see
+//     fa_softmax_block); the row maximum then needs the other half-wave once (v_permlane32_swap).
 //   * 1-D grid, XCD-aware: the q chunks of one (sequence, head) get consecutive logical ids on ONE XCD, so K / Vt (262 KB per
 //     head at 1026 tokens) are fetched into one L2 instead of five.
 #pragma once
@@ -33,13 +33,19 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // Online softmax of one 32-key block of one 32-query group: s = this lane's 16 scores (query = lane & 31, keys per the permuted
 // row map), m / l = running maximum (exp2 domain) / this lane's partial row sum, o = the group's O^T accumulators.
-// Branch-free: the rescale factor alpha = exp2(m_old - m_new) multiplies O and l in EVERY block (16 v_pk_mul_f32).  A rescale
-// behind a wave-uniform "maximum grew" branch is cheaper in instructions, but hipcc then renames the 32 accumulator registers
-// across the branch and pays ~100 v_mov per block on the path that does not rescale (measured in the ISA); straight-line code
-// also lets the scheduler run this VALU work under the neighbouring blocks' MFMAs.
-template <bool MASKED>
+// The kernel is VALU-issue bound (measured by ablation: with every MFMA removed it loses 20 % of its time, with the exponentials
+// 10 %, and what remains -- the fma / add / max / pack per score -- is 40 %), so this function is counted in instructions per score:
+//   1 v_fma (s.log2e - m) + 1 v_exp + 1/2 v_pk_add (row sum, two running sums) + 1/2 v_max3 (inline asm: fmaxf on MFMA results gets a
+//   canonicalising v_max per operand from hipcc) + 1/2 v_cvt_pk_bf16.
+// Deferred maximum: m is raised -- and O, l rescaled -- only when some row's block maximum exceeds it by more than 2^8 (P stays
+// <= 256: harmless for bf16's 8-bit exponent and the fp32 sums; m cancels in O / l).  After the first blocks no wave takes that
+// branch on ordinary data; tests/test_gpu_round3.py forces it with spiked keys.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ float fa_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template <bool MASKED, int ABL = 0>
 __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[2], int key0, int half, int len) {
   constexpr float LOG2E = 1.4426950408889634f;
+  constexpr float THR = 8.0f;
   float v[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -50,25 +56,33 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
       v[e] = key < len ? v[e] : -INFINITY;
     }
   }
-  float bm = fmaxf(fmaxf(v[0], v[1]), v[2]);
+  float bm = fa_max3(v[0], v[1], v[2]);
 #pragma unroll
-  for (int e = 3; e < 15; e += 2) bm = fmaxf(fmaxf(bm, v[e]), v[e + 1]);
-  bm = fmaxf(bm, v[15]);
-  // the other half-wave holds the other 16 keys of the same query
-  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bm), __float_as_uint(bm), false, false);
-  const float row = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-  const float mn = fmaxf(m, row * LOG2E);            // never -inf after the first block (key 0 is always valid)
-  const float alpha = __builtin_amdgcn_exp2f(m - mn); // m = -inf (first block): 0
-  m = mn;
-  float p[16], sum = 0.f;
+  for (int e = 3; e < 15; e += 2) bm = fa_max3(bm, v[e], v[e + 1]);
+  bm = fa_max3(bm, v[15], v[15]);
+  if (!(ABL & 1)) {
+    if (__builtin_expect(__any(bm * LOG2E > m + THR), 0)) {
+      // the other half-wave holds the other 16 keys of the same query; every row of the group moves to its true running maximum
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bm), __float_as_uint(bm), false, false);
+      const float row = fa_max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), m * (1.0f / LOG2E)) * LOG2E;
+      const float mn = row > m ? row : m;               // (m = -inf in the first block)
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      l *= alpha;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    p[e] = __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -mn));
-    sum += p[e];
+      for (int t = 0; t < 2; ++t) o[t] *= alpha;
+      m = mn;
+    }
   }
-  l = fmaf(l, alpha, sum);
+  float p[16];
+  f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < 2; ++t) o[t] *= alpha;
+  for (int e = 0; e < 16; e += 2) {
+    const float x0 = fmaf(v[e], LOG2E, -m), x1 = fmaf(v[e + 1], LOG2E, -m);
+    p[e] = (ABL & 2) ? x0 : __builtin_amdgcn_exp2f(x0);   // (ABL: measurement variants, see attn_fast64_kernel)
+    p[e + 1] = (ABL & 2) ? x1 : __builtin_amdgcn_exp2f(x1);
+    sum2 += (f32x2_t){p[e], p[e + 1]};
+  }
+  l += sum2[0] + sum2[1];
   // chunk c (16 keys): registers i in {2c, 2c+1}  ->  slots j = 4 (i & 1) + r  <->  keys 16 c + 8 half + j
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -78,6 +92,9 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
   }
 }
 
+// ABL != 0: measurement variants with parts of the work removed (wrong results; PCY_FA_ABL, tools/bench_attn_esm.py):
+//   1 no O rescale, 2 no exponentials, 4 no P.V MFMAs, 8 no Q.K^T MFMAs, 16 no Vt fragment reads, 32 no K fragment reads, 64 no DMA
+template <int ABL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fast64_kernel(PcyAttnArgs a, int nchunk) {
   constexpr int DH = 64, KT = 64, QW = 64, QB = 4 * QW, NBUF = 3;
   constexpr int TILE = KT * DH * 2;                     // 8 KiB: K tile, then Vt tile
@@ -111,25 +128,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gptr_t;
+  // Staging addresses are per-thread constants plus a tile offset (recomputing row / chunk / clamp per tile cost ~40 of the ~450
+  // instructions of a tile); only the ragged last tile clamps its key rows.
+  const bf16_t* kp[2]; const bf16_t* vp[2]; int srow[2], schunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = i * 256 + tid, row = slot >> 3, cp = slot & 7;
+    srow[i] = row; schunk[i] = (cp ^ ((row >> 1) & 7)) * 8;
+    kp[i] = kglob + (size_t)row * a.ldk + schunk[i];
+    vp[i] = vglob + (size_t)row * a.vt_total + schunk[i];
+  }
+  const size_t ktile_stride = (size_t)KT * a.ldk;
   auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
+    if (ABL & 64) return;
+    const bool clamp = (kt + 1) * KT > len;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int slot = i * 256 + tid, row = slot >> 3, cp = slot & 7;
-      const int c = cp ^ ((row >> 1) & 7);
-      int key = kt * KT + row;
-      key = key < len ? key : len - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(kglob + (size_t)key * a.ldk + c * 8), (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vglob + (size_t)row * a.vt_total + kt * KT + c * 8),
-                                       (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+      const bf16_t* ks = kp[i] + kt * ktile_stride;
+      if (clamp) { int key = kt * KT + srow[i]; key = key < len ? key : len - 1; ks = kglob + (size_t)key * a.ldk + schunk[i]; }
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vp[i] + kt * KT), (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
     }
   };
   // A-operand row (lane & 31) of S^T  ->  key of the 32-key block
   const int krow = 16 * (col >> 4) + 8 * ((col >> 2) & 1) + 4 * ((col >> 3) & 1) + (col & 3);
   auto kfrag = [&](const char* buf, int sub, int ks) __attribute__((always_inline)) {
+    if (ABL & 32) return qf[0][ks];
     const int row = krow + 32 * sub;
     return *reinterpret_cast<const bf16x8*>(buf + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
   };
   auto vfrag = [&](const char* buf, int t, int sub, int c) __attribute__((always_inline)) {
+    if (ABL & 16) return qf[1][t + 2 * c];
     const int row = 32 * t + col;
     return *reinterpret_cast<const bf16x8*>(buf + TILE + row * 128 + (((4 * sub + 2 * c + half) ^ ((row >> 1) & 7)) << 4));
   };
@@ -153,15 +182,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #define FA_QK(S, G)                                                            \
   do {                                                                         \
     _Pragma("unroll") for (int e = 0; e < 16; ++e) S[e] = 0.f;                 \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[G][ks], S, 0, 0, 0); \
+    if (ABL & 8) {                                                             \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { S[4 * ks] = __builtin_bit_cast(f32x4, kf[ks])[0]; S[4 * ks + 1] = __builtin_bit_cast(f32x4, qf[G][ks])[1]; } \
+    } else {                                                                   \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[G][ks], S, 0, 0, 0); \
+    }                                                                          \
   } while (0)
 #define FA_SM_PV(BUF, KT_, SUB, S, M, L, O, TAIL)                                                        \
   do {                                                                                                   \
     bf16x8 pf[2];                                                                                        \
-    fa_softmax_block<TAIL>(S, M, L, O, pf, (KT_) * KT + 32 * (SUB), half, len);                          \
+    fa_softmax_block<TAIL, ABL>(S, M, L, O, pf, (KT_) * KT + 32 * (SUB), half, len);                     \
     _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                        \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                      \
-        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(BUF, t, SUB, c), pf[c], O[t], 0, 0, 0);     \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                    \
+        const bf16x8 vf_ = vfrag(BUF, t, SUB, c);                                                        \
+        if (ABL & 4) { asm volatile("" :: "v"(vf_), "v"(pf[c])); O[t][c] += 1.0f; }                      \
+        else O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_, pf[c], O[t], 0, 0, 0);                  \
+      }                                                                                                  \
   } while (0)
 
   const int ntiles = (len + KT - 1) / KT;
@@ -171,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   // buffer the DMA of tile u+2 then overwrites.
   stage(0, smem);
   if (ntiles > 1) stage(1, smem + 2 * TILE);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (active && nfull > 0) { FA_LOAD_K(smem, 0); FA_QK(s0, 0); }
   for (int u = 0; u < nfull; ++u) {
@@ -185,6 +222,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       FA_SM_PV(buf, u, 1, s0, m0, l0, o0, false);
     }
     if (u + 1 < ntiles) {
+      // hipcc does NOT put a vmcnt wait in front of this barrier (the loop's only VMEM operations are LDS-DMA, which its waitcnt
+      // pass does not count against the barrier: the ISA had `s_waitcnt lgkmcnt(0); s_barrier`): tile u+1 could then be read before
+      // it has landed -- seen once as NaNs in ~100 runs.  The wait must be explicit.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (u + 2 < ntiles) stage(u + 2, smem + ((u + 2) % NBUF) * 2 * TILE);
       if (active && u + 1 < nfull) { FA_LOAD_K(smem + ((u + 1) % NBUF) * 2 * TILE, 0); FA_QK(s0, 0); }   // ((u+1).a, g0)
@@ -234,7 +275,15 @@ inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_
   if (a.dh != 64 || a.causal || a.keep || a.scale != 1.0f || a.H != a.Hkv || !vt_pad64) return false;
   if ((a.ldq | a.ldk | a.qcol0 | a.kcol0 | a.vt_total) % 8 || a.ldo % 4) return false;
   const int nchunk = (a.max_len + 255) / 256;
-  hipLaunchKernelGGL(attn_fast64_kernel, dim3(nchunk * a.H * a.nseq), dim3(256), 0, s, a, nchunk);
+  const dim3 grid(nchunk * a.H * a.nseq);
+  const char* e = getenv("PCY_FA_ABL");   // measurement variants (wrong results)
+  const int abl = e ? atoi(e) : 0;
+  switch (abl) {
+#define FA_CASE(V) case V: hipLaunchKernelGGL(attn_fast64_kernel<V>, grid, dim3(256), 0, s, a, nchunk); break;
+    FA_CASE(1) FA_CASE(2) FA_CASE(3) FA_CASE(4) FA_CASE(8) FA_CASE(12) FA_CASE(48) FA_CASE(64) FA_CASE(112) FA_CASE(15) FA_CASE(127)
+#undef FA_CASE
+    default: hipLaunchKernelGGL(attn_fast64_kernel<0>, grid, dim3(256), 0, s, a, nchunk); break;
+  }
   return true;
 }
 

@@ -69,6 +69,10 @@ struct pcy_ctx {
   size_t beam_ws_bytes = 0;
 
   int reserve(size_t bytes) {
+    // PCY_DEBUG_POISON_WS=1 (tests): fill the workspace with NaN patterns before every use -- a kernel that reads a workspace
+    // location before writing it then fails deterministically instead of depending on what the allocator handed out
+    static const bool poison = [] { const char* e = getenv("PCY_DEBUG_POISON_WS"); return e && atoi(e) != 0; }();
+    if (poison && ws && bytes <= ws_bytes) HIP_TRY(hipMemsetAsync(ws, 0xFF, ws_bytes, stream));
     if (bytes <= ws_bytes) return 0;
     if (ws) {
       HIP_TRY(hipStreamSynchronize(stream));
@@ -79,6 +83,7 @@ struct pcy_ctx {
     bytes = align_up(bytes + (bytes >> 3), 1 << 20);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws), bytes));
     ws_bytes = bytes;
+    if (poison) HIP_TRY(hipMemsetAsync(ws, 0xFF, ws_bytes, stream));
     return 0;
   }
   void drop_graph() {

@@ -1,0 +1,23 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PCY_DEBUG_POISON_WS"] = "1"
+import torch
+from procyon_amd.engine import Context
+ctx = Context.get()
+H, dh = 3, 64
+for rep in range(40):
+    for lens in ([1026], [64, 1, 33, 700, 257, 1026, 63, 65, 128], [5, 1026, 1026, 31]):
+        n = sum(lens)
+        g = torch.Generator().manual_seed(rep)
+        q, k, v = [(torch.randn(n, H * dh, generator=g) * s).bfloat16().cuda() for s in (0.35, 1, 1)]
+        for mode in ("exact", "fast"):
+            os.environ["PCY_ESM_ATTN"] = mode
+            out = ctx.attention(q, k, v, lens, H, H, dh, False, 1.0)
+            if mode == "fast":
+                a = out.clone()
+                b = ctx.attention(q, k, v, lens, H, H, dh, False, 1.0)
+                nb = int(torch.isnan(out.float()).any(1).sum())
+                same = torch.equal(a, b)
+                if nb or not same or rep == 0:
+                    print(rep, lens[:3], mode, "nan rows", nb, "deterministic", same, flush=True)
+print("done")
