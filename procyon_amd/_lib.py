@@ -95,6 +95,7 @@ SIGNATURES = {
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),
     "pcy_esm_encode": (ci, [vp, C.POINTER(EsmDesc), vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]),
     "pcy_llama_prefill": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp]),
+    "pcy_llama_prefill_all": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, vp, vp, vp, vp, ci, ci, vp, ci, vp, vp]),
     "pcy_llama_decode": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci]),
     "pcy_debug_mc_trace": (ci, [vp, ci]),
     "pcy_llama_decode_layers": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci]),

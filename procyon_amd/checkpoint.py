@@ -26,15 +26,18 @@ _FAIR2HF = [
     (r"^layers\.(\d+)\.fc1\.(weight|bias)$", r"esm.encoder.layer.\1.intermediate.dense.\2"),
     (r"^layers\.(\d+)\.fc2\.(weight|bias)$", r"esm.encoder.layer.\1.output.dense.\2"),
     (r"^layers\.(\d+)\.final_layer_norm\.(weight|bias)$", r"esm.encoder.layer.\1.LayerNorm.\2"),
+    # masked-LM head (RobertaLMHead: dense -> gelu -> layer_norm -> tied decoder + bias), read by ESM_PLM.forward(aggregate=False)
+    (r"^lm_head\.weight$", "lm_head.decoder.weight"),
 ]
 
 
 def fair_esm_to_hf(sd):
-    """fair-esm ESM2 parameter names -> the HF Esm names the engine consumes.  Unused tensors (lm_head, contact head,
-    rotary inv_freq buffers) are dropped.  Already-HF dicts pass through."""
+    """fair-esm ESM2 parameter names -> the HF Esm names the engine consumes.  Unused tensors (contact head,
+    rotary inv_freq buffers) are dropped; the masked-LM head is kept (ESM_PLM.forward(aggregate=False) returns its logits).
+    Already-HF dicts pass through."""
     out = {}
     for k, v in sd.items():
-        if k.startswith("esm."):
+        if k.startswith("esm.") or (k.startswith("lm_head.") and k != "lm_head.weight"):   # HF names (the masked-LM head keeps its names)
             out[k] = v
             continue
         for pat, rep in _FAIR2HF:

@@ -865,10 +865,12 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   return check_launch("pcy_esm_encode");
 }
 
-int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
-                      const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
-                      int n_logit_rows, void* logits_out, void* hidden_out, const int32_t* sum_rows, int n_sum_rows,
-                      void* hidden_sum_out) {
+}  // extern "C"
+namespace {
+int llama_prefill_impl(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
+                       const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
+                       int n_logit_rows, void* logits_out, void* hidden_out, const int32_t* sum_rows, int n_sum_rows,
+                       void* hidden_sum_out, void* hidden_all_out) {
   PCY_STICKY(c);
   const int d = m->d, H = m->n_heads, Hkv = m->n_kv_heads, dh = m->head_dim, F = m->ffn;
   if (dh != 32 && dh != 64 && dh != 128) return fail(1, "pcy_llama_prefill: head_dim %d unsupported (32/64/128)", dh);
@@ -920,6 +922,10 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     pcy_launch_gemm(s, g);
   };
   HIP_TRY(hipMemcpyAsync(x, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  // hidden_all_out [L+1][M][d]: HF's `hidden_states` tuple -- the embeddings, the output of layers 0..L-2, and the FINAL-NORMED
+  // output of layer L-1 (pmc_llama.py:575,584 always asks for it; only materialised here when the caller does)
+  bf16_t* hall = (bf16_t*)hidden_all_out;
+  if (hall) HIP_TRY(hipMemcpyAsync(hall, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   // hidden_states = (embeddings, output of layers 0..L-2, final-normed output of layer L-1)  [HF LlamaModel.forward]
   pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 1);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
@@ -957,6 +963,7 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
       linear8(x, d, L8->wgu, L8->sgu, nullptr, act, F, 2 * F, EPI_SWIGLU, (const bf16_t*)L.ln2);
       linear8(act, F, L8->wdown, L8->sdown, x, x, d, d, EPI_RESID);
       if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
+      if (hall && l + 1 < m->n_layers) HIP_TRY(hipMemcpyAsync(hall + (size_t)(l + 1) * M * d, x, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
       continue;
     }
     if (M <= 8) {
@@ -971,7 +978,9 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
              (const bf16_t*)m->layers[l + 1].ln1, xn, &xn_ready, m->rms_eps, m->rms_cast);
     else linear(s, act, F, (const bf16_t*)L.wdown, nullptr, x, d, x, d, M, d, F, EPI_RESID, sk_ws, sk_bytes);
     if (l + 1 < m->n_layers) pcy_launch_acc_rows(s, x, d, sum_rows, hsum, n_sum_rows, d, 0);
+    if (hall && l + 1 < m->n_layers) HIP_TRY(hipMemcpyAsync(hall + (size_t)(l + 1) * M * d, x, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   }
+  if (hall) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, hall + (size_t)m->n_layers * M * d, M, d, m->rms_eps, m->rms_cast);
   if (hidden_out) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, (bf16_t*)hidden_out, M, d, m->rms_eps, m->rms_cast);
   if (n_sum_rows > 0) {
     pcy_launch_copy_rows(s, x, d, hsum_tmp, d, sum_rows, n_sum_rows, d);
@@ -979,7 +988,13 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     pcy_launch_acc_rows(s, hsum_tmp, d, nullptr, hsum, n_sum_rows, d, 0);
     pcy_launch_acc_finish(s, hsum, (bf16_t*)hidden_sum_out, (size_t)n_sum_rows * d);
   }
-  if (n_logit_rows > 0 && logits_out) {
+  if (n_logit_rows > 64 && logits_out) {
+    // many rows (the reference's full [B,T,V] logits): final norm of those rows, then lm_head as an MFMA GEMM -- the GEMV would
+    // stream the 1 GB matrix once per 32 rows
+    pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
+    pcy_launch_rmsnorm(s, lastx, (const bf16_t*)m->final_norm, lastx, n_logit_rows, d, m->rms_eps, m->rms_cast);
+    linear(s, lastx, d, (const bf16_t*)m->lm_head, nullptr, nullptr, 0, (bf16_t*)logits_out, m->vocab, n_logit_rows, m->vocab, d, EPI_STORE);
+  } else if (n_logit_rows > 0 && logits_out) {
     pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
     PcyGemvArgs h{};
     h.W = (const bf16_t*)m->lm_head; h.x = lastx; h.y = (bf16_t*)logits_out; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
@@ -987,6 +1002,22 @@ int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* k
     pcy_launch_gemv(s, h);
   }
   return check_launch("pcy_llama_prefill");
+}
+}  // namespace
+extern "C" {
+int pcy_llama_prefill(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
+                      const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
+                      int n_logit_rows, void* logits_out, void* hidden_out, const int32_t* sum_rows, int n_sum_rows,
+                      void* hidden_sum_out) {
+  return llama_prefill_impl(c, m, kv, embeds, keep, pos, cu, vt_cu, B, T, logit_rows, n_logit_rows, logits_out, hidden_out, sum_rows,
+                            n_sum_rows, hidden_sum_out, nullptr);
+}
+int pcy_llama_prefill_all(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const void* embeds, const uint8_t* keep,
+                          const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
+                          int n_logit_rows, void* logits_out, void* hidden_all_out) {
+  if (!hidden_all_out) return fail(1, "pcy_llama_prefill_all: hidden_all_out is NULL");
+  return llama_prefill_impl(c, m, kv, embeds, keep, pos, cu, vt_cu, B, T, logit_rows, n_logit_rows, logits_out, nullptr, nullptr, 0,
+                            nullptr, hidden_all_out);
 }
 
 int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B) {

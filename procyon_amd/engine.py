@@ -514,6 +514,37 @@ class LlamaEngine:
             return logits, hidden, hsum
         return logits, hidden
 
+    def prefill_all(self, embeds, attn_mask, cache: KVCache, logit_rows="all"):
+        """The prefill with everything `LlamaPostTokenization.forward` returns (pmc_llama.py:575-596): (logits [n,V] for
+        `logit_rows` ("all" = every token row, the reference's [B,T,V]; "last"; None; or flat rows), hidden_states [L+1,B,T,d] =
+        embeddings, outputs of layers 0..L-2, final-normed output of layer L-1)."""
+        B, T, d = embeds.shape
+        embeds = embeds.contiguous()
+        _chk_bf16(embeds)
+        dev = self.device
+        keep = None
+        if attn_mask is not None and not bool((attn_mask != 0).all()):
+            keep = (attn_mask != 0).to(dev, torch.uint8).contiguous()
+        pos = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        Tp = (T + 31) // 32 * 32
+        cu = torch.arange(B + 1, dtype=torch.int32, device=dev) * T
+        vt_cu = torch.arange(B + 1, dtype=torch.int32, device=dev) * Tp
+        if isinstance(logit_rows, str) and logit_rows == "all":
+            rows = torch.arange(B * T, dtype=torch.int32, device=dev)
+        elif isinstance(logit_rows, str) and logit_rows == "last":
+            rows = (torch.arange(B, dtype=torch.int32, device=dev) + 1) * T - 1
+        elif logit_rows is None:
+            rows = torch.zeros(0, dtype=torch.int32, device=dev)
+        else:
+            rows = logit_rows.to(dev, torch.int32).contiguous()
+        n = rows.numel()
+        logits = torch.empty(n, self.cfg.vocab, dtype=BF16, device=dev)
+        hidden_all = torch.empty(self.cfg.n_layers + 1, B, T, d, dtype=BF16, device=dev)
+        L.check(self.ctx.lib.pcy_llama_prefill_all(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(embeds), _p(keep), _p(pos),
+                                                   _p(cu), _p(vt_cu), B, T, _p(rows), n, _p(logits), _p(hidden_all)),
+                "pcy_llama_prefill_all")
+        return logits, hidden_all
+
     def decode(self, cache: KVCache, st: GenState, B):
         L.check(self.ctx.lib.pcy_llama_decode(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B), "pcy_llama_decode")
 
@@ -671,6 +702,13 @@ class EsmEngine:
             self._keep.append(ts)
             arr[l] = L.EsmLayer(*[t.data_ptr() for t in ts])
         self._arr = arr
+        # masked-LM head (fair-esm RobertaLMHead / HF EsmLMHead: dense -> gelu -> layer_norm -> decoder tied to the embedding + bias),
+        # only when the checkpoint carries it; consumed by ESM_PLM.forward(aggregate=False) (esm.py:547-558)
+        self.lm_head = None
+        if "lm_head.dense.weight" in sd:
+            dec = sd["lm_head.decoder.weight"] if "lm_head.decoder.weight" in sd else sd["esm.embeddings.word_embeddings.weight"]
+            self.lm_head = dict(wd=g("lm_head.dense.weight"), bd=g("lm_head.dense.bias"), lw=g("lm_head.layer_norm.weight"),
+                                lb=g("lm_head.layer_norm.bias"), wo=dec.to(dev, BF16).contiguous(), bo=g("lm_head.bias"))
         self.desc = L.EsmDesc(cfg.d, cfg.n_layers, cfg.n_heads, cfg.ffn, cfg.vocab, cfg.ln_eps,
                               1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
                               self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
@@ -734,6 +772,33 @@ class EsmEngine:
         idx = (torch.arange(S)[None, :] < pk["lens"][:, None]).to(self.device)
         out[idx] = h
         return out
+
+    def lm_logits(self, hidden):
+        """masked-LM logits [..., vocab] of final-layer states [..., d]: linear + bias -> ESM gelu (op by op, as fair-esm's
+        `gelu`) -> LayerNorm -> tied decoder + bias; every Linear / norm rounds to bf16 like the eager reference"""
+        if self.lm_head is None:
+            raise ValueError("this ESM checkpoint carries no masked-LM head (lm_head.*): logits are not available")
+        h = self.lm_head
+        x = hidden.reshape(-1, hidden.shape[-1]).contiguous()
+        y = self.ctx.gemm(x, h["wd"], bias=h["bd"], epi=L.EPI_GELU_ESM)
+        y = self.ctx.layernorm(y, h["lw"], h["lb"], self.cfg.ln_eps)
+        out = self.ctx.gemm(y, h["wo"], bias=h["bo"])
+        return out.reshape(*hidden.shape[:-1], h["wo"].shape[0])
+
+    def forward_tokens(self, tokens, mask_pads=True, max_protein_len=1024, long_protein_strategy="split", want_logits=True):
+        """`ESM_PLM.forward(tokens, aggregate=False)` (esm.py:547-558): per-position final-layer states [B, max_eos + 1, d] (the
+        chunks of a split protein laid end to end by `reverse_batched_split`) and, when the checkpoint has the head, the
+        masked-LM logits of the same positions.  Pad positions are zero (the reference leaves whatever the padded forward
+        computed there; they are masked by every consumer)."""
+        from .sequences import reverse_batched_split, split_or_truncate_long_seq
+        rows, keys, eos_loc = split_or_truncate_long_seq(tokens.cpu().long(), PAD_ID, EOS_ID, long_protein_strategy, max_protein_len)
+        z = self.hidden_states(rows, mask_pads)
+        logits = self.lm_logits(z) if (want_logits and self.lm_head is not None) else None
+        if keys is not None:
+            z = reverse_batched_split(z, keys, eos_loc)
+            if logits is not None:
+                logits = reverse_batched_split(logits, keys, eos_loc)
+        return z, logits
 
     def forward(self, tokens, pooling="mean", correction=False, mask_pads=True, max_protein_len=1024):
         """`ESM_PLM.forward(tokens, aggregate=True)`: split long proteins, encode, pool per original protein."""

@@ -17,13 +17,14 @@ ESM2_GEOMETRY = {
 
 
 class ESM_PLM:
-    """forward(tokens, aggregate=True) -> (z [B,D], logits=None).
+    """forward(tokens, aggregate=True) -> (z [B,D], logits=None); forward(tokens, aggregate=False) -> (z [B,len,D], logits
+    [B,len,33] or None when the checkpoint has no masked-LM head).
 
     pooling_method / protein_pooling_correction_option / long_protein_strategy / max_protein_len keep the
     reference's meaning (esm.py:318-376, training_args_IT.py:65-103).  `official=True` reproduces the
     HF-"official" call that passes no attention mask (esm.py:533, quirk Q12).  The masked-LM logits the
     reference also returns are never consumed on the inference path (model_unified.py:1060) and are not
-    computed: `logits` is None.  aggregate=False (per-residue states, MLM path) is out of scope."""
+    computed on the pooled path: `logits` is None there."""
 
     def __init__(self, state_dict, cfg: EsmConfig, pooling_method="max", protein_pooling_correction_option=False,
                  long_protein_strategy="split", max_protein_len=1024, official=False, device=None):
@@ -45,11 +46,11 @@ class ESM_PLM:
         return self
 
     def forward(self, tokens, aggregate=True):
-        if not aggregate:
-            raise NotImplementedError("aggregate=False (MLM / per-residue) is outside the north-star path")
         if self.long_protein_strategy == "truncate":       # cut to max_protein_len residues, re-terminate (train_utils.py:1575-1588)
             from ..sequences import split_or_truncate_long_seq
             tokens, _, _ = split_or_truncate_long_seq(tokens.cpu().long(), self.padding_idx, self.eos_idx, "truncate", self.max_protein_len)
+        if not aggregate:      # per-position states + masked-LM logits (esm.py:547-558)
+            return self.engine.forward_tokens(tokens, mask_pads=not self.official, max_protein_len=self.max_protein_len)
         z = self.engine.forward(tokens, pooling=self.pooling_method, correction=self.correction,
                                 mask_pads=not self.official, max_protein_len=self.max_protein_len)
         return z, None

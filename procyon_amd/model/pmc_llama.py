@@ -32,15 +32,46 @@ class _Past:
         return (self[l] for l in range(len(self)))
 
 
+class _HiddenStates:
+    """`outputs.hidden_states` (pmc_llama.py:575,584 `output_hidden_states=True`): the L+1 tuple of [B,T,d] tensors -- embeddings,
+    outputs of layers 0..L-2, final-normed output of layer L-1.  The engine's fast path keeps only what the shipped configuration
+    reads, `hidden_states[-1]` (ret_token_access='last', model_unified.py:556-559); ANY other access -- another index,
+    iteration, `torch.stack(hidden_states, -1)` of ret_token_access='all' (:560-563), len() -- materialises the whole tuple by
+    running the (deterministic) prefill once more with every layer's state written out.  So a caller that keeps the reference's
+    `UnifiedProCyon` and swaps only this sub-module (INTEGRATION.md route B) sees the reference's object, and callers that read
+    [-1] pay nothing."""
+
+    def __init__(self, n, last, materialise):
+        self._n, self._last, self._mat, self._all = n, last, materialise, None
+
+    def _full(self):
+        if self._all is None:
+            self._all = tuple(self._mat())
+        return self._all
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, int) and (i == -1 or i == self._n - 1) and self._last is not None:
+            return self._last
+        return self._full()[i]
+
+    def __iter__(self):
+        return iter(self._full())
+
+
 class LlamaPostTokenization:
     """forward(input_embeds|input_ids, attn_masks, full_labels, past_key_values, use_cache, output_attentions)
     -> object with .logits, .past_key_values, .hidden_states, .loss   (pmc_llama.py:546-596).
 
-    Exactly one of input_embeds / input_ids (:562).  Differences, all documented in DESIGN.md:
-      * `logit_positions` (extension): LongTensor [B] -> logits only at those positions ([B,1,V]); the
-        reference always materialises [B,T,V] (1 GB per 2048-token row).  None = all rows.
-      * .hidden_states holds only the final (post-norm) state, as [-1] (ret_token_access='last',
-        llama3-full.yml:53); the 33-tuple the reference builds is not materialised.
+    Exactly one of input_embeds / input_ids (:562).  With the reference's arguments only, the returned object is the
+    reference's: `.logits` [B,T,V] for every row and `.hidden_states` the L+1 tuple (lazily materialised, see _HiddenStates).
+    Extensions used by the engine-backed `UnifiedProCyon` (never required):
+      * `logit_positions`: LongTensor [B] -> logits only at those positions ([B,1,V]); the reference always materialises
+        [B,T,V] (1 GB per 2048-token row).  None = all rows.
+      * `want_hidden=False` skips the final hidden state, `hidden_sum_positions` asks for the sum over all L+1 states at
+        given rows only (ret_token_access='all' without the tuple), `output_hidden_states=True` materialises the tuple eagerly.
       * full_labels / loss / output_attentions: training-side, not computed (loss=None).
       * max_new_tokens: KV capacity reserved beyond the prompt when use_cache=True.
     """
@@ -59,7 +90,8 @@ class LlamaPostTokenization:
         return self.engine.embed
 
     def forward(self, input_embeds=None, input_ids=None, attn_masks=None, full_labels=None, past_key_values=None,
-                use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None):
+                use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None,
+                output_hidden_states=False):
         assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
         eng = self.engine
         if past_key_values is None:
@@ -72,15 +104,31 @@ class LlamaPostTokenization:
             else:
                 rows = (torch.arange(B) * T + logit_positions.cpu().long()).to(torch.int32)
             hsum = None
-            if hidden_sum_positions is not None:
+            embeds_dev = input_embeds.to(eng.device)
+            L1 = self.cfg.n_layers + 1
+
+            def materialise():      # the whole tuple, from a second (deterministic) pass; the KV cache it fills is a scratch one
+                _, hall = eng.prefill_all(embeds_dev, attn_masks, eng.new_cache(B, T), None)
+                return [hall[i] for i in range(L1)]
+
+            if output_hidden_states:
+                logits, hall = eng.prefill_all(embeds_dev, attn_masks, cache, rows)
+                states = [hall[i] for i in range(L1)]
+                hs = _HiddenStates(L1, states[-1], lambda: states)
+                if hidden_sum_positions is not None:
+                    flat = hall.view(L1, B * T, -1)[:, hidden_sum_positions.to(eng.device).long()]
+                    hsum = flat.float().sum(0).to(hall.dtype)
+            elif hidden_sum_positions is not None:
                 # ret_token_access='all': sum of all L+1 hidden states, only at the requested flat token rows
-                logits, hidden, hsum = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden,
+                logits, hidden, hsum = eng.prefill(embeds_dev, attn_masks, cache, rows, want_hidden=want_hidden,
                                                    sum_rows=hidden_sum_positions)
+                hs = _HiddenStates(L1, hidden, materialise)
             else:
-                logits, hidden = eng.prefill(input_embeds.to(eng.device), attn_masks, cache, rows, want_hidden=want_hidden)
+                logits, hidden = eng.prefill(embeds_dev, attn_masks, cache, rows, want_hidden=want_hidden)
+                hs = _HiddenStates(L1, hidden, materialise)
             logits = logits.view(B, -1, self.cfg.vocab)
             past = _Past(cache, T) if use_cache else None
-            return SimpleNamespace(logits=logits, past_key_values=past, hidden_states=(hidden,), hidden_state_sum_rows=hsum, loss=None)
+            return SimpleNamespace(logits=logits, past_key_values=past, hidden_states=hs, hidden_state_sum_rows=hsum, loss=None)
         # cached decode: one new token per row, no mask, position = cache length (quirks Q1/Q2)
         assert input_ids is not None and input_ids.shape[1] == 1, "cached decode takes input_ids [B,1]"
         cache, t = past_key_values.cache, past_key_values.t

@@ -106,3 +106,27 @@ def split_or_truncate_long_seq(toks, padding_idx=1, eos_idx=2, long_protein_stra
             new = toks
         return new, None, None
     raise NotImplementedError(f"long_protein_strategy={long_protein_strategy!r}")
+
+
+def reverse_batched_split(protein_embeds, batch_keys, eos_locs):
+    """`reverse_batched_split` (train_utils.py:1599-1649): per-position states of the chunk rows [B', S, d] -> one row per
+    ORIGINAL protein [B, max(eos_locs) + 1, d].  The chunks of a protein are laid end to end in row order, dropping the last
+    column of every chunk but the last (the <eos> a split chunk was re-terminated with) and the first column of every chunk but
+    the first (its re-inserted <cls>); then padded with zeros / cut to max(eos_locs) + 1 positions."""
+    d = protein_embeds.shape[-1]
+    max_size = int(max(int(e) for e in eos_locs)) + 1
+    out = []
+    for i in range(int(batch_keys.max()) + 1):
+        rows = (batch_keys == i).nonzero(as_tuple=True)[0].sort()[0]
+        if rows.numel() == 0:
+            continue
+        parts = []
+        for j, r in enumerate(rows.tolist()):
+            lo = 1 if j > 0 else 0
+            hi = protein_embeds.shape[1] - (1 if j < rows.numel() - 1 else 0)
+            parts.append(protein_embeds[r, lo:hi])
+        cat = torch.cat(parts, 0)
+        if cat.shape[0] < max_size:
+            cat = torch.cat([cat, torch.zeros(max_size - cat.shape[0], d, dtype=cat.dtype, device=cat.device)], 0)
+        out.append(cat[:max_size])
+    return torch.stack(out)

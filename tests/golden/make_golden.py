@@ -66,7 +66,7 @@ def ref_ns():
     import torch.nn.functional as F
     from typing import List, Optional
     ns = {"torch": torch, "nn": nn, "F": F, "math": math, "np": np, "List": List, "Optional": Optional}
-    extract("procyon/training/train_utils.py", {"batched_split_long_seq", "get_after_answer_tokens"}, ns)
+    extract("procyon/training/train_utils.py", {"batched_split_long_seq", "get_after_answer_tokens", "reverse_batched_split"}, ns)
     extract("procyon/model/esm.py", {"ProteinPooler"}, ns)
     extract("procyon/model/model_utils.py", {"create_mlp", "left_pad_tensors"}, ns)
     extract("procyon/model/model_unified.py",
@@ -435,10 +435,30 @@ def g11():
     print("wrote g11_prompts.json.gz", len(cases), "cases")
 
 
+# --------------------------------------------------------------------------- g12 reverse_batched_split (ESM_PLM.forward(aggregate=False))
+def g12(ns):
+    """per-position states of split proteins laid end to end again (train_utils.py:1599-1649), fed by the reference's own splitter"""
+    out = {}
+    g = torch.Generator().manual_seed(12)
+    for n, lens in enumerate([[300, 40], [2049, 300, 1500], [3073, 10], [1025, 1024, 7]]):
+        toks = synth.protein_tokens(lens, seed=120 + n)
+        new, keys, eos = ns["batched_split_long_seq"](toks.clone(), 1, 2, "split", 1024)
+        emb = torch.randn(new.shape[0], new.shape[1], 2, generator=g)
+        out[f"toks{n}"] = toks
+        out[f"emb{n}"] = emb
+        out[f"keys{n}"] = keys
+        out[f"eos{n}"] = torch.tensor([int(e) for e in eos])
+        out[f"out{n}"] = ns["reverse_batched_split"](emb.clone(), keys, eos)
+    save("g12_reverse_split", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["g12"]:
+        g12(ref_ns())
+        sys.exit(0)
     if sys.argv[1:] == ["g11"]:
         g11()
         sys.exit(0)
     ns = ref_ns()
-    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns); g11()
+    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns); g11(); g12(ns)

@@ -318,3 +318,78 @@ def test_esm_layer_stack_fast_vs_exact_attention(monkeypatch):
     e = rel_err(b, a)
     print(f"4-layer ESM2-650M-width stack: err(fast attention, exact attention) {e:.3e}")
     assert e < 8e-3
+
+
+# ---------------------------------------------------------------------------------------------- full sub-module outputs (waist contract)
+def test_llama_forward_full_logits_and_hidden_states_tuple():
+    """`LlamaPostTokenization.forward` with the reference's arguments only returns the reference's object (pmc_llama.py:575-596):
+    `.logits` [B,T,V] for every row and `.hidden_states` = the L+1 tuple (embeddings, layer outputs, final-normed last state),
+    which route B of INTEGRATION.md (the reference's own UnifiedProCyon over these sub-modules) reads at model_unified.py:556-563."""
+    from oracle import llama_ref as LR
+    from procyon_amd import synth
+    from procyon_amd.engine import LlamaConfig
+    from procyon_amd.model import LlamaPostTokenization
+    kw = dict(vocab=331, d=256, n_layers=3, n_heads=4, n_kv_heads=2, ffn=512)
+    sd = synth.llama_state_dict(**kw)
+    enc = LlamaPostTokenization({k: v.clone() for k, v in sd.items()}, LlamaConfig(**kw, max_pos=256), torch.device("cuda"), 8)
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 70                                   # 140 rows > 64: the lm_head runs as a GEMM
+    ids = torch.randint(0, 331, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long); mask[1, -9:] = 0
+    emb = torch.nn.functional.embedding(ids, sd["model.embed_tokens.weight"])
+    out = enc(input_embeds=emb.cuda(), attn_masks=mask)
+    ref = LR.llama_forward(sd, LR.LlamaGeom(**kw), inputs_embeds=emb, attn_mask=mask, want_hidden=True)
+    assert out.logits.shape == (B, T, 331) and len(out.hidden_states) == kw["n_layers"] + 1
+    valid = mask.bool()
+    assert rel_err(out.logits.cpu()[valid], ref["logits"][valid]) < 1e-2
+    hs = [h.cpu() for h in out.hidden_states]                  # iteration materialises the tuple
+    assert torch.equal(hs[0], emb)
+    for i, (a, b) in enumerate(zip(hs, ref["hidden_states"])):
+        assert a.shape == (B, T, 256) and rel_err(a[valid], b[valid]) < 6e-3, i
+    assert torch.equal(out.hidden_states[-1].cpu(), hs[-1])    # the fast path's last state == the materialised one
+    # what ret_token_access='all' does with it (model_unified.py:560-563)
+    summed = torch.stack(list(out.hidden_states), dim=-1).sum(dim=-1).cpu()
+    assert rel_err(summed[valid], torch.stack(ref["hidden_states"], dim=-1).sum(dim=-1)[valid]) < 6e-3
+    # eager form + the engine's row-limited sum agree with the tuple
+    out2 = enc(input_embeds=emb.cuda(), attn_masks=mask, output_hidden_states=True, hidden_sum_positions=torch.tensor([3, 80]))
+    assert torch.equal(out2.hidden_states[2], out.hidden_states[2])
+    assert rel_err(out2.hidden_state_sum_rows.cpu(), summed.view(B * T, -1)[[3, 80]]) < 4e-3
+
+
+def test_esm_plm_forward_aggregate_false_states_and_mlm_logits():
+    """`ESM_PLM.forward(tokens, aggregate=False)` (esm.py:547-558): per-position states of split proteins laid end to end
+    (`reverse_batched_split`) and the masked-LM logits, against the oracle's encoder + an op-by-op restatement of the head"""
+    import torch.nn.functional as F
+    from oracle import esm_ref as ER
+    from oracle import procyon_ref as PR
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig
+    from procyon_amd.model import ESM_PLM
+    from procyon_amd.sequences import reverse_batched_split
+    kw = dict(d=128, n_layers=2, n_heads=2, ffn=256)
+    sd = synth.esm_state_dict(**kw)
+    g = torch.Generator().manual_seed(8)
+    r = lambda *s, std=0.05: (torch.randn(*s, generator=g) * std).to(BF)
+    head = {"lm_head.dense.weight": r(128, 128), "lm_head.dense.bias": r(128), "lm_head.layer_norm.weight": (1 + r(128)).to(BF),
+            "lm_head.layer_norm.bias": r(128), "lm_head.bias": r(33)}
+    plm = ESM_PLM({**sd, **head}, EsmConfig(**kw), pooling_method="mean", max_protein_len=64, device=torch.device("cuda"))
+    toks = synth.protein_tokens([150, 30, 64, 65], seed=5)       # 150 -> 3 chunks, 65 -> 2 chunks at max_protein_len 64
+    z, logits = plm(toks, aggregate=False)
+    rows, keys, eos = PR.batched_split_long_seq(toks, max_protein_len=64)
+    h = ER.esm_forward(sd, ER.EsmGeom(**kw), rows)
+    h = h * (rows != 1)[..., None]                              # pad positions: zero here
+    z_ref = reverse_batched_split(h, keys, eos)
+    assert z.shape == z_ref.shape == (4, 152, 128)
+    assert rel_err(z.cpu(), z_ref) < 8e-3
+    y = F.linear(h, head["lm_head.dense.weight"], head["lm_head.dense.bias"])
+    y = ((y * 0.5) * (1.0 + torch.erf(y / 2 ** 0.5)))           # fair-esm `gelu`, each op materialised in bf16
+    y = F.layer_norm(y, (128,), head["lm_head.layer_norm.weight"], head["lm_head.layer_norm.bias"], 1e-5)
+    lg_ref = reverse_batched_split(F.linear(y, sd["esm.embeddings.word_embeddings.weight"], head["lm_head.bias"]), keys, eos)
+    assert logits.shape == lg_ref.shape == (4, 152, 33)
+    real = torch.zeros(4, 152, dtype=torch.bool)
+    for i, n in enumerate([150, 30, 64, 65]):
+        real[i, :n + 2] = True
+    assert rel_err(logits.cpu()[real], lg_ref[real]) < 1.5e-2
+    # a checkpoint without the head: states only
+    z2, lg2 = ESM_PLM(sd, EsmConfig(**kw), pooling_method="mean", max_protein_len=64, device=torch.device("cuda"))(toks, aggregate=False)
+    assert lg2 is None and torch.equal(z2, z)

@@ -186,3 +186,16 @@ def test_engine_batch_chooser_and_lazy_past_views():
         assert False
     except IndexError:
         pass
+
+
+def test_reverse_batched_split_matches_the_reference(golden):
+    """`ESM_PLM.forward(aggregate=False)` relies on `reverse_batched_split` (train_utils.py:1599-1649): the product restatement
+    against the reference's own function (golden g12, fed by the reference's splitter), and the product splitter feeding it"""
+    from procyon_amd.sequences import reverse_batched_split, split_or_truncate_long_seq
+    g = golden("g12_reverse_split")
+    for n in range(4):
+        out = reverse_batched_split(g[f"emb{n}"], g[f"keys{n}"], g[f"eos{n}"].tolist())
+        assert torch.equal(out, g[f"out{n}"]), n
+        rows, keys, eos = split_or_truncate_long_seq(g[f"toks{n}"], 1, 2, "split", 1024)
+        assert torch.equal(keys, g[f"keys{n}"]) and eos == g[f"eos{n}"].tolist()
+        assert out.shape[:2] == (g[f"toks{n}"].shape[0], max(eos) + 1)
