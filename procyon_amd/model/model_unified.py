@@ -70,6 +70,24 @@ def multi_replace_tokens(a, b, replace_token, eval=False):
     return result
 
 
+def special_token_ids(tokenizer, text_encoder_fname):
+    """The token ids `UnifiedProCyon.__init__` / `_init_tokenizer` keep (model_unified.py:1100-1133, 342-347), read from a
+    tokenizer on which the eight ProCyon tokens are already registered (`procyon_amd.checkpoint.hf_tokenizer` does that in the
+    reference's order; the reference reads them back with `tokenizer(tok, add_special_tokens=False).input_ids[0]`, which for an
+    added token is its id).  Llama-3 names take the yes / no ids of " yes" / " no" (leading space), others of "yes" / "no"."""
+    t = tokenizer
+    ids = dict(prot_replacement_idx=t.convert_tokens_to_ids("<|protein|>"), prot_retrieval_idx=t.convert_tokens_to_ids("[PROT]"),
+               answer_idx=t.convert_tokens_to_ids("[ANSWER]"), struct_idx=t.convert_tokens_to_ids("<|struct|>"),
+               drug_idx=t.convert_tokens_to_ids("<|drug|>"), ext_idx=t.convert_tokens_to_ids("[EXT]"))
+    if "llama-3" in text_encoder_fname.lower():  # model_unified.py:342-347
+        ids["yes_token"] = t.encode(" yes", add_special_tokens=False)[0]
+        ids["no_token"] = t.encode(" no", add_special_tokens=False)[0]
+    else:
+        ids["yes_token"] = t.encode("yes", add_special_tokens=False)[0]
+        ids["no_token"] = t.encode("no", add_special_tokens=False)[0]
+    return ids
+
+
 class UnifiedProCyon:
     def __init__(self, config: ProCyonConfig, text_encoder, tokenizer, protein_seq_encoder=None, token_projectors=None,
                  aaseq_shared_projector: Optional[MlpEngine] = None, aaseq_lm_projector: Optional[MlpEngine] = None,
@@ -95,19 +113,8 @@ class UnifiedProCyon:
         self.train_qa_full_lm = False
         self.struct_dropout_prob = config.protein_struct_dropout
         # special tokens, registered in the order of `_init_tokenizer` (model_unified.py:1100-1133)
-        t = tokenizer
-        self.prot_replacement_idx = t.convert_tokens_to_ids("<|protein|>")
-        self.prot_retrieval_idx = t.convert_tokens_to_ids("[PROT]")
-        self.answer_idx = t.convert_tokens_to_ids("[ANSWER]")
-        self.struct_idx = t.convert_tokens_to_ids("<|struct|>")
-        self.drug_idx = t.convert_tokens_to_ids("<|drug|>")
-        self.ext_idx = t.convert_tokens_to_ids("[EXT]")
-        if "llama-3" in config.text_encoder_fname.lower():  # model_unified.py:342-347
-            self.yes_token = t.encode(" yes", add_special_tokens=False)[0]
-            self.no_token = t.encode(" no", add_special_tokens=False)[0]
-        else:
-            self.yes_token = t.encode("yes", add_special_tokens=False)[0]
-            self.no_token = t.encode("no", add_special_tokens=False)[0]
+        for k, v in special_token_ids(tokenizer, config.text_encoder_fname).items():
+            setattr(self, k, v)
 
     # nn.Module protocol used by the callers (retrieval_utils.py:90-101, procyon.py:64-67).  The reference model is built in the
     # checkpoint's dtype (fp32) and every shipped entry point calls `.bfloat16()` before the first forward -- except

@@ -452,8 +452,112 @@ def g12(ns):
     save("g12_reverse_split", **out)
 
 
+# --------------------------------------------------------------------------- g13 input builders (row f2)
+def g13():
+    """The REFERENCE's `create_caption_input_simple` / `create_qa_input_simple` / `create_input_retrieval`
+    (procyon/data/inference_utils.py:67-244, 247-420, 663-843, AST-extracted; their helpers `construct_task_id`,
+    `get_text_sequences_compositions`, `get_prompt[_open_def]` and the column tables come from the reference too) run over the
+    synthetic ProCyon-Instruct tree of tests/synth_instruct.py.  The fixture holds the inputs the tree is built from (seven task
+    templates are already in g11; here the description-column tables of the four datasets of the tree) and the returned
+    dictionaries.  The CPU test rebuilds the identical tree and runs the shim's builders."""
+    import gzip
+    import importlib.util
+    import json
+    import tempfile
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_instruct as SI
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ref_ic = load("ref_ic", "procyon/data/instruct_tune/instruct_constructor.py")
+    ref_const = load("ref_const", "procyon/data/constants.py")
+    datasets = ("uniprot", "omim", "disgenet", "pfam")
+    tables = {"ENTITY_DESCRIPTION_NAMES": {d: ref_const.ENTITY_DESCRIPTION_NAMES[d] for d in datasets}}
+    for key in ("QA_SUBSETS", "RETRIEVAL_SUBSETS", "CAPTION_SUBSETS"):
+        t = getattr(ref_const, key)
+        tables[key] = {str(ver): {d: cols[d] for d in datasets if d in cols} for ver, cols in t.items()}
+    with gzip.open(os.path.join(HERE, "g11_prompts.json.gz"), "rt") as f:
+        tasks = json.load(f)["tasks"]
+    with tempfile.TemporaryDirectory() as root:
+        data_dir, home_dir = SI.build_tree(root, tasks, tables)
+        from typing import Dict, List, Optional
+        from procyon.training.training_args_IT import DataArgs       # the shim's argument class (same fields)
+        ns = {"torch": torch, "pd": pd, "np": np, "os": os, "json": json, "List": List, "Dict": Dict, "Optional": Optional,
+              "DataArgs": DataArgs, "DATA_DIR": data_dir, "HOME_DIR": home_dir, "get_prompt": ref_ic.get_prompt,
+              "get_prompt_open_def": ref_ic.get_prompt_open_def,
+              "QA_SUBSETS": ref_const.QA_SUBSETS, "RETRIEVAL_SUBSETS": ref_const.RETRIEVAL_SUBSETS, "CAPTION_SUBSETS": ref_const.CAPTION_SUBSETS,
+              "ENTITY_DESCRIPTION_NAMES": ref_const.ENTITY_DESCRIPTION_NAMES, "DRUGMASK": None}
+        extract("procyon/data/it_collator.py", {"construct_task_id"}, ns)
+        extract("procyon/data/data_utils.py", {"get_text_sequences_compositions"}, ns)
+        # module-level tables of the reference file, built the way it builds them (inference_utils.py:42-51)
+        ns["UNIPROT_IDS"] = pd.read_pickle(os.path.join(data_dir, "integrated_data/v1/protein/", "protein_info_filtered.pkl"))[["index", "protein_id", "name"]]
+        ns["functional_descriptions"] = pd.read_pickle(
+            os.path.join(data_dir, "integrated_data/v1/protein/uniprot_functional_descriptions.pkl")).sort_values("index", axis=0)["function"]
+        extract("procyon/data/inference_utils.py", {"create_caption_input_simple", "create_qa_input_simple", "create_input_retrieval",
+                                                    "uniprot_id_to_index", "index_to_uniprot_id"}, ns)
+        cases = []
+        for fn, kw in SI.BUILDER_CASES:
+            try:
+                out = SI.jsonable(ns[fn](data_args=DataArgs(), **kw))
+            except Exception as e:      # the reference's own behaviour on this argument combination (e.g. QA + task_definition: KeyError 'answer')
+                out = {"__raises__": type(e).__name__}
+            cases.append(dict(fn=fn, kwargs=kw, out=out))
+        ids = dict(p530=ns["uniprot_id_to_index"]("P00530"), i5=ns["index_to_uniprot_id"](5))
+    with gzip.open(os.path.join(HERE, "g13_input_builders.json.gz"), "wt") as f:
+        json.dump(dict(tables=tables, cases=cases, ids=ids), f)
+    print("wrote g13_input_builders.json.gz", len(cases), "cases", os.path.getsize(os.path.join(HERE, "g13_input_builders.json.gz")), "bytes")
+
+
+# --------------------------------------------------------------------------- g14 _init_tokenizer on a real tokenizer object (row f2)
+def g14(ns):
+    """The REFERENCE's `_init_tokenizer` (model_unified.py:1088-1133), its yes / no id rule (:342-347) and
+    `_prepare_text_inputs_and_tokenize` (:1177-1293), run over a real `PreTrainedTokenizerFast` (tests/synth_tokenizer.py: a
+    Llama-3-style byte-level BPE built in the container, loaded through $LLAMA3_PATH like the reference does)."""
+    import json
+    import random
+    import tempfile
+    import transformers
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth_tokenizer as ST
+    extract("procyon/model/model_unified.py", {"UnifiedProCyon._init_tokenizer", "UnifiedProCyon._prepare_text_inputs_and_tokenize"}, ns)
+    ns.update(random=random, os=os, transformers=transformers)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        ST.build(d)
+        os.environ["LLAMA3_PATH"] = d
+        self = types.SimpleNamespace(config=types.SimpleNamespace(text_encoder_fname="llama-3-8b", max_text_len=96), pretrained_weights_dir=d,
+                                     training=False, context_crop_sampling=False)
+        ns["_init_tokenizer"](self)
+        tk = self.tokenizer
+        out["ids"] = {k: int(getattr(self, k)) for k in ("prot_replacement_idx", "prot_retrieval_idx", "answer_idx", "struct_idx", "drug_idx", "ext_idx")}
+        out["sep_token_id"], out["pad_token_id"], out["len"] = int(tk.sep_token_id), int(tk.pad_token_id), len(tk)
+        out["eos_token_id"], out["bos_token_id"], out["padding_side"] = int(tk.eos_token_id), int(tk.bos_token_id), tk.padding_side
+        out["yes_token"] = int(tk.encode(" yes", add_special_tokens=False)[0])      # model_unified.py:342-344 ("llama-3" in the name)
+        out["no_token"] = int(tk.encode(" no", add_special_tokens=False)[0])
+        out["encode_samples"] = {t: tk(t, add_special_tokens=True)["input_ids"] for t in
+                                 ("w <|protein|> x [ANSWER]", "[EXT][PROT] yes", " yes", "yes", "<|drug|> tail")}
+        for no_pad, left_pad, nm in ((False, False, "pad"), (True, True, "leftpad")):
+            ids, mask = ns["_prepare_text_inputs_and_tokenize"](self, list(ST.INSTRUCTIONS), [list(t) for t in ST.TEXTS], crop_off=True,
+                                                                retrieval=False, no_pad=no_pad, left_pad=left_pad)
+            out[f"prep_ids_{nm}"], out[f"prep_mask_{nm}"] = ids.tolist(), mask.tolist()
+        out["decode"] = tk.batch_decode(torch.tensor(out["prep_ids_leftpad"])[:, -12:])
+    with open(os.path.join(HERE, "g14_real_tokenizer.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote g14_real_tokenizer.json", out["ids"], out["len"], os.path.getsize(os.path.join(HERE, "g14_real_tokenizer.json")), "bytes")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["g14"]:
+        g14(ref_ns())
+        sys.exit(0)
+    if sys.argv[1:] == ["g13"]:
+        g13()
+        sys.exit(0)
     if sys.argv[1:] == ["g12"]:
         g12(ref_ns())
         sys.exit(0)
@@ -461,4 +565,4 @@ if __name__ == "__main__":
         g11()
         sys.exit(0)
     ns = ref_ns()
-    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns); g11(); g12(ns)
+    g1(ns); g2(ns); g3(ns); g4(ns); g5(); g6(); g7(ns); g8(ns); g9(ns); g10(ns); g11(); g12(ns); g13(); g14(ns)

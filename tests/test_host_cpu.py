@@ -86,10 +86,12 @@ def test_checkpoint_key_mapping():
         k2 = k2.replace("attention.LayerNorm", "self_attn_layer_norm").replace("intermediate.dense", "fc1").replace("output.dense", "fc2")
         k2 = k2.replace(".LayerNorm.", ".final_layer_norm.")
         fair[k2] = v
-    fair["lm_head.weight"] = torch.zeros(3)                  # dropped
+    fair["lm_head.weight"] = torch.zeros(3)                  # the tied decoder of the masked-LM head: kept under its HF name
+    fair["lm_head.dense.weight"] = torch.zeros(3)
+    fair["contact_head.regression.weight"] = torch.zeros(3)  # dropped
     fair["layers.0.self_attn.rot_emb.inv_freq"] = torch.zeros(3)
     back = fair_esm_to_hf(fair)
-    assert set(back) == set(hf) and all(back[k] is hf[k] for k in hf)
+    assert set(back) == set(hf) | {"lm_head.decoder.weight", "lm_head.dense.weight"} and all(back[k] is hf[k] for k in hf)
     llama = synth.llama_state_dict(vocab=50, d=256, n_layers=2, n_heads=2, n_kv_heads=1, ffn=512, dtype=torch.float32)
     sd = {"text_encoder.model." + k: v for k, v in llama.items()}
     sd.update({"protein_seq_encoder.model." + k: v for k, v in fair.items()})
@@ -99,7 +101,7 @@ def test_checkpoint_key_mapping():
     sd["protein_seq_embeddings.weight"] = torch.zeros(5, 64)
     sd["contrastive_head.temperature"] = torch.zeros(1)      # training-only, ignored
     parts = split_state_dict(sd)
-    assert set(parts["llama"]) == set(llama) and set(parts["esm"]) == set(hf)
+    assert set(parts["llama"]) == set(llama) and set(parts["esm"]) == set(hf) | {"lm_head.decoder.weight", "lm_head.dense.weight"}
     assert [w.shape for w, _ in parts["projectors"]["token_aaseq"]] == [(96, 64), (96, 96), (256, 96)]
     assert set(parts["projectors"]) == {"token_aaseq", "aaseq_shared_projector", "aaseq_lm_projector"}
     assert list(parts["tables"]) == ["protein_seq_embeddings"]
@@ -199,3 +201,39 @@ def test_reverse_batched_split_matches_the_reference(golden):
         rows, keys, eos = split_or_truncate_long_seq(g[f"toks{n}"], 1, 2, "split", 1024)
         assert torch.equal(keys, g[f"keys{n}"]) and eos == g[f"eos{n}"].tolist()
         assert out.shape[:2] == (g[f"toks{n}"].shape[0], max(eos) + 1)
+
+
+def test_init_tokenizer_on_a_real_pretrained_tokenizer_fast(tmp_path):
+    """Row f2: the tokenizer set-up on a REAL `PreTrainedTokenizerFast` (a Llama-3-style byte-level BPE built in the container,
+    tests/synth_tokenizer.py) against the reference's own `_init_tokenizer` / yes-no rule / `_prepare_text_inputs_and_tokenize`
+    run over the identical tokenizer directory (golden g14): registration order, `[EXT]` = len(tokenizer) - 1, pad / sep ids,
+    " yes" / " no" ids, BOS handling, [EXT] splicing with truncation budgets, left padding."""
+    import json
+    import os
+    import synth_tokenizer as ST
+    from procyon_amd.checkpoint import hf_tokenizer
+    from procyon_amd.model.model_unified import special_token_ids
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_real_tokenizer.json")))
+    tk = hf_tokenizer(ST.build(str(tmp_path / "llama3")))
+    import transformers
+    assert isinstance(tk, transformers.PreTrainedTokenizerFast)
+    ids = special_token_ids(tk, "llama-3-8b")
+    for k, v in g["ids"].items():
+        assert ids[k] == v, k
+        tok_str = {"prot_replacement_idx": "<|protein|>", "prot_retrieval_idx": "[PROT]", "answer_idx": "[ANSWER]", "struct_idx": "<|struct|>",
+                   "drug_idx": "<|drug|>", "ext_idx": "[EXT]"}[k]
+        assert tk(tok_str, add_special_tokens=False).input_ids[0] == v      # the reference's way of reading it back
+    assert (ids["yes_token"], ids["no_token"]) == (g["yes_token"], g["no_token"])
+    assert (tk.sep_token_id, tk.pad_token_id, len(tk), tk.eos_token_id, tk.bos_token_id, tk.padding_side) == \
+        (g["sep_token_id"], g["pad_token_id"], g["len"], g["eos_token_id"], g["bos_token_id"], g["padding_side"])
+    assert ids["ext_idx"] == len(tk) - 1                                    # the embedding table has len(tokenizer) - 1 rows (:166)
+    for text, want in g["encode_samples"].items():
+        assert tk(text, add_special_tokens=True)["input_ids"] == want, text
+    m = object.__new__(UnifiedProCyon)
+    m.tokenizer, m.config = tk, ProCyonConfig(max_text_len=96)
+    m.drug_idx, m.ext_idx = ids["drug_idx"], ids["ext_idx"]
+    for no_pad, left_pad, nm in ((False, False, "pad"), (True, True, "leftpad")):
+        out_ids, mask = m._prepare_text_inputs_and_tokenize(list(ST.INSTRUCTIONS), [list(t) for t in ST.TEXTS], crop_off=True,
+                                                            no_pad=no_pad, left_pad=left_pad)
+        assert out_ids.tolist() == g[f"prep_ids_{nm}"] and mask.tolist() == g[f"prep_mask_{nm}"], nm
+    assert tk.batch_decode(torch.tensor(g["prep_ids_leftpad"])[:, -12:]) == g["decode"]

@@ -306,3 +306,32 @@ def test_eval_plugins_follow_the_registry_constructor_contract(monkeypatch, caps
     # ignored fields: *path, n_model_pieces, model_splitting
     a, b = ModelArgs(protein_seq_embeddings_path="/a"), ModelArgs(protein_seq_embeddings_path="/b")
     assert compare_and_warn_model_args(a, b) == []
+
+
+def test_input_builders_match_the_reference_functions(tmp_path, g11, monkeypatch):
+    """Row f2: `create_caption_input_simple` / `create_qa_input_simple` / `create_input_retrieval` against the REFERENCE's own
+    functions (AST-extracted and run in the build container over the same synthetic tree: golden g13, tests/golden/make_golden.py),
+    incl. the description-column tables, the first-non-missing-column rule, context augmentation, custom task definitions and
+    the argument combination on which the reference itself raises."""
+    import synth_instruct as SI
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "g13_input_builders.json.gz"), "rt") as f:
+        g13 = json.load(f)
+    data, home = SI.build_tree(str(tmp_path), g11["tasks"], g13["tables"])
+    monkeypatch.setenv("DATA_DIR", data)
+    monkeypatch.setenv("HOME_DIR", home)
+    import procyon.data.constants as C
+    import procyon.data.inference_utils as IU
+    from procyon.training.training_args_IT import DataArgs
+    C._cache = None
+    IU._LAZY.clear()
+    assert IU.uniprot_id_to_index("P00530") == g13["ids"]["p530"] and IU.index_to_uniprot_id(5) == g13["ids"]["i5"]
+    assert len(g13["cases"]) >= 16
+    for c in g13["cases"]:
+        fn = getattr(IU, c["fn"])
+        if "__raises__" in c["out"]:
+            with pytest.raises(Exception) as ei:
+                fn(data_args=DataArgs(), **c["kwargs"])
+            assert type(ei.value).__name__ == c["out"]["__raises__"], (c["fn"], c["kwargs"])
+            continue
+        out = SI.jsonable(fn(data_args=DataArgs(), **c["kwargs"]))
+        assert out == c["out"], (c["fn"], c["kwargs"], out, c["out"])
