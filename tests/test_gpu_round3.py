@@ -393,3 +393,141 @@ def test_esm_plm_forward_aggregate_false_states_and_mlm_logits():
     # a checkpoint without the head: states only
     z2, lg2 = ESM_PLM(sd, EsmConfig(**kw), pooling_method="mean", max_protein_len=64, device=torch.device("cuda"))(toks, aggregate=False)
     assert lg2 is None and torch.equal(z2, z)
+
+
+# ---------------------------------------------------------------------------------------------- bulk scripts + service (row f4)
+def _service_checkpoint(root, vocab, n_prot=20000, D=128):
+    """checkpoint directory of an embedding-table model (use_aaseq_embeddings=True, the shipped ProCyon-Full layout): Llama-geometry
+    decoder with head_dim 128, projectors, protein_seq_embeddings [n_prot, D], and the cached target matrix of the service"""
+    from procyon.training.training_args_IT import DataArgs, ModelArgs
+    from procyon_amd import synth
+    kw = dict(vocab=vocab, d=256, n_layers=2, n_heads=2, n_kv_heads=1, ffn=512)
+    sd = {"text_encoder.model." + k: v for k, v in synth.llama_state_dict(**kw).items()}
+    for name, (i, o), off in (("token_projectors.aaseq", (D, 256), 0), ("aaseq_shared_projector", (D, D), 20), ("aaseq_lm_projector", (256, D), 40)):
+        for j, (w, b) in zip((0, 3, 6), synth.mlp_layers(3, i, o, 96, off)):
+            sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = w, b
+    g = torch.Generator().manual_seed(77)
+    table = (torch.randn(n_prot, D, generator=g) * 0.5).to(BF)
+    sd["protein_seq_embeddings.weight"] = table
+    os.makedirs(root, exist_ok=True)
+    torch.save(ModelArgs(use_aaseq_embeddings=True, ret_token_access="last", protein_pooling_opt="mean", max_text_len=160), os.path.join(root, "model_args.pt"))
+    torch.save(DataArgs(data_dir="/x"), os.path.join(root, "data_args.pt"))
+    torch.save(sd, os.path.join(root, "txllm_model_ckpt.pt"))
+    return sd, table
+
+
+@pytest.fixture()
+def instruct_env(tmp_path, monkeypatch):
+    import gzip
+    import json
+    import synth_instruct as SI
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with gzip.open(os.path.join(root, "tests", "golden", "g11_prompts.json.gz"), "rt") as f:
+        tasks = json.load(f)["tasks"]
+    with gzip.open(os.path.join(root, "tests", "golden", "g13_input_builders.json.gz"), "rt") as f:
+        tables = json.load(f)["tables"]
+    data, home = SI.build_tree(str(tmp_path), tasks, tables)
+    monkeypatch.setenv("DATA_DIR", data)
+    monkeypatch.setenv("HOME_DIR", home)
+    import procyon.data.constants as C
+    import procyon.data.inference_utils as IU
+    C._cache = None
+    IU._LAZY.clear()
+    return tmp_path
+
+
+def test_bulk_caption_then_qa_filter_pipeline_matches_the_one_by_one_loops(instruct_env):
+    """scripts/caption_bulk.py:99-148 and scripts/qa_filter_captions.py:63-100 batched across proteins / pairs: the tables equal those
+    of the scripts' own one-prompt-per-call loops (restated here), the running pickle appears when the loop would have written it."""
+    import pandas as pd
+    from procyon.data.inference_utils import ProCyonQAInference, create_caption_input_simple, create_qa_input_simple, uniprot_id_to_index
+    from procyon_amd.checkpoint import from_pretrained
+    from procyon_amd.pipelines import caption_bulk, chunk_rows, qa_filter_captions
+    from procyon_amd.tokenizer import SyntheticTokenizer
+    tok = SyntheticTokenizer(n_text=2000, base_vocab=2048, bos_token_id=2040, eos_token_id=2041)
+    ckpt = str(instruct_env / "ckpt")
+    _service_checkpoint(ckpt, vocab=len(tok) - 1)
+    model, margs = from_pretrained(checkpoint_dir=ckpt, tokenizer=tok, max_new_tokens=16, max_pos=512)
+    from procyon.training.training_args_IT import DataArgs
+    dargs = DataArgs()
+    ids = [f"P{i:05d}" for i in (530, 7, 11, 19999, 5, 4242, 77)]
+    save = str(instruct_env / "captions.out")
+    seen = []
+    real_to_pickle = pd.DataFrame.to_pickle
+
+    def spy(self, path, *a, **k):
+        seen.append(len(self))
+        return real_to_pickle(self, path, *a, **k)
+
+    pd.DataFrame.to_pickle = spy
+    try:
+        df = caption_bulk(model, margs, dargs, ids, "uniprot", "all", max_len=6, beam_size=4, diversity_penalty=0.8, save_path=save, batch_size=3)
+    finally:
+        pd.DataFrame.to_pickle = real_to_pickle
+    assert list(df.columns) == ["uniprot_id", "response0", "response1"] and df["uniprot_id"].tolist() == ids
+    assert seen == [6]                                            # i = 5 is the only i % 5 == 0, i > 0 among 7 proteins: rows 0..5
+    assert pd.read_csv(save, index_col=0).shape == (7, 3)
+    # the script's loop: one protein per generate call
+    for i, u in enumerate(ids):
+        inp = create_caption_input_simple(input_aaseq_ids=[uniprot_id_to_index(u)], data_args=dargs, instruction_source_dataset="uniprot",
+                                          instruction_source_relation="all", aaseq_type="protein", task_type="caption", icl_example_number=1)
+        _, _, _, text = model.generate(inputs=inp, aaseq_type="protein", max_len=6, method="beam", beam_size=4, beam_group_size=2,
+                                       diversity_penalty=0.8)
+        want = [t.split("<|end_of_text|>")[0] for j, t in enumerate(text[0]) if j % 2 == 0]
+        assert [df["response0"].iloc[i], df["response1"].iloc[i]] == want, u
+    # QA filter over the captions (template: omim_all_qa)
+    qa = qa_filter_captions(model, dargs, df, "omim", "all", batch_size=4)
+    assert list(qa.columns) == ["uniprot_id", "response_num", "caption_output", "yes", "no"] and len(qa) == 14
+    assert qa["response_num"].tolist() == ["response0", "response1"] * 7
+    qam = ProCyonQAInference(model, device=model.device)
+    for k in (0, 5, 13):
+        u, cap = qa["uniprot_id"].iloc[k], qa["caption_output"].iloc[k]
+        one = qam(create_qa_input_simple(input_aaseq_ids=[uniprot_id_to_index(u)], data_args=dargs, input_description=cap,
+                                         instruction_source_dataset="omim", instruction_source_relation="all", aaseq_type="protein",
+                                         icl_example_number=1))["pred"]
+        assert abs(one[0, qam.yes_token].item() - qa["yes"].iloc[k]) < 2e-3 * max(1e-3, abs(qa["yes"].iloc[k])) + 1e-6
+        assert abs(one[0, qam.no_token].item() - qa["no"].iloc[k]) < 2e-3 * max(1e-3, abs(qa["no"].iloc[k])) + 1e-6
+    # chunking rules of the two scripts
+    assert chunk_rows(10, None, None) == (0, 10) and chunk_rows(10, 3, 0, "qa_filter_captions") == (0, 4)
+    assert chunk_rows(10, 3, 2, "qa_filter_captions") == (8, 10) and chunk_rows(10, 3, 1, "caption_bulk") == (4, 8)
+
+
+def test_fastapi_service_round_trip_on_a_synthetic_checkpoint(instruct_env, monkeypatch):
+    """procyon/app/main.py: start-up loads $CHECKPOINT_PATH through `startup_retrieval` (tokenizer files from $LLAMA3_PATH -- a real
+    PreTrainedTokenizerFast built in the container), POST /retrieve ranks the cached target matrix on the device."""
+    import pandas as pd
+    import torch.nn.functional as F
+    import synth_tokenizer as ST
+    from fastapi.testclient import TestClient
+    from procyon_amd.checkpoint import hf_tokenizer
+    tokdir = ST.build(str(instruct_env / "llama3"))
+    tk = hf_tokenizer(tokdir)
+    ckpt = str(instruct_env / "ckpt")
+    _, table = _service_checkpoint(ckpt, vocab=len(tk) - 1)
+    g = torch.Generator().manual_seed(5)
+    targets = torch.randn(20000, 128, generator=g)                           # fp32, as the reference's cached matrix
+    torch.save((targets, list(range(20000))), os.path.join(ckpt, "protein_target_embeddings.pkl"))
+    for k, v in (("CHECKPOINT_PATH", ckpt), ("LLAMA3_PATH", tokdir)):
+        monkeypatch.setenv(k, v)
+    import procyon.app.main as APP
+    with TestClient(APP.app) as client:
+        r = client.post("/retrieve", json={"task_desc": "Find proteins linked to the condition.", "disease_desc": "a disease description",
+                                           "instruction_source_dataset": "disgenet", "k": 7})
+        assert r.status_code == 200, r.text
+        rows = r.json()["results"]
+        assert len(rows) == 7 and set(rows[0]) == {"uniprot_id", "name", "sim_score"}
+        sims = [x["sim_score"] for x in rows]
+        assert sims == sorted(sims, reverse=True)
+        # the same query straight through the model: identical ranking
+        model = APP.state["model"]
+        from procyon.data.inference_utils import create_input_retrieval
+        inp = create_input_retrieval(input_description="a disease description", data_args=APP.state["data_args"],
+                                     task_definition="Find proteins linked to the condition.", instruction_source_dataset="disgenet")
+        q = model(inputs=inp, retrieval=True, aaseq_type="protein")["contrastive_out"]["positive"]["text"][0].float().cpu()
+        ref = F.normalize(q[None].double()) @ F.normalize(targets.double()).T
+        top = torch.argsort(ref[0], descending=True)[:7].tolist()
+        assert [x["uniprot_id"] for x in rows] == [f"P{i:05d}" for i in top]
+        bad = client.post("/retrieve", json={"task_desc": "t", "disease_desc": "d", "instruction_source_dataset": "uniprot"})
+        assert bad.status_code == 422
+        allr = client.post("/retrieve", json={"task_desc": "t", "disease_desc": "d", "instruction_source_dataset": "omim"})
+        assert allr.status_code == 200 and len(allr.json()["results"]) == 20000
