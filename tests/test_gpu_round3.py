@@ -404,7 +404,7 @@ def _service_checkpoint(root, vocab, n_prot=20000, D=128):
     kw = dict(vocab=vocab, d=256, n_layers=2, n_heads=2, n_kv_heads=1, ffn=512)
     sd = {"text_encoder.model." + k: v for k, v in synth.llama_state_dict(**kw).items()}
     for name, (i, o), off in (("token_projectors.aaseq", (D, 256), 0), ("aaseq_shared_projector", (D, D), 20), ("aaseq_lm_projector", (256, D), 40)):
-        for j, (w, b) in zip((0, 3, 6), synth.mlp_layers(3, i, o, 96, off)):
+        for j, (w, b) in zip((0, 3, 6), synth.mlp_layers(3, i, o, 128, off)):
             sd[f"{name}.{j}.weight"], sd[f"{name}.{j}.bias"] = w, b
     g = torch.Generator().manual_seed(77)
     table = (torch.randn(n_prot, D, generator=g) * 0.5).to(BF)
@@ -529,5 +529,5 @@ def test_fastapi_service_round_trip_on_a_synthetic_checkpoint(instruct_env, monk
         assert [x["uniprot_id"] for x in rows] == [f"P{i:05d}" for i in top]
         bad = client.post("/retrieve", json={"task_desc": "t", "disease_desc": "d", "instruction_source_dataset": "uniprot"})
         assert bad.status_code == 422
-        allr = client.post("/retrieve", json={"task_desc": "t", "disease_desc": "d", "instruction_source_dataset": "omim"})
+        allr = client.post("/retrieve", json={"task_desc": "t", "disease_desc": "d", "instruction_source_dataset": "disgenet"})
         assert allr.status_code == 200 and len(allr.json()["results"]) == 20000
