@@ -174,3 +174,26 @@ def test_fp8_prefill_fused_norm_quant_bit_identical(monkeypatch):
             outs.append((logits.cpu(), hidden.cpu(), cache.k.cpu().clone(), cache.v.cpu().clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+def test_fp8_error_growth_per_layer_is_a_random_walk():
+    """Round-2 review item 6: the answer-row logits of the fp8 path sit 0.66 (relative) from the bf16 path after 32 random-init
+    layers -- W8A8 noise or a kernel defect?  Walk the layers (tools/fp8_layer_walk.py): the distance of the residual stream must
+    (a) start at the one-layer quantisation distance the CPU oracle's fp8 path shows for the same weights, (b) grow like
+    e_1 * sqrt(l) -- independent, equally sized kicks into an undamped residual stream -- with no jump at any layer, and (c) the
+    GPU's fp8 states must stay much closer to the oracle's fp8 states than fp8 is to bf16."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fp8_layer_walk import walk
+    r = walk(n_layers=32, oracle_layers=3, T=48, verbose=False)
+    rows = r["rows"]
+    e = [x["gpu_fp8_vs_bf16"] for x in rows]
+    print("err(fp8, bf16) after layers 1, 2, 4, 8, 16, 31:", [f"{e[i]:.3f}" for i in (0, 1, 3, 7, 15, 30)], "| sqrt model:",
+          [f"{rows[i]['sqrt_model']:.3f}" for i in (0, 1, 3, 7, 15, 30)], "| last-row logits", f"{r['last_row_logits']:.3f}")
+    for i in range(3):          # (a), (c): the first layers against the oracle
+        assert 0.6 < e[i] / rows[i]["oracle_fp8_vs_bf16"] < 1.6, (i, e[i], rows[i]["oracle_fp8_vs_bf16"])
+        assert rows[i]["gpu_fp8_vs_oracle_fp8"] < 0.6 * rows[i]["oracle_fp8_vs_bf16"], i
+    for i in range(1, len(e)):  # (b): sqrt growth within a factor, and no jump
+        assert 0.5 < e[i] / rows[i]["sqrt_model"] < 1.8, (i + 1, e[i], rows[i]["sqrt_model"])
+        assert e[i] < 1.35 * e[i - 1] + 0.02, (i + 1, e[i - 1], e[i])
