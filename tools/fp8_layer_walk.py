@@ -24,7 +24,8 @@ def walk(n_layers=32, oracle_layers=4, T=64, B=2, vocab=512, seed=11, verbose=Tr
     kw = dict(vocab=vocab, d=4096, n_heads=32, n_kv_heads=8, ffn=14336)
     g = torch.Generator().manual_seed(seed)
     emb = (torch.randn(B, T, 4096, generator=g) * 0.02).bfloat16()
-    eng = LlamaEngine(synth.llama_state_dict(**kw, n_layers=n_layers, device="cuda"), LlamaConfig(**kw, n_layers=n_layers, max_pos=512),
+    # weights seeded on the CPU (the device generator draws other numbers): the oracle's first layers are then the SAME tensors
+    eng = LlamaEngine(synth.llama_state_dict(**kw, n_layers=n_layers, workers=16), LlamaConfig(**kw, n_layers=n_layers, max_pos=512),
                       free_source=True, fp8_prefill=True)
     eng.set_fp8(False)
     lg16, h16 = eng.prefill_all(emb.cuda(), None, eng.new_cache(B, T), "last")
