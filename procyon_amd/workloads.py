@@ -55,6 +55,37 @@ def run_config4(model, new_tokens=512, ragged=False, rows=32):
             "seconds": round(dt, 3), "tokens_per_s": round(rows * new_tokens / dt, 1)}
 
 
+def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
+    """HBM roofline of the BATCHED decode step (BASELINE configs[3] shape: `rows` prompts of `prompt` tokens, `new_tokens` greedy
+    steps): HIP-event time of the hipGraph-replayed steps, algorithmic bytes per step = every weight once
+    (15,009,906,688 B for Llama-3-8B) + the K/V rows read, rows * t * 131,072 B at the mean cache length."""
+    from .engine import Context, GenState
+    eng = model.text_encoder.engine
+    cfg = eng.cfg
+    ctx = Context.get(eng.device)
+    g = torch.Generator().manual_seed(3)
+    emb = (torch.randn(rows, prompt, cfg.d, generator=g) * 0.02).to(torch.bfloat16).to(eng.device)
+    cache = eng.new_cache(rows, prompt + new_tokens)
+    st = GenState(rows, cfg.vocab, new_tokens, eng.device)
+    logits, _ = eng.prefill(emb, None, cache, "last")
+    st.logits.copy_(logits); st.pos.fill_(prompt)
+    eng.pick(cache, st, rows, advance_pos=False)
+    eng.greedy_steps(cache, st, rows, 8)
+    n = new_tokens - 16
+    ctx.timer_start()
+    eng.greedy_steps(cache, st, rows, n)
+    ms = ctx.timer_stop() / n
+    ctx.sync()
+    w_bytes = 2 * (cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d
+                                   + 3 * cfg.d * cfg.ffn + 2 * cfg.d) + cfg.d + cfg.vocab * cfg.d)
+    t_mean = prompt + 8 + n / 2.0
+    kv_bytes = rows * t_mean * (2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2)
+    gbps = (w_bytes + kv_bytes) / 1e9 / (ms / 1e3)
+    return {"bound": "hbm", "kernel": "batched decode step (hipGraph: per layer qkv / attention / o / gate-up / down launches + lm_head + pick)",
+            "rows": rows, "mean_cache_len": round(t_mean, 1), "ms_per_step": round(ms, 4), "tokens_per_s_decode_only": round(rows * 1e3 / ms, 1),
+            "bytes_per_step": int(w_bytes + kv_bytes), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+
+
 def config5_inputs(pairs=256, chunk=64, seed=7):
     g = torch.Generator().manual_seed(seed)
     plen = [805] + [int(x) for x in torch.randint(8, 41, (pairs + 2,), generator=g)]   # receptor + peptides
