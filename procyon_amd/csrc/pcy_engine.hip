@@ -52,6 +52,7 @@ struct pcy_ctx {
   unsigned* xwg_err = nullptr;
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
+  unsigned* tile_ctr = nullptr;       // 16 zeroed words: dynamic tile queue of the persistent GEMM (PcyGemmArgs.tile_ctr)
   // tagged hand-over vectors of the MLP chain launches: [layer][ffn + d] words, owned by one model geometry at a time
   uint32_t* mc_tags = nullptr;
   const void* mc_tags_model = nullptr;
@@ -113,8 +114,10 @@ int take_sticky_error(pcy_ctx* c) {
   return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (code %u): its workgroups were not all resident -- is "
                  "another kernel running on this device? -- results since the last successful pcy_ctx_sync are invalid", code);
 }
+thread_local unsigned* g_cur_tile_ctr = nullptr;   // the calling context's tile-queue words (PcyGemmArgs.tile_ctr), set per ABI call
 #define PCY_STICKY(c)                                 \
   do {                                                \
+    g_cur_tile_ctr = (c)->tile_ctr;                   \
     if (int r_ = take_sticky_error(c)) return r_;     \
   } while (0)
 
@@ -142,6 +145,7 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
   a.splitk_ws = splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
   a.next_rms_w = next_w; a.next_xn = next_xn; a.fused_next = fused; a.rms_eps = rms_eps; a.rms_cast = rms_cast;
+  a.tile_ctr = g_cur_tile_ctr;
   pcy_launch_gemm(s, a);
 }
 
@@ -487,6 +491,8 @@ int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tile_ctr), 64));
+  HIP_TRY(hipMemset(c->tile_ctr, 0, 64));
   *out = c;
   return 0;
 }
@@ -497,6 +503,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->xwg_err) hipHostFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
+  if (c->tile_ctr) hipFree(c->tile_ctr);
   if (c->mc_tags) hipFree(c->mc_tags);
   if (c->dev_layers) hipFree(c->dev_layers);
   if (c->op_tags) hipFree(c->op_tags);
@@ -528,6 +535,7 @@ int pcy_gemm(pcy_ctx* c, const void* A, int lda, const void* W, const void* bias
   PcyGemmArgs a{};
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = (const bf16_t*)bias; a.resid = (const bf16_t*)resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
+  a.tile_ctr = c->tile_ctr;
   pcy_launch_gemm(c->stream, a);
   return check_launch("pcy_gemm");
 }

@@ -120,11 +120,34 @@ __device__ __forceinline__ void tile_origin(const PcyGemmArgs& a, int tile, int&
 // All global reads of the epilogue (bias: 16 values per lane, residual: 16 x 8 B per lane) are issued up front as
 // independent vector loads -- element-wise loads inside the rounding chain serialised ~64 L2 round trips per tile
 // (20 us of the 37 us a K=1280 tile took).
-template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true>
+// LDS_OUT: the finished bf16 quads go to the wave's private LDS tile instead of global memory (rows = the wave's 64 tokens, 256
+// bytes each, 16-byte chunk c of row r at c ^ (r & 15)); gemm_wide_flush then stores whole rows (see gemm_epilogue_wide).
+__device__ __forceinline__ void lds_put4(char* wave_lds, int row, int col, uint2 w) {
+  *reinterpret_cast<uint2*>(wave_lds + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) = w;
+}
+template <int COLS>   // 128 features per wave row (64 for the SwiGLU output)
+__device__ __forceinline__ void gemm_wide_flush(const PcyGemmArgs& a, const char* wave_lds, int mw, int nw, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CPR = COLS / 8, RPI = 64 / CPR;       // 16-byte chunks per row, rows per wave-instruction
+  const int c = lane % CPR, n = nw + c * 8;
+#pragma unroll 4
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int row = it * RPI + lane / CPR, m = mw + row;
+    const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * 256 + ((c ^ (row & 15)) << 4));
+    if (m < a.M && n < (COLS == 64 ? a.N / 2 : a.N)) *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = v;
+  }
+}
+template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true, bool LDS_OUT = false>
 __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int m0, int n0, int wm, int wn, int fr, int fq,
-                                              const uint16_t* gelu_lut = nullptr) {
+                                              const uint16_t* gelu_lut = nullptr, char* wave_lds = nullptr) {
   m0 += wm * WTM * 16 - wm * 64;   // the code below adds wm * 64 / wn * 64 (the 4 x 4 layout)
   n0 += wn * WTN * 16 - wn * 64;
+  const int mw_ = m0 + wm * 64, nw_ = n0 + wn * 64;   // first token / feature of this wave's tile
+  auto emit = [&](int m, int n, uint2 w) __attribute__((always_inline)) {
+    if (LDS_OUT) lds_put4(wave_lds, m - mw_, n - nw_, w);
+    else *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = w;
+  };
   const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
   if (EPI == EPI_SWIGLU) {
 #pragma unroll
@@ -142,7 +165,8 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
           const float g = rbf(acc[i][j][r]), u = rbf(acc[i + 1][j][r]);
           o[r] = rbf(silu_f(g)) * u;
         }
-        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+        if (LDS_OUT) lds_put4(wave_lds, m - mw_, f - (nw_ >> 1), make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3])));
+        else *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
       }
     }
     return;
@@ -216,8 +240,8 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
               o1[r] = y1; o2[r] = y2;
             }
           }
-          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n1) = make_uint2(pack_bf(o1[0], o1[1]), pack_bf(o1[2], o1[3]));
-          *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n2) = make_uint2(pack_bf(o2[0], o2[1]), pack_bf(o2[2], o2[3]));
+          emit(m, n1, make_uint2(pack_bf(o1[0], o1[1]), pack_bf(o1[2], o1[3])));
+          emit(m, n2, make_uint2(pack_bf(o2[0], o2[1]), pack_bf(o2[2], o2[3])));
         }
       }
     }
@@ -283,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
         for (int r = 0; r < 4; ++r) v[r] = gelu_lut ? gelu_esm_lut(v[r], gelu_lut) : gelu_esm_chain(v[r]);
       }
       if (vec_ok) {
-        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3]));
+        emit(m, n, make_uint2(pack_bf(v[0], v[1]), pack_bf(v[2], v[3])));
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -525,13 +549,62 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(PcyGemmArgs a, int s
 // 4 + fq) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) -- A and B use the same k -> slot map, which is all
 // a dot product needs.  Twice the k per MFMA issue slot at the MX rate = 2x the bf16 flops for the same LDS / global bytes.
 // The per-token / per-output-row dequantisation scales are applied to the fp32 accumulators in front of the epilogue.
+// Epilogue of the 256 x 256 kernel through LDS (plain / residual epilogues): the accumulator layout gives a lane 4 consecutive
+// features of one token, so a direct store instruction writes 16 row segments of 32 bytes -- a quarter of a 128-byte line each,
+// 1024 partial-line writes per wave tile.  Here the wave first parks its bf16 tile [64 tokens][128 features] in its OWN 16 KiB of
+// the (now idle) stage buffers -- 16-byte chunk c of row r at position c ^ (r & 15): conflict-free 8-byte writes and 16-byte
+// reads, no barrier, the tile is wave-private -- and then moves whole rows: 16 lanes x 16 bytes = 256 contiguous bytes per
+// token row, for the residual read as well as for the store.  Same values, same rounding order (bias, round, + residual,
+// round) as gemm_epilogue.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_wide(const PcyGemmArgs& a, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane,
+                                                   char* wave_lds) {
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nw = n0 + wn * 128, mw = m0 + wm * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = nw + i * 16 + fq * 4;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + (n + 3 < a.N ? n : 0));
+      b[0] = lo_bf(bb.x); b[1] = hi_bf(bb.x); b[2] = lo_bf(bb.y); b[3] = hi_bf(bb.y);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = j * 16 + fr;
+      const int chunk = 2 * i + (fq >> 1);
+      const uint2 w = make_uint2(pack_bf(acc[i][j][0] + b[0], acc[i][j][1] + b[1]), pack_bf(acc[i][j][2] + b[2], acc[i][j][3] + b[3]));
+      *reinterpret_cast<uint2*>(wave_lds + row * 256 + ((chunk ^ (row & 15)) << 4) + (fq & 1) * 8) = w;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int c = lane & 15;
+  const int n = nw + c * 8;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4);
+    const int m = mw + row;
+    uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * 256 + ((c ^ (row & 15)) << 4));
+    if (m >= a.M || n >= a.N) continue;
+    if (EPI == EPI_RESID) {
+      const uint4 r = *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.ldr + n);
+      v.x = pack_bf(lo_bf(v.x) + lo_bf(r.x), hi_bf(v.x) + hi_bf(r.x));
+      v.y = pack_bf(lo_bf(v.y) + lo_bf(r.y), hi_bf(v.y) + hi_bf(r.y));
+      v.z = pack_bf(lo_bf(v.z) + lo_bf(r.z), hi_bf(v.z) + hi_bf(r.z));
+      v.w = pack_bf(lo_bf(v.w) + lo_bf(r.w), hi_bf(v.w) + hi_bf(r.w));
+    }
+    *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = v;
+  }
+}
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
   return (i32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-template <int EPI, bool F8 = false>
+template <int EPI, bool F8 = false, bool WIDE = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -658,6 +731,21 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
     return;
   }
+  if constexpr (WIDE) {
+    // whole-row stores through the (now idle: every wave has passed the barrier that closed the last k-step) stage buffers, 16 KiB
+    // per wave; the ESM GELU table sits behind them (the launcher allocates 12 KiB more)
+    char* wave_lds = smem + wave * 16384;
+    if constexpr (EPI == EPI_RESID) {
+      gemm_epilogue_wide<EPI>(a, acc, m0, n0, wm, wn, lane, wave_lds);
+    } else {
+      const uint16_t* lut = nullptr;
+      if constexpr (EPI == EPI_GELU_ESM) { gelu_lut_to_lds<512>(smem + 2 * (TILE_A + TILE_W)); lut = reinterpret_cast<const uint16_t*>(smem + 2 * (TILE_A + TILE_W)); }
+      gemm_epilogue<EPI, WTN, WTM, true, true>(a, acc, m0, n0, wm, wn, fr, fq, lut, wave_lds);
+      if constexpr (EPI == EPI_SWIGLU) gemm_wide_flush<64>(a, wave_lds, m0 + wm * 64, (n0 + wn * 128) >> 1, lane);
+      else gemm_wide_flush<128>(a, wave_lds, m0 + wm * 64, n0 + wn * 128, lane);
+    }
+    return;
+  }
   if constexpr (EPI == EPI_GELU_ESM) {
     gelu_lut_to_lds<512>(smem);
     gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
@@ -669,7 +757,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 // Persistent variant of gemm_kernel_big for the ESM fc1 GEMM (EPI_GELU_ESM, K = 1280: 20 k-steps per tile, so the first-stage
 // round trip and the table-lookup epilogue are a large share of a tile).  The other epilogues keep gemm_kernel_big: inside a
 // tile loop their register demand passes 256 VGPRs (measured: spills, fp8 prefill -12 %).
-template <int EPI, bool F8 = false>
+// DQ = true: the tiles of an XCD's contiguous run are handed out by a per-XCD atomic counter instead of a fixed stride, and the
+// workgroups take their FIRST tile after a delay of 0..7 eighths of a tile time.  One workgroup per CU and tiles of equal length
+// keep every CU in lock-step otherwise: all 256 epilogues (33.5 MB of stores) hit HBM in the same ~8 us while every matrix pipe
+// idles, once per tile round.  Out of phase, a CU's epilogue shares the memory system with 7/8 of the chip in its mainloop; the
+// queue makes the late starters take fewer tiles, so the stagger does not come back as a tail.  a.tile_ctr: 9 zeroed words
+// (8 XCD heads + an exit counter; the last workgroup to leave zeroes them again).
+template <int EPI, bool F8 = false, bool DQ = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -685,15 +779,35 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   const int ntiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
   const int xq = ntiles >> 3, xr = ntiles & 7;
   auto tile_of = [&](int vb) { const int xcd = vb & 7; return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (vb >> 3); };
+  __shared__ int next_slot;
+  const int my_xcd = blockIdx.x & 7;
+  const int run_start = my_xcd < xr ? my_xcd * (xq + 1) : xr * (xq + 1) + (my_xcd - xr) * xq;
+  const int run_len = xq + (my_xcd < xr ? 1 : 0);
+  int cur_j = 0;
+  if (DQ) {
+    const int nk0 = F8 ? a.K / 128 : a.K / BK;
+    const int phase = ((blockIdx.x >> 3) * 5) & 7;                       // neighbours in dispatch order get distant phases
+    for (int i = 0; i < phase * nk0; ++i) __builtin_amdgcn_s_sleep(7);    // ~ phase/8 of a tile: a k-step is ~3.4 k cycles, s_sleep(7) = 448
+    if (threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);
+    __syncthreads();
+    cur_j = next_slot;
+    __syncthreads();
+    if (cur_j >= run_len) {
+      if (threadIdx.x == 0 && atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x - 1)
+        for (int i = 0; i < 9; ++i) a.tile_ctr[i] = 0;
+      return;
+    }
+  }
   int m0, n0;
-  tile_origin<TBM, TBN>(a, tile_of(blockIdx.x), m0, n0);
+  tile_origin<TBM, TBN>(a, DQ ? run_start + cur_j : tile_of(blockIdx.x), m0, n0);
   // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
   const int nk = F8 ? a.K / 128 : a.K / BK;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
   stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
   stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
   const int fr = lane & 15, fq = lane >> 4;
-  for (int vb = blockIdx.x; PERSIST ? vb < ntiles : vb == (int)blockIdx.x; vb += gridDim.x) {
+  for (int vb = blockIdx.x; DQ ? true : (PERSIST ? vb < ntiles : vb == (int)blockIdx.x); vb += gridDim.x) {
+  if (DQ && threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);   // the NEXT tile: the answer is read after the mainloop's barriers
   f32x4 acc[WTN][WTM];
 #pragma unroll
   for (int i = 0; i < WTN; ++i)
@@ -749,8 +863,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   // wave still reads LDS; the ESM GELU table goes to buffer 1)
   const int nvb = vb + gridDim.x;
   int nm0 = 0, nn0 = 0;
-  if (PERSIST && nvb < ntiles) {
-    tile_origin<TBM, TBN>(a, tile_of(nvb), nm0, nn0);
+  const int nj = DQ ? next_slot : 0;                 // (written before the k-loop, whose barriers order it)
+  const bool have_next = DQ ? nj < run_len : (PERSIST && nvb < ntiles);
+  if (have_next) {
+    tile_origin<TBM, TBN>(a, DQ ? run_start + nj : tile_of(nvb), nm0, nn0);
     stage_tile<BK, TBM, NW>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
     stage_tile<BK, TBN, NW>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
   }
@@ -784,7 +900,10 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
     gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
   }
   m0 = nm0; n0 = nn0;
+  if (DQ && !have_next) break;
   }   // tile loop
+  if (DQ && threadIdx.x == 0 && atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x - 1)
+    for (int i = 0; i < 9; ++i) a.tile_ctr[i] = 0;
 }
 
 }  // namespace
@@ -845,6 +964,28 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
       if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
+      }
+      // epilogue through LDS (whole-row stores; PCY_GEMM_WIDE_EPI=1, same bits as the direct stores).  OFF by default: measured
+      // alone the plain-store shapes with many tile rounds gain (M = 25650: N = 3840 271 -> 241 us, N = 5120 324 -> 298 us, residual
+      // shapes 107 -> 98 / 303 -> 301 us), but inside the encoder / the Llama prefill the interleaved A/B is a wash (ESM2-650M
+      // batch 25: 46.0 vs 46.3 ms; pair scoring 1047 vs 1048 TFLOP/s): the fc1 GEMM loses its persistent tile loop (the table and
+      // the wave tiles do not fit beside a prefetched stage) and the rotary epilogue spills three registers.  The store pattern
+      // is not what a tile round waits for.
+      const char* we = getenv("PCY_GEMM_WIDE_EPI");
+      const int Nout = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
+      b.wide_epi = (we && atoi(we) != 0) && (Nout % 8 == 0) && (a.ldc % 8 == 0) && (a.resid == nullptr || a.ldr % 8 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.resid)) & 15) == 0 &&
+                   (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0) && (a.N % 4 == 0) && EPI != EPI_GELU_ERF;
+      if (b.wide_epi) {
+        constexpr int smem_w = smem + (EPI == EPI_GELU_ESM ? GELU_LUT_N * 2 : 0);
+        static bool configured_w = false;
+        if (!configured_w) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+          configured_w = true;
+        }
+        ++g_pcy_dispatch[EPI == EPI_GELU_ESM ? PCY_DISPATCH_GEMM_BIG_PERSIST : PCY_DISPATCH_GEMM_BIG];
+        hipLaunchKernelGGL((gemm_kernel_big<EPI, false, true>), dim3(tiles_big), dim3(512), smem_w, s, b);
+        return;
       }
       if constexpr (EPI == EPI_GELU_ESM) {
         static bool configured_p = false;

@@ -816,10 +816,9 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
   mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
 }
 
-template <int EPI, int BT>
-void launch_mfma3(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
+template <int EPI, int BT, int S>
+void launch_mfma3_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
-  constexpr int S = RT == 2 ? 3 : 6;           // 96 KB of weight rings per workgroup either way
   constexpr size_t smem = (size_t)4 * S * RT * 4096 + 2 * BT * 16 * (256 * 2 + 16);
   static bool configured = false;
   if (!configured) {
@@ -827,6 +826,21 @@ void launch_mfma3(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
     configured = true;
   }
   hipLaunchKernelGGL((gemv_mfma3_kernel<EPI, BT, S>), dim3(bx, ksplit), dim3(256), smem, s, a, ksplit);
+}
+// Ring depth S (super-steps of 128 k kept in flight per wave = S - 1): the SwiGLU kernel streams two row tiles per wave (S = 3: 96 KB
+// of rings, one workgroup per CU).  The single-row-tile kernels (qkv, o, down, lm_head) ran S = 6 (96 KB, one workgroup per CU);
+// S = 3 halves the rings so that TWO workgroups share a CU (48 + 33 KB each) -- same bytes in flight per CU, twice the
+// workgroups to split K over.  PCY_GEMV_S1 = 3 | 6 selects (measured: see DESIGN.md round 3).
+inline int gemv_ring_depth_rt1() {
+  static const int v = [] { const char* e = getenv("PCY_GEMV_S1"); const int x = e ? atoi(e) : 6; return x == 3 ? 3 : 6; }();
+  return v;
+}
+template <int EPI, int BT>
+void launch_mfma3(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  if constexpr (RT == 2) launch_mfma3_s<EPI, BT, 3>(s, a, bx, ksplit);
+  else if (gemv_ring_depth_rt1() == 3) launch_mfma3_s<EPI, BT, 3>(s, a, bx, ksplit);
+  else launch_mfma3_s<EPI, BT, 6>(s, a, bx, ksplit);
 }
 
 template <int EPI>
@@ -838,7 +852,7 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     // K split until ~3/4 of the CUs have a workgroup (measured batch-32 decode step with the fill target at 128 / 192 / 256 / 512
     // workgroups: 4.46 / 4.21 / 4.28 / 4.56 ms); only with a plain / residual epilogue and a workspace
     int ksplit = 1;
-    constexpr int kfill = 192;
+    static const int kfill = [] { const char* e = getenv("PCY_GEMV_KFILL"); const int x = e ? atoi(e) : 192; return x > 0 ? x : 192; }();
     if ((EPI == EPI_STORE || EPI == EPI_RESID) && a.splitk_ws && a.N % 4 == 0 && (a.ldy & 3) == 0)
       while (ksplit < 8 && bx * ksplit < kfill && a.K % (ksplit * 2 * 512) == 0 &&
              (size_t)(ksplit * 2) * a.B * a.N * 4 <= a.splitk_ws_bytes) ksplit *= 2;

@@ -74,6 +74,9 @@ struct PcyGemmArgs {
   // optional (split-K path with the residual epilogue only): the finish kernel also writes next_xn = RMSNorm(C) * next_rms_w and
   // sets *fused_next = 1; otherwise *fused_next stays 0 and the caller launches the norm itself.  Same bits as the two launches.
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next; float rms_eps; int rms_cast;
+  // optional: 9 zeroed device words for the dynamic tile queue of the persistent 256 x 256 kernel (see gemm_kernel_big_persist, DQ)
+  unsigned* tile_ctr;
+  int wide_epi;         // set by the launcher: the 256 x 256 kernel's plain / residual epilogue goes through LDS (whole-row stores)
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)

@@ -6,8 +6,8 @@ from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 kw = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
 eng = LlamaEngine(synth.llama_state_dict(**kw, device="cuda"), LlamaConfig(**kw, max_pos=4096), free_source=True)
 ctx = Context.get()
-T, N = 128, 64
-for B in (1, 4, 5, 8, 16, 20, 32):
+T, N = int(os.environ.get("T", 128)), 64
+for B in [int(x) for x in os.environ.get("BATCHES", "1,4,5,8,16,20,32").split(",")]:
     emb = (torch.randn(B, T, 4096, device="cuda") * 0.02).bfloat16()
     cache = eng.new_cache(B, T + N)
     st = GenState(B, kw["vocab"], N, "cuda")
