@@ -533,10 +533,10 @@ def test_fastapi_service_round_trip_on_a_synthetic_checkpoint(instruct_env, monk
         assert allr.status_code == 200 and len(allr.json()["results"]) == 20000
 
 
-@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+@pytest.mark.parametrize("epi", [0, 1, 3])
 def test_gemm_epilogue_through_lds_bit_identical(ctx, monkeypatch, epi):
-    """PCY_GEMM_WIDE_EPI=1: the 256 x 256 kernel parks its finished tile in LDS and stores whole rows (plain, residual, ESM GELU,
-    SwiGLU epilogues; ragged M and N edges) -- the same values as the direct per-lane stores, bit for bit."""
+    """PCY_GEMM_WIDE_EPI=1: the 256 x 256 kernel parks its finished tile in LDS and stores whole rows (plain, residual, ESM GELU
+    epilogues; ragged M and N edges) -- the same values as the direct per-lane stores, bit for bit."""
     from procyon_amd import _lib as L
     from procyon_amd.engine import interleave_gate_up
     M, N, K = 2048 + 300, 1280 + 256 + 8, 1280
