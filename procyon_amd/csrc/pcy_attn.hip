@@ -522,8 +522,49 @@ __global__ __launch_bounds__(512) void attn_dec_kernel(PcyDecAttnArgs a) {
   attn_dec_body<DH, G, DS>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The same with the new token's q / k / v taken from the K-split partial sums of the batched qkv projection (a.qkv_partials):
+// the cache rows are requested first, then 192 threads add the splits of the kv head's G + 2 rows in split order into LDS.
+template <int DH, int G, int DS>
+__global__ __launch_bounds__(512) void attn_dec_splitk_kernel(PcyDecAttnArgs a, int stage_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* stage = reinterpret_cast<bf16_t*>(smem + stage_off);   // [G + 2][DH]
+  const int kvh = blockIdx.y, b = blockIdx.z;
+  const float* ws = a.qkv_partials;
+  const int splits = a.qkv_splits, H = a.H, Hkv = a.Hkv, B = a.B, ld = a.ld;
+  a.staged = stage;
+  auto hook = [=]() __attribute__((always_inline)) {
+    const int tid = pcy_tid();
+    constexpr int NV4 = (G + 2) * DH / 4;
+    static_assert(NV4 <= 512, "one quad per thread");
+    if (tid < NV4) {
+      const int seg = tid / (DH / 4), e4 = tid % (DH / 4);
+      const int n = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)b * ld + n);
+      for (int s_ = 1; s_ < splits; ++s_) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(ws + ((size_t)s_ * B + b) * ld + n);
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+      }
+      *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2(pack_bf(rbf(v[0]), rbf(v[1])), pack_bf(rbf(v[2]), rbf(v[3])));
+    }
+    __syncthreads();
+  };
+  attn_dec_body<DH, G, DS>(a, smem, blockIdx.x, kvh, b, hook);
+}
+
 template <int DH, int G, int DS>
 void launch_dec_ds(hipStream_t s, const PcyDecAttnArgs& a) {
+  if (a.qkv_partials) {
+    const int stage_off = (int)((attn_dec_smem_bytes(G, DS, DH, a.Tmax) + 15) & ~(size_t)15);
+    const size_t smem = (size_t)stage_off + (size_t)(G + 2) * DH * 2;
+    static size_t configured = 0;
+    if (smem > 65536 && smem > configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_splitk_kernel<DH, G, DS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      configured = smem;
+    }
+    hipLaunchKernelGGL((attn_dec_splitk_kernel<DH, G, DS>), dim3(DH / DS, a.Hkv, a.B), dim3(512), smem, s, a, stage_off);
+    return;
+  }
   const size_t smem = attn_dec_smem_bytes(G, DS, DH, a.Tmax);
   static size_t configured = 0;
   if (smem > 65536 && smem > configured) {

@@ -175,7 +175,8 @@ bool decode_step_enabled() {
   const char* e = getenv("PCY_DECODE_STEP");
   return !e || atoi(e) != 0;
 }
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0); }
+bool qkv_finish_launch() { const char* e = getenv("PCY_QKV_FINISH"); return e && atoi(e) == 1; }   // read per call: tests compare both
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
@@ -343,7 +344,10 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       if (pcy_launch_decode_layer(s, t, bp, mc, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS)) continue;
       try_layer = false;   // geometry not covered: the same for every layer
     }
+    int qkv_splits = 0;   // batched: the attention adds up the K-split partial sums of ITS rows (no finish launch); PCY_QKV_FINISH=1: separate launch
+    if (batched && sk_ws && !try_ao && !qkv_finish_launch()) g.defer_finish = &qkv_splits;
     pcy_launch_gemv(s, g);
+    if (qkv_splits > 1) { t.qkv_partials = sk_ws; t.qkv_splits = qkv_splits; }
     if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
                                        c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
       pcy_launch_attn_decode(s, t);

@@ -816,6 +816,129 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
   mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
 }
 
+// Fourth version: the same copies and the same MFMA order (same bits), a different schedule.  LDS-DMA copies retire in issue
+// order (one vmcnt), so "x(c+1) has landed" in gemv_mfma3_kernel also means "every weight copy issued before it has landed": with
+// x staged one chunk ahead the waves drain their weight rings to two super-steps at every chunk end, whatever S is (S = 6 measured
+// like S = 3).  Here x travels exactly like the weights -- a [16 batch rows][256 B] tile per 128-k super-step, pieces XOR-swizzled
+// by the row on the source side, in a ring of the SAME depth S shared by the four waves -- and x(i), W(i) are issued as a pair
+// S - 1 super-steps ahead: one counted wait per super-step ("pair ss has landed": (S-2) younger pairs may be in flight), one
+// barrier (everyone's part of x(ss) is there, everyone is done with the slot about to be refilled).
+//   LDS: 4 waves x S x RT x 4 KB + S x BT x 4 KB  (gate/up, batch 32: S = 4 -> exactly 160 KB, 96 KB of weights in flight per CU
+//   instead of 64; single-row-tile kernels: S = 6 -> 144 KB, 80 KB in flight instead of 32).
+template <int EPI, int BT, int S>
+__global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr int WT = 16 * 256;                 // one 16-row tile of one super-step (weights and x alike)
+#ifndef PCY_GEMV_W_AUX
+#define PCY_GEMV_W_AUX 2
+#endif
+  constexpr int W_AUX = PCY_GEMV_W_AUX;        // cache policy of the weight copies: 2 = nt (read once: batch-32 step 4.81 -> 4.68 ms), 0 = default
+  extern __shared__ __attribute__((aligned(1024))) char smem4[];
+  char* xs = smem4 + 4 * S * RT * WT;          // [S][BT][WT] behind the four waves' weight rings
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* wring = smem4 + wave * S * RT * WT;    // [S][RT][16 rows][256 B]
+  const int fr = lane & 15, fq = lane >> 4;
+  const int K = a.K;
+  const int nrows = (EPI == EPI_SWIGLU) ? 2 * a.N : a.N;
+  const int r0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  const int ks = K / ksplit;                   // multiple of 128
+  const int kbeg = blockIdx.y * ks;
+  const int nss = ks / 128;
+  const bf16_t* wsrc[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 4 + (lane >> 4);
+      int r = r0 + rt * 16 + row;
+      r = r < nrows ? r : nrows - 1;
+      wsrc[rt][q] = a.W + (size_t)r * K + kbeg + ((lane & 15) ^ row) * 8;
+    }
+  // this wave's share of an x tile set: instructions wave*BT .. wave*BT + BT-1 of the BT*4 (tile bt = i >> 2, rows (i & 3)*4 .. +3)
+  const bf16_t* xsrc[BT];
+  int xdst[BT];
+#pragma unroll
+  for (int t = 0; t < BT; ++t) {
+    const int i = wave * BT + t, bt = i >> 2, q = i & 3;
+    const int row = q * 4 + (lane >> 4);
+    int b = bt * 16 + row;
+    b = b < a.B ? b : a.B - 1;
+    xsrc[t] = a.x + (size_t)b * a.ldx + kbeg + ((lane & 15) ^ row) * 8;
+    xdst[t] = bt * WT + q * 1024;
+  }
+  auto issue = [&](int ss) __attribute__((always_inline)) {   // (past the end: the last super-step again, the counts stay uniform)
+    const int k = (ss < nss ? ss : nss - 1) * 128;
+    const int slot = ss % S;
+    char* xb = xs + slot * BT * WT;
+#pragma unroll
+    for (int t = 0; t < BT; ++t) __builtin_amdgcn_global_load_lds((gv_gptr_t)(xsrc[t] + k), (gv_lds_ptr_t)(xb + xdst[t]), 16, 0, 0);
+    char* dst = wring + slot * RT * WT;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_global_load_lds((gv_gptr_t)(wsrc[rt][q] + k), (gv_lds_ptr_t)(dst + rt * WT + q * 1024), 16, 0, W_AUX);
+  };
+  f32x4 acc[RT][BT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int ss) __attribute__((always_inline)) {
+    const int slot = ss % S;
+    const char* wb = wring + slot * RT * WT;
+    const char* xb = xs + slot * BT * WT;
+    bf16x8 wf[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[rt][j] = *reinterpret_cast<const bf16x8*>(wb + rt * WT + fr * 256 + (((j * 4 + fq) ^ fr) << 4));
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+      bf16x8 xf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xb + bt * WT + fr * 256 + (((j * 4 + fq) ^ fr) << 4));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[j], acc[rt][bt], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < S - 1; ++i) issue(i);
+  for (int ss = 0; ss < nss; ++ss) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (BT + RT * 4)) : "memory");   // this wave's copies of pair ss have landed
+    __builtin_amdgcn_s_barrier();                                                     // ... and everybody else's; slot (ss-1) % S is free
+    issue(ss + S - 1);
+    mma(ss);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this workgroup's LDS may still be written when it retires
+  mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
+}
+
+template <int EPI, int BT, int S>
+bool launch_mfma4_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  constexpr size_t smem = (size_t)4 * S * RT * 4096 + (size_t)S * BT * 4096;
+  static int configured = 0;   // 1 ok, -1 the device refused the LDS size
+  if (!configured)
+    configured = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma4_kernel<EPI, BT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem) == hipSuccess ? 1 : -1;
+  if (configured < 0) { (void)hipGetLastError(); return false; }
+  hipLaunchKernelGGL((gemv_mfma4_kernel<EPI, BT, S>), dim3(bx, ksplit), dim3(256), smem, s, a, ksplit);
+  return true;
+}
+// ring depths of gemv_mfma4_kernel: the deepest that fit 160 KB of LDS
+template <int EPI, int BT>
+bool launch_mfma4(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
+  constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
+  if constexpr (RT == 2) return launch_mfma4_s<EPI, BT, 4>(s, a, bx, ksplit);                   // 128 + 16 BT KB
+  else if constexpr (BT == 1) return launch_mfma4_s<EPI, BT, 8>(s, a, bx, ksplit);              // 128 + 32 KB
+  else return launch_mfma4_s<EPI, BT, 6>(s, a, bx, ksplit);                                      // 96 + 48 KB
+}
+
 template <int EPI, int BT, int S>
 void launch_mfma3_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -859,11 +982,16 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     // PCY_GEMV_LDS=0: weights through registers (gemv_mfma2_kernel) instead of LDS-DMA (gemv_mfma3_kernel); read per call, same bits
     const char* lds_env = getenv("PCY_GEMV_LDS");
     const bool lds = !(lds_env && atoi(lds_env) == 0) && a.K % (ksplit * 256) == 0;
-    if (lds) {
+    // PCY_GEMV_LDS=3: the previous schedule (gemv_mfma3_kernel: x one chunk ahead); read per call, same bits
+    const bool v4 = lds && !(lds_env && atoi(lds_env) == 3) && a.K % (ksplit * 128) == 0;
+    if (v4 && (a.B <= 16 ? launch_mfma4<EPI, 1>(s, a, bx, ksplit) : launch_mfma4<EPI, 2>(s, a, bx, ksplit))) {
+    } else if (lds) {
       if (a.B <= 16) launch_mfma3<EPI, 1>(s, a, bx, ksplit);
       else launch_mfma3<EPI, 2>(s, a, bx, ksplit);
     } else if (a.B <= 16) hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 1>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
     else hipLaunchKernelGGL((gemv_mfma2_kernel<EPI, 2>), dim3(bx, ksplit), dim3(256), 0, s, a, ksplit);
+    if (a.defer_finish) *a.defer_finish = 0;
+    if (ksplit > 1 && EPI == EPI_STORE && a.defer_finish && !a.bias) { *a.defer_finish = ksplit; return; }
     if (ksplit > 1) {
       const int eb = (int)(((size_t)a.B * (a.N / 4) + 255) / 256);
       const char* fn_env = getenv("PCY_FINISH_NORM");   // read per call: tests compare both paths in one process

@@ -19,6 +19,10 @@ struct PcyGemvArgs {
   // next_xn = RMSNorm(y) * next_rms_w (rms_eps / rms_cast above) and sets *fused_next = 1; otherwise *fused_next stays 0 and
   // the caller launches the norm itself.  Same summation order as rmsnorm_kernel -> identical bits.
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next;
+  // optional (batched K-split path, plain epilogue without bias): leave the partial sums in splitk_ws, launch no finish kernel and
+  // report the number of splits in *defer_finish (0: y has been written as usual) -- the consumer adds them up itself
+  // (decode attention: PcyDecAttnArgs::qkv_partials)
+  int* defer_finish;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 // Launches whose workgroups wait for each other INSIDE the launch need every workgroup resident at once: true when the occupancy
@@ -151,6 +155,10 @@ struct PcyDecAttnArgs {
   // attention block launch only (device-side fields, zero otherwise): the new token's roped-to-be q heads / k / v of this kv head
   // staged in LDS as [G + 2][dh] (nullptr: read from `qkv`); `o` stored as {tag : bf16} words into o_tag instead
   const bf16_t* staged; uint32_t* o_tag; uint32_t tag;
+  // batched decode: the qkv projection's K-split partial sums [qkv_splits][B][ld] fp32 (nullptr: `qkv` holds the finished rows).
+  // The attention workgroup adds the G + 2 rows of ITS kv head in split order (what gemv_splitk_finish_kernel does: same bits)
+  // into LDS -- one launch less per decoder layer.
+  const float* qkv_partials; int qkv_splits;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;

@@ -392,6 +392,39 @@ def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
                 assert torch.equal(x, y), (B, use_graph)
 
 
+def test_batched_decode_qkv_finish_in_attention_bit_identical(monkeypatch):
+    """Batched decode: the K-split partial sums of the qkv projection are added up by the attention workgroup that needs them
+    (attn_dec_splitk_kernel, default) instead of by a finish launch (PCY_QKV_FINISH=1).  Same split order, same rounding: logits,
+    tokens and the appended K/V rows are bit-identical, eager and under graph replay; batches of 5..32 rows incl. a ragged keep mask."""
+    from procyon_amd import synth
+    from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=256))
+    T, N = 40, 4
+    for B in (5, 20, 32):
+        torch.manual_seed(B)
+        emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
+
+        def run(separate, use_graph):
+            monkeypatch.setenv("PCY_QKV_FINISH", "1" if separate else "0")
+            cache = eng.new_cache(B, T + N + 2)
+            st = GenState(B, kw["vocab"], N + 2, "cuda")
+            logits, _ = eng.prefill(emb, None, cache, "last")
+            st.logits.copy_(logits); st.pos.fill_(T)
+            eng.pick(cache, st, B, advance_pos=False)
+            out = []
+            for _ in range(N):
+                eng.greedy_steps(cache, st, B, 1, use_graph=use_graph)
+                out.append(st.logits.clone())
+            return (torch.stack(out).cpu(), st.tokens_out[:, :N + 1].cpu(), cache.k[:, :B, :, T:T + N].cpu(), cache.v[:, :B, :, T:T + N].cpu())
+
+        ref = run(True, False)
+        for use_graph in (False, True):
+            got = run(False, use_graph)
+            for x, y in zip(got, ref):
+                assert torch.equal(x, y), (B, use_graph)
+
+
 def test_llama2_7b_geometry_layer():
     """BASELINE configs[0] geometry (ProCyon-Split text side: Llama-2-7B, multi-head attention H = Hkv = 32, F = 11008, odd
     vocabulary 32007) at full width, one layer: prefill + 3 cached decode steps against the oracle.  Exercises G = 1 in both
