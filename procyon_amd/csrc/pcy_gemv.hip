@@ -569,10 +569,11 @@ __global__ __launch_bounds__(256) void gemv_splitk_finish_norm_kernel(PcyGemvArg
 
 // Epilogue of the batched MFMA GEMVs: lane holds D[n = fq*4 + r][b = fr] of every (row tile, batch tile)
 template <int EPI, int RT, int BT>
-__device__ __forceinline__ void mfma_gemv_epilogue(const PcyGemvArgs& a, f32x4 (&acc)[RT][BT], int r0, int nrows, int ksplit, int fr, int fq) {
+__device__ __forceinline__ void mfma_gemv_epilogue(const PcyGemvArgs& a, f32x4 (&acc)[RT][BT], int r0, int nrows, int ksplit, int fr, int fq,
+                                                   int split = blockIdx.y) {
   if (r0 >= nrows) return;
   if (ksplit > 1) {
-    float* ws = a.splitk_ws + (size_t)blockIdx.y * a.B * a.N;
+    float* ws = a.splitk_ws + (size_t)split * a.B * a.N;
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) {
       const int b = bt * 16 + fr;
@@ -816,6 +817,9 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
   mfma_gemv_epilogue<EPI, RT, BT>(a, acc, r0, nrows, ksplit, fr, fq);
 }
 
+#ifndef PCY_GEMV_ABL
+#define PCY_GEMV_ABL 0   // timing ablations (tools only): 1 = no x copies, 2 = no per-step barrier, 4 = no MFMAs
+#endif
 // Fourth version: the same copies and the same MFMA order (same bits), a different schedule.  LDS-DMA copies retire in issue
 // order (one vmcnt), so "x(c+1) has landed" in gemv_mfma3_kernel also means "every weight copy issued before it has landed": with
 // x staged one chunk ahead the waves drain their weight rings to two super-steps at every chunk end, whatever S is (S = 6 measured
@@ -871,7 +875,8 @@ __global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int kspl
     const int slot = ss % S;
     char* xb = xs + slot * BT * WT;
 #pragma unroll
-    for (int t = 0; t < BT; ++t) __builtin_amdgcn_global_load_lds((gv_gptr_t)(xsrc[t] + k), (gv_lds_ptr_t)(xb + xdst[t]), 16, 0, 0);
+    for (int t = 0; t < BT; ++t)
+      if (!(PCY_GEMV_ABL & 1)) __builtin_amdgcn_global_load_lds((gv_gptr_t)(xsrc[t] + k), (gv_lds_ptr_t)(xb + xdst[t]), 16, 0, 0);
     char* dst = wring + slot * RT * WT;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -908,10 +913,10 @@ __global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int kspl
 #pragma unroll
   for (int i = 0; i < S - 1; ++i) issue(i);
   for (int ss = 0; ss < nss; ++ss) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (BT + RT * 4)) : "memory");   // this wave's copies of pair ss have landed
-    __builtin_amdgcn_s_barrier();                                                     // ... and everybody else's; slot (ss-1) % S is free
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (((PCY_GEMV_ABL & 1) ? 0 : BT) + RT * 4)) : "memory");   // this wave's copies of pair ss have landed
+    if (!(PCY_GEMV_ABL & 2)) __builtin_amdgcn_s_barrier();                                                     // ... and everybody else's; slot (ss-1) % S is free
     issue(ss + S - 1);
-    mma(ss);
+    if (!(PCY_GEMV_ABL & 4)) mma(ss);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this workgroup's LDS may still be written when it retires
@@ -1008,6 +1013,10 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
   }
 }
 
+
+}  // namespace
+#include "pcy_bdec_chain.h"
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Batch-1 decode: gate/up + SwiGLU -> down + residual as ONE launch (PcyMlpChainArgs; pcy_decode_mlp).  The body, shared with the
