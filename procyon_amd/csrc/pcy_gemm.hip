@@ -604,7 +604,10 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
   const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
   return (i32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-template <int EPI, bool F8 = false, bool WIDE = false>
+// SPLITK: grid = tiles x a.splits, workgroup (tile, split) accumulates k in [split * K / splits, +K / splits) and stores its fp32
+// partial tile to a.splitk_ws[split] (finished by gemm_splitk_epilogue / the finish + norm kernel, as for gemm_splitk_kernel: same
+// k order per element, same bits); EPI is then ignored.
+template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -612,7 +615,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   char* smem = smem_dyn;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = SPLITK ? gridDim.x / a.splits : gridDim.x, bid = SPLITK ? blockIdx.x % nwg : blockIdx.x;
+  const int split = SPLITK ? blockIdx.x / nwg : 0;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   int m0, n0;
@@ -625,10 +629,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
-  const int nk = F8 ? a.K / 128 : a.K / BK;
+  const int nk = F8 ? a.K / 128 : (SPLITK ? a.K / a.splits / BK : a.K / BK);
+  const int kbeg = SPLITK ? split * (a.K / a.splits) : 0;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
-  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
+  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
+  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -648,8 +653,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 #endif
     if (((F8 && !PCY_F8_VARIANT) || (!F8 && !(PCY_BIG_VARIANT & 1))) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
     if constexpr (F8) {
       i32x8 xf[WTM];
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       // PCY_F8_VARIANT 1: the A stage behind the x fragment reads, the W stage after half of the MFMAs, priority raised
       // (measured no better than the plain order on the fp8 prefill: 1609-1615 vs 1619-1620 TFLOP/s; off)
       if (PCY_F8_VARIANT && kt + 1 < nk)
-        stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
+        stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
       if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         if (PCY_F8_VARIANT && i == WTN / 2 - 1 && kt + 1 < nk) {
           __builtin_amdgcn_s_setprio(0);
-          stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
+          stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
           __builtin_amdgcn_s_setprio(1);
         }
       }
@@ -684,8 +689,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
         for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
         if ((PCY_BIG_VARIANT & 1) && !(PCY_BIG_VARIANT & 4) && kt + 1 < nk) {   // one operand's stage behind each kb's fragment reads
           char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
         }
         if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -696,8 +701,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
           if ((PCY_BIG_VARIANT & 4) && (i & 1) && kt + 1 < nk) {   // one DMA piece after every 8 MFMAs
             char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
             if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
-            if (kb == 0) stage_piece<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane, i >> 1);
-            else stage_piece<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane, i >> 1);
+            if (kb == 0) stage_piece<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane, i >> 1);
+            else stage_piece<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane, i >> 1);
             if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
           }
         }
@@ -705,6 +710,24 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       }
     }
     __syncthreads();
+  }
+  if constexpr (SPLITK) {   // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
+    float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = m0 + wm * WTM * 16 + j * 16 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) {
+        const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
+        if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * a.N + n) = acc[i][j];
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) ws[(size_t)m * a.N + n + r] = acc[i][j][r];
+      }
+    }
+    return;
   }
   if constexpr (F8) {
     // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
@@ -1046,11 +1069,33 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     // the split count depends on (N, K) only -- sized for four row tiles (one 512-token prompt) -- so that a row's result
     // does not change with the number of rows in the batch (tests: batch invariance); callers pass the workspace only
     // for M <= 1024
-    const int tiles_ref = 4 * tiles_n;
+    // PCY_SPLITK_BIG=1 (OFF by default): a split rule sized for the 256 x 256 tiles of one 512-token prompt -- two row tiles x
+    // N / 256 column tiles, split until <= 256 workgroups (Llama-3-8B: qkv 4, o 8, down 8 instead of 2, 4, 4) -- and the 256 x 256
+    // mainloop above 256 rows (below, the 128 x 128 kernel with the SAME split count: same bits for every M).  Measured at T = 512:
+    // the projections themselves 44.8 / 29.8 / 80.3 -> 42 / 30.5 / 67.3 us, but twice the partial sums make the finish launches
+    // 6.5 + 2 x 10.7 -> 9.8 + 2 x 21.1 us: prefill 10.66 -> 11.01 ms.
+    static const bool big_rule = [] { const char* e = getenv("PCY_SPLITK_BIG"); return e && atoi(e) == 1; }();
+    const int tiles_ref = big_rule ? 2 * ((a.N + 255) / 256) : 4 * tiles_n;
     int splits = 1;
-    while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    if (big_rule) while (splits < 8 && tiles_ref * splits * 2 <= 256 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    else while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
     if (splits > 1 && (size_t)splits * a.M * a.N * 4 <= a.splitk_ws_bytes) {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_SPLITK];
+      if (big_rule && a.M > 256) {
+        constexpr int smem = 2 * (256 + 256) * 64 * 2;
+        static bool configured = false;
+        if (!configured) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI_STORE, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          configured = true;
+        }
+        PcyGemmArgs b = a;
+        const int tn = (a.N + 255) / 256;
+        long gnb = (5L << 19) / ((long)256 * (a.K / splits) * 2);
+        if (gnb < 2) gnb = 2;
+        b.gn = (int)(gnb > tn ? tn : gnb);
+        b.splits = splits;
+        hipLaunchKernelGGL((gemm_kernel_big<EPI_STORE, false, false, true>), dim3(((a.M + 255) / 256) * tn * splits), dim3(512), smem, s, b);
+      } else
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
       // residual epilogue + the RMSNorm that follows in ONE finish launch (one workgroup per row) where the caller asks for it

@@ -103,6 +103,7 @@ struct PcyGemmArgs {
   // optional: 9 zeroed device words for the dynamic tile queue of the persistent 256 x 256 kernel (see gemm_kernel_big_persist, DQ)
   unsigned* tile_ctr;
   int wide_epi;         // set by the launcher: the 256 x 256 kernel's plain / residual epilogue goes through LDS (whole-row stores)
+  int splits;           // set by the launcher (split-K forms): number of K ranges, partial sums in splitk_ws [splits][M][N]
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)
