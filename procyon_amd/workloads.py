@@ -81,7 +81,7 @@ def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
     t_mean = prompt + 8 + n / 2.0
     kv_bytes = rows * t_mean * (2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2)
     gbps = (w_bytes + kv_bytes) / 1e9 / (ms / 1e3)
-    return {"bound": "hbm", "kernel": "batched decode step (hipGraph: per layer qkv / attention / o / gate-up / down launches + lm_head + pick)",
+    return {"bound": "hbm", "kernel": "batched decode step (hipGraph: per layer qkv / attention (+ qkv finish) / o / finish+norm / gate-up / down / finish+norm launches, lm_head, pick)",
             "rows": rows, "mean_cache_len": round(t_mean, 1), "ms_per_step": round(ms, 4), "tokens_per_s_decode_only": round(rows * 1e3 / ms, 1),
             "bytes_per_step": int(w_bytes + kv_bytes), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
 
