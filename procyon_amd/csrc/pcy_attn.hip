@@ -1066,6 +1066,7 @@ bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int 
   if (e && e[0] == 'e') return false;
   return dh == 64 && !causal && !has_keep && scale == 1.0f && H == Hkv;
 }
+bool pcy_attn_fast_vrow() { const char* e = getenv("PCY_FA_VROW"); return !(e && atoi(e) == 0); }
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
   if (a.vt_pad64 && pcy_attn_fast_eligible(a.dh, a.causal, a.keep != nullptr, a.scale, a.H, a.Hkv) && pcy_launch_attn_fast64(s, a, true)) {

@@ -94,7 +94,13 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
 
 // ABL != 0: measurement variants with parts of the work removed (wrong results; PCY_FA_ABL, tools/bench_attn_esm.py):
 //   1 no O rescale, 2 no exponentials, 4 no P.V MFMAs, 8 no Q.K^T MFMAs, 16 no Vt fragment reads, 32 no K fragment reads, 64 no DMA
-template <int ABL>
+// VROW: V is read where the qkv projection left it (token-major rows, a.v / a.ldv / a.vcol0) -- no transposed copy.  A V tile lands in
+// LDS as [64 keys][64 dh] (128-byte rows, the two 64-byte halves of a row swapped when bit 1 of the key is set) and the A operand of
+// O^T = Vt.P^T comes from two ds_read_b64_tr_b16: a 16-lane group supplies the addresses of a [4 keys][16 dh] block (lane L: key L >> 2,
+// dh 4 (L & 3) ..) and lane i receives column i = 4 consecutive keys of ONE dh (lane map pinned by tools/probes/tr_read_map.hip); the
+// half swap puts the four 64-byte row pieces of the 32 lanes that share an LDS cycle on four different bank quarters.
+typedef __attribute__((ext_vector_type(4))) short fa_s16x4;
+template <int ABL, bool VROW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fast64_kernel(PcyAttnArgs a, int nchunk) {
   constexpr int DH = 64, KT = 64, QW = 64, QB = 4 * QW, NBUF = 3;
   constexpr int TILE = KT * DH * 2;                     // 8 KiB: K tile, then Vt tile
@@ -111,9 +117,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   if (bq0 >= len) return;                               // uniform per workgroup
   const int qr0 = bq0 + wave * QW;
   const bool active = qr0 < len;
-  const int vt0 = a.vt_cu[sq];
+  const int vt0 = VROW ? 0 : a.vt_cu[sq];
   const bf16_t* kglob = a.k + (size_t)t0 * a.ldk + a.kcol0 + h * DH;
-  const bf16_t* vglob = a.vt + (size_t)h * DH * a.vt_total + vt0;
+  const bf16_t* vglob = VROW ? a.v + (size_t)t0 * a.ldv + a.vcol0 + h * DH : a.vt + (size_t)h * DH * a.vt_total + vt0;
 
   // Q fragments (B operand of S^T): lane holds Q[query col][16 ks + 8 half .. +8]
   bf16x8 qf[2][4];
@@ -130,24 +136,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   typedef const __attribute__((address_space(1))) void* gptr_t;
   // Staging addresses are per-thread constants plus a tile offset (recomputing row / chunk / clamp per tile cost ~40 of the ~450
   // instructions of a tile); only the ragged last tile clamps its key rows.
-  const bf16_t* kp[2]; const bf16_t* vp[2]; int srow[2], schunk[2];
+  const bf16_t* kp[2]; const bf16_t* vp[2]; int srow[2], schunk[2], vchunk[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = i * 256 + tid, row = slot >> 3, cp = slot & 7;
     srow[i] = row; schunk[i] = (cp ^ ((row >> 1) & 7)) * 8;
+    vchunk[i] = (cp ^ (((row >> 1) & 1) << 2)) * 8;     // (VROW) the 64-byte halves of a key row swap with bit 1 of the key
     kp[i] = kglob + (size_t)row * a.ldk + schunk[i];
-    vp[i] = vglob + (size_t)row * a.vt_total + schunk[i];
+    vp[i] = VROW ? vglob + (size_t)row * a.ldv + vchunk[i] : vglob + (size_t)row * a.vt_total + schunk[i];
   }
-  const size_t ktile_stride = (size_t)KT * a.ldk;
+  const size_t ktile_stride = (size_t)KT * a.ldk, vtile_stride = VROW ? (size_t)KT * a.ldv : (size_t)KT;
   auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
     if (ABL & 64) return;
     const bool clamp = (kt + 1) * KT > len;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bf16_t* ks = kp[i] + kt * ktile_stride;
-      if (clamp) { int key = kt * KT + srow[i]; key = key < len ? key : len - 1; ks = kglob + (size_t)key * a.ldk + schunk[i]; }
+      const bf16_t* vs = vp[i] + kt * vtile_stride;
+      if (clamp) {
+        int key = kt * KT + srow[i]; key = key < len ? key : len - 1;
+        ks = kglob + (size_t)key * a.ldk + schunk[i];
+        if (VROW) vs = vglob + (size_t)key * a.ldv + vchunk[i];   // (rows beyond the sequence: any finite values, their P is 0)
+      }
       __builtin_amdgcn_global_load_lds((gptr_t)ks, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vp[i] + kt * KT), (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
     }
   };
   // A-operand row (lane & 31) of S^T  ->  key of the 32-key block
@@ -157,10 +169,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int row = krow + 32 * sub;
     return *reinterpret_cast<const bf16x8*>(buf + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
   };
+  // (VROW) byte offset of this lane's 8-byte piece in the [4 keys][16 dh] block its 16-lane group supplies, dh tile t = 0 / 1
+  const int vl = lane & 15, vsw = (vl >> 3) & 1;
+  const int vbase = (8 * half + (vl >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (vl & 3)) * 2;
+  const int voff[2] = {vbase + (vsw << 6), vbase + ((vsw ^ 1) << 6)};
   auto vfrag = [&](const char* buf, int t, int sub, int c) __attribute__((always_inline)) {
     if (ABL & 16) return qf[1][t + 2 * c];
-    const int row = 32 * t + col;
-    return *reinterpret_cast<const bf16x8*>(buf + TILE + row * 128 + (((4 * sub + 2 * c + half) ^ ((row >> 1) & 7)) << 4));
+    if constexpr (VROW) {
+      typedef __attribute__((address_space(3))) fa_s16x4* tr_ptr_t;
+      const char* p = buf + TILE + voff[t] + (32 * sub + 16 * c) * 128;
+      const fa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(p));
+      const fa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(p + 4 * 128));
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      return __builtin_bit_cast(bf16x8, (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    } else {
+      const int row = 32 * t + col;
+      return *reinterpret_cast<const bf16x8*>(buf + TILE + row * 128 + (((4 * sub + 2 * c + half) ^ ((row >> 1) & 7)) << 4));
+    }
   };
 
   float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
@@ -273,9 +298,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // of 64 keys (so that a whole 64-key tile of Vt can be fetched; the pad columns are zero)
 inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_pad64) {
   if (a.dh != 64 || a.causal || a.keep || a.scale != 1.0f || a.H != a.Hkv || !vt_pad64) return false;
-  if ((a.ldq | a.ldk | a.qcol0 | a.kcol0 | a.vt_total) % 8 || a.ldo % 4) return false;
+  if ((a.ldq | a.ldk | a.qcol0 | a.kcol0) % 8 || a.ldo % 4) return false;
   const int nchunk = (a.max_len + 255) / 256;
   const dim3 grid(nchunk * a.H * a.nseq);
+  if (a.v != nullptr) {   // V token-major as the projection wrote it (no transposed copy)
+    if ((a.ldv | a.vcol0) % 8) return false;
+    hipLaunchKernelGGL((attn_fast64_kernel<0, true>), grid, dim3(256), 0, s, a, nchunk);
+    return true;
+  }
+  if (a.vt_total % 8) return false;
   const char* e = getenv("PCY_FA_ABL");   // measurement variants (wrong results)
   const int abl = e ? atoi(e) : 0;
   switch (abl) {

@@ -668,13 +668,16 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
   }
   if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096)) return r;
   bf16_t* vt = reinterpret_cast<bf16_t*>(c->ws);
-  if (fast) {
+  // the single-pass kernel reads V token-major where it is (PCY_FA_VROW=0: from a transposed copy, as the other kernels do)
+  const bool vrow = fast && pcy_attn_fast_vrow() && ldv % 8 == 0 && vcol0 % 8 == 0;
+  if (fast && !vrow) {
     vt_cu64 = reinterpret_cast<int32_t*>(c->ws + align_up((size_t)Hkv * dh * vt_total * 2, 256));
     pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
     vt_cu = vt_cu64;
   }
-  pcy_launch_transpose_v(c->stream, (const bf16_t*)v, ldv, vcol0, Hkv, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
+  if (!vrow) pcy_launch_transpose_v(c->stream, (const bf16_t*)v, ldv, vcol0, Hkv, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
   PcyAttnArgs t{};
+  if (vrow) { t.v = (const bf16_t*)v; t.ldv = ldv; t.vcol0 = vcol0; }
   t.q = (const bf16_t*)q; t.ldq = ldq; t.qcol0 = qcol0; t.k = (const bf16_t*)k; t.ldk = ldk; t.kcol0 = kcol0; t.vt = vt;
   t.vt_total = vt_total; t.o = (bf16_t*)o; t.ldo = ldo; t.cu = cu; t.vt_cu = vt_cu; t.keep = keep; t.nseq = nseq; t.max_len = max_len;
   t.H = H; t.Hkv = Hkv; t.dh = dh; t.causal = causal; t.scale = scale; t.vt_pad64 = fast ? 1 : 0;
@@ -870,7 +873,8 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   bf16_t* act = cv.take<bf16_t>((size_t)ntok * F);
   bf16_t* vt = cv.take<bf16_t>((size_t)d * vt_total);
   int32_t* vt_cu64 = cv.take<int32_t>((size_t)nseq + 1);
-  if (fast) {
+  const bool vrow = fast && pcy_attn_fast_vrow();   // the single-pass kernel reads V out of qkv: no transposed copy
+  if (fast && !vrow) {
     pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
     vt_cu = vt_cu64;
   }
@@ -893,8 +897,9 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
       pcy_launch_rope(s, qkv, 3 * d, 0, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, qscale);
       pcy_launch_rope(s, qkv, 3 * d, d, H, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, ntok, m->rope_mode, 0.f);
     }
-    pcy_launch_transpose_v(s, qkv, 3 * d, 2 * d, H, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
+    if (!vrow) pcy_launch_transpose_v(s, qkv, 3 * d, 2 * d, H, dh, cu, vt_cu, nseq, max_len, vt, vt_total);
     PcyAttnArgs t{};
+    if (vrow) { t.v = qkv; t.ldv = 3 * d; t.vcol0 = 2 * d; }
     t.q = qkv; t.ldq = 3 * d; t.qcol0 = 0; t.k = qkv; t.ldk = 3 * d; t.kcol0 = d; t.vt = vt; t.vt_total = vt_total;
     t.o = ao; t.ldo = d; t.cu = cu; t.vt_cu = vt_cu; t.keep = nullptr; t.nseq = nseq; t.max_len = max_len; t.H = H; t.Hkv = H;
     t.dh = dh; t.causal = 0; t.scale = 1.0f; t.vt_pad64 = fast ? 1 : 0;

@@ -61,10 +61,34 @@ __device__ __forceinline__ float gelu_esm_lut(float v /* bf16-valued */, const u
 // stage a [128 rows][BK k] bf16 tile with 1-KiB wave-instructions (LDS image lane-linear).  A row holds CPR = BK/8
 // 16-byte chunks; LDS chunk position c' of row r holds global chunk c' ^ swz(r), the same XOR is applied on the read side:
 //   BK=64 (128-B rows): swz = r & 7        BK=32 (64-B rows): swz = (r >> 2) & 3      -> conflict-free ds_read_b128
-template <int BK>
-__device__ __forceinline__ int swz(int r) { return BK == 64 ? (r & 7) : ((r >> 2) & 3); }
+// SW = 1 (BK = 64 only): the swizzle of a W tile whose rows are read in the PERMUTED order of the 256 x 256 kernels (wperm_row
+// below: the 16 lanes fr of a fragment read hit rows a*8 + h*4 + b, a = fr >> 2, b = fr & 3) -- s(r) = 2*((r >> 3) & 3) + ((r >> 1) & 1)
+// puts the 16 lanes of every ds_read_b128 lane group on 16 distinct 16-byte slots, as r & 7 does for 16 consecutive rows.
+// SW = 2: the same for the SwiGLU row order (wperm_row_swiglu: a = bits 5 and 3 of the row).
+template <int BK, int SW = 0>
+__device__ __forceinline__ int swz(int r) {
+  if (SW == 1) return (((r >> 3) & 3) << 1) | ((r >> 1) & 1);
+  if (SW == 2) return (((r >> 5) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 1) & 1);
+  return BK == 64 ? (r & 7) : ((r >> 2) & 3);
+}
+// Row order of the W operand inside a wave's feature range (256 x 256 kernels).  MFMA tile i, operand row q (= lane & 15 on the
+// read side, = fq*4 + r on the accumulator side) is the wave's feature (i>>1)*32 + (q>>2)*8 + (i&1)*4 + (q&3): a lane's
+// accumulators of the tile pair (2p, 2p+1) are then EIGHT consecutive features of one token -> 16-byte epilogue loads / stores,
+// four lanes = 64 contiguous bytes of a row per instruction instead of 32 (the write path of a CU is bound by requests: the
+// plain epilogue of a tile round took 8 us).  A pure relabelling of which weight row sits in which MFMA row: every output element
+// keeps its k order, same bits.
+__device__ __forceinline__ int wperm_row(int i, int q) { return (i >> 1) * 32 + (q >> 2) * 8 + (i & 1) * 4 + (q & 3); }
 
-template <int BK, int ROWS = 128, int NW = 4>
+// The SwiGLU form (packed W rows: 16 gate rows, then the 16 up rows of the same features, ...): a quad of tiles (4Q .. 4Q+3) = (gate,
+// up) of features +0..3 and (gate, up) of features +4..7 of the lane's eight output features Q*32 + fq*8 + [0, 8), so the gate and
+// the up value of a feature meet in one lane and the product leaves as a 16-byte store.
+__device__ __forceinline__ int wperm_row_swiglu(int i, int q) {
+  return (i >> 2) * 64 + (q >> 3) * 32 + (i & 1) * 16 + ((q >> 2) & 1) * 8 + ((i >> 1) & 1) * 4 + (q & 3);
+}
+template <int EPI>
+__device__ __forceinline__ int wperm(int i, int q) { return EPI == EPI_SWIGLU ? wperm_row_swiglu(i, q) : wperm_row(i, q); }
+
+template <int BK, int ROWS = 128, int NW = 4, int SW = 0>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = ROWS / RPI;
@@ -73,7 +97,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
     const int inst = wave * (NINST / NW) + i;
     const int r = inst * RPI + lane / CPR;
     const int cp = lane % CPR;
-    const int c = cp ^ swz<BK>(r);
+    const int c = cp ^ swz<BK, SW>(r);
     int gr = row0 + r;
     gr = gr < nrows_valid ? gr : nrows_valid - 1;
     const bf16_t* src = g + (size_t)gr * ld + k0 + c * 8;
@@ -94,9 +118,9 @@ __device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ g, int ld
   __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
 }
 
-template <int BK>
+template <int BK, int SW = 0>
 __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK>(row)) << 4));
+  return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK, SW>(row)) << 4));
 }
 
 // Tile rasterisation for L2 reuse.  Each XCD (private 4 MiB L2) receives a contiguous run of the logical tile order
@@ -312,6 +336,242 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < a.N) a.C[(size_t)m * a.ldc + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+// Epilogue of the 256 x 256 kernels with the W rows in wperm_row order: the lane (fr, fq) holds, in the tile pair (2p, 2p+1),
+// features nw + p*32 + fq*8 + [0, 8) of token mw + j*16 + fr (tile 2p: +0..3, tile 2p+1: +4..7).  Same values, same rounding
+// order as gemm_epilogue; bias / residual / rotary tables / output move as 16-byte pieces.  mw / nw = first token / feature of
+// the wave's tile (callers with half a wave tile -- the fp8 kernels -- pass the half's first feature).
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = lo_bf(u.x); f[1] = hi_bf(u.x); f[2] = lo_bf(u.y); f[3] = hi_bf(u.y);
+  f[4] = lo_bf(u.z); f[5] = hi_bf(u.z); f[6] = lo_bf(u.w); f[7] = hi_bf(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf(f[0], f[1]), pack_bf(f[2], f[3]), pack_bf(f[4], f[5]), pack_bf(f[6], f[7]));
+}
+template <int EPI, int WTN, int WTM, int JBR = 2>
+__device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int mw, int nw, int fr, int fq,
+                                                   const uint16_t* gelu_lut = nullptr, const float* sx = nullptr) {
+  // sx != nullptr (fp8 kernels): the accumulators are still raw; token j's scale sx[j] and the feature scales a.sw are applied
+  // here, (acc * sx) * sw as in oracle/fp8_ref.py, feature scales fetched per tile pair (all 32 of a wave tile up front spill)
+  constexpr int NP = WTN / 2;
+  const bool vec_ok = (a.ldc % 8 == 0) && (a.N % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                      (a.resid == nullptr || (a.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(a.resid) & 15) == 0)) &&
+                      (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+  if constexpr (EPI == EPI_STORE) if (a.rope_cos != nullptr) {
+    // fused rotary (head_dim 64; callers guarantee N % 64 == 0 and 16-byte aligned rows): a head = 4 tiles, the lane holds
+    // e = fq*8 + [0, 8) in tiles (4hg, 4hg+1) and the partners e + 32 in tiles (4hg+2, 4hg+3).  Loads first: bias, positions,
+    // then per token four 16-byte pieces of its cos / sin rows (shared by every head).
+    constexpr int NH = WTN / 4;
+    float b1[NH][8], b2[NH][8];
+#pragma unroll
+    for (int hg = 0; hg < NH; ++hg) {
+      const int n1 = nw + hg * 64 + fq * 8;
+      const int nc = (a.bias && n1 + 40 <= a.N) ? n1 : 0;
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      unpack8(a.bias ? *reinterpret_cast<const uint4*>(a.bias + nc) : z, b1[hg]);
+      unpack8(a.bias ? *reinterpret_cast<const uint4*>(a.bias + nc + 32) : z, b2[hg]);
+    }
+    int pj[WTM];
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = mw + j * 16 + fr;
+      pj[j] = a.rope_pos[m < a.M ? m : a.M - 1];
+    }
+    constexpr int JB = 2;   // tokens per batch of table loads (all four at once: 64 VGPRs of 16-byte pieces, spills)
+#pragma unroll
+    for (int j0 = 0; j0 < WTM; j0 += JB) {
+      uint4 cs[JB][4];   // [token][cos lo, cos hi, sin lo, sin hi]
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const bf16_t* crow = a.rope_cos + (size_t)pj[j0 + jj] * 64 + fq * 8;
+        const bf16_t* srow = a.rope_sin + (size_t)pj[j0 + jj] * 64 + fq * 8;
+        cs[jj][0] = *reinterpret_cast<const uint4*>(crow);
+        cs[jj][1] = *reinterpret_cast<const uint4*>(crow + 32);
+        cs[jj][2] = *reinterpret_cast<const uint4*>(srow);
+        cs[jj][3] = *reinterpret_cast<const uint4*>(srow + 32);
+      }
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+        const int m = mw + j * 16 + fr;
+        if (m >= a.M) continue;
+        float cc1[8], cc2[8], ss1[8], ss2[8];
+        unpack8(cs[jj][0], cc1); unpack8(cs[jj][1], cc2); unpack8(cs[jj][2], ss1); unpack8(cs[jj][3], ss2);
+#pragma unroll
+        for (int hg = 0; hg < NH; ++hg) {
+          const int nh = nw + hg * 64;   // first feature of this head
+          if (nh >= a.N) continue;
+          const bool rot = nh < a.rope_ncols, scl = nh < a.rope_qcols;
+          float o1[8], o2[8];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int x = t * 4 + r;
+              float a1 = acc[hg * 4 + t][j][r], a2 = acc[hg * 4 + 2 + t][j][r];
+              if (sx) {
+                const int n1 = nh + fq * 8 + x;
+                a1 = (a1 * sx[j]) * a.sw[n1 < a.N ? n1 : a.N - 1];
+                a2 = (a2 * sx[j]) * a.sw[n1 + 32 < a.N ? n1 + 32 : a.N - 1];
+              }
+              float y1 = rbf(a1 + b1[hg][x]), y2 = rbf(a2 + b2[hg][x]);
+              if (rot) {
+                if (scl) { y1 = rbf(y1 * a.rope_scale); y2 = rbf(y2 * a.rope_scale); }
+                if (a.rope_mode == 0) {
+                  o1[x] = rbf(rbf(y1 * cc1[x]) + rbf(-y2 * ss1[x]));
+                  o2[x] = rbf(rbf(y2 * cc2[x]) + rbf(y1 * ss2[x]));
+                } else {
+                  o1[x] = y1 * cc1[x] + (-y2) * ss1[x];
+                  o2[x] = y2 * cc2[x] + y1 * ss2[x];
+                }
+              } else {
+                o1[x] = y1; o2[x] = y2;
+              }
+            }
+          bf16_t* dst = a.C + (size_t)m * a.ldc + nh + fq * 8;
+          *reinterpret_cast<uint4*>(dst) = pack8(o1);
+          *reinterpret_cast<uint4*>(dst + 32) = pack8(o2);
+        }
+      }
+    }
+    return;
+  }
+  float bias[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int n = nw + p * 32 + fq * 8;
+    if (a.bias && vec_ok && n < a.N) {
+      unpack8(*reinterpret_cast<const uint4*>(a.bias + n), bias[p]);
+    } else {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int nn = (n + x) < a.N ? (n + x) : a.N - 1;
+        bias[p][x] = a.bias ? bf2f(a.bias[nn]) : 0.f;
+      }
+    }
+  }
+  constexpr int JB = JBR;   // tokens per batch of residual loads (a whole wave tile of 16-byte pieces at once spills; the fp8 kernels ask for 1)
+#pragma unroll
+  for (int j0 = 0; j0 < WTM; j0 += JB) {
+    uint4 res[JB][NP];
+    if (EPI == EPI_RESID && vec_ok) {
+#pragma unroll
+      for (int jj = 0; jj < JB; ++jj) {
+        const int m = mw + (j0 + jj) * 16 + fr;
+        const int mc = m < a.M ? m : a.M - 1;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int n = nw + p * 32 + fq * 8;
+          res[jj][p] = *reinterpret_cast<const uint4*>(a.resid + (size_t)mc * a.ldr + (n < a.N ? n : 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      const int j = j0 + jj;
+      const int m = mw + j * 16 + fr;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int n = nw + p * 32 + fq * 8;
+        if (n >= a.N) continue;
+        float v[8];
+        if (sx) {
+          float sw8[8];
+          if (n + 8 <= a.N && (reinterpret_cast<uintptr_t>(a.sw) & 15) == 0) {
+            const float4 s0 = *reinterpret_cast<const float4*>(a.sw + n), s1 = *reinterpret_cast<const float4*>(a.sw + n + 4);
+            sw8[0] = s0.x; sw8[1] = s0.y; sw8[2] = s0.z; sw8[3] = s0.w; sw8[4] = s1.x; sw8[5] = s1.y; sw8[6] = s1.z; sw8[7] = s1.w;
+          } else {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) sw8[x] = a.sw[n + x < a.N ? n + x : a.N - 1];
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[t * 4 + r] = rbf((acc[2 * p + t][j][r] * sx[j]) * sw8[t * 4 + r] + bias[p][t * 4 + r]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[t * 4 + r] = rbf(acc[2 * p + t][j][r] + bias[p][t * 4 + r]);
+        }
+        if (EPI == EPI_RESID) {
+          if (vec_ok) {
+            float rr[8];
+            unpack8(res[jj][p], rr);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) v[x] = rbf(v[x] + rr[x]);
+          } else {
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+              if (n + x < a.N) v[x] = rbf(v[x] + bf2f(a.resid[(size_t)m * a.ldr + n + x]));
+          }
+        }
+        if (EPI == EPI_GELU_ERF) {
+#pragma unroll
+          for (int x = 0; x < 8; ++x) v[x] = rbf(gelu_erf_f(v[x]));
+        }
+        if (EPI == EPI_GELU_ESM) {
+#pragma unroll
+          for (int x = 0; x < 8; ++x) v[x] = gelu_lut ? gelu_esm_lut(v[x], gelu_lut) : gelu_esm_chain(v[x]);
+        }
+        if (vec_ok) {
+          *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = pack8(v);
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; ++x)
+            if (n + x < a.N) a.C[(size_t)m * a.ldc + n + x] = f2bf(v[x]);
+        }
+      }
+    }
+  }
+}
+
+// SwiGLU epilogue over W rows in wperm_row_swiglu order: nwp = first PACKED row of the wave's tile (or of its half), the lane's
+// outputs are features nwp/2 + Q*32 + fq*8 + [0, 8) of token mw + j*16 + fr.  Rounding as gemm_epilogue's SwiGLU branch.
+template <int WTN, int WTM>
+__device__ __forceinline__ void gemm_epilogue_perm_swiglu(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int mw, int nwp, int fr, int fq,
+                                                          const float* sx = nullptr) {
+  const int Nout = a.N >> 1;
+  const bool vec_ok = (a.ldc % 8 == 0) && (Nout % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+#pragma unroll
+  for (int Q = 0; Q < WTN / 4; ++Q) {
+    const int nout = (nwp >> 1) + Q * 32 + fq * 8;
+    if (nout >= Nout) continue;
+    float swg[8], swu[8];
+    if (sx) {
+      const int rg = nwp + Q * 64 + (fq >> 1) * 32 + (fq & 1) * 8;   // packed row of the lane's first gate feature; up = +16
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        swg[x] = a.sw[rg + x < a.N ? rg + x : a.N - 1];
+        swu[x] = a.sw[rg + 16 + x < a.N ? rg + 16 + x : a.N - 1];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) {
+      const int m = mw + j * 16 + fr;
+      if (m >= a.M) continue;
+      float o[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int x = hf * 4 + r;
+          float ga = acc[Q * 4 + hf * 2][j][r], ua = acc[Q * 4 + hf * 2 + 1][j][r];
+          if (sx) { ga = (ga * sx[j]) * swg[x]; ua = (ua * sx[j]) * swu[x]; }
+          const float g = rbf(ga), u = rbf(ua);
+          o[x] = rbf(silu_f(g)) * u;
+        }
+      if (vec_ok && nout + 8 <= Nout) {
+        *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + nout) = pack8(o);
+      } else {
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (nout + x < Nout) a.C[(size_t)m * a.ldc + nout + x] = f2bf(o[x]);
       }
     }
   }
@@ -607,10 +867,14 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
 // SPLITK: grid = tiles x a.splits, workgroup (tile, split) accumulates k in [split * K / splits, +K / splits) and stores its fp32
 // partial tile to a.splitk_ws[split] (finished by gemm_splitk_epilogue / the finish + norm kernel, as for gemm_splitk_kernel: same
 // k order per element, same bits); EPI is then ignored.
-template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false>
+template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false, bool NOPERM = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
+  // W rows in wperm_row order + the 16-byte epilogue (the LDS-epilogue experiment, the K-split partial store and -- for now --
+  // the SwiGLU epilogue keep the natural order)
+  constexpr bool PERM = !WIDE && !SPLITK && !NOPERM;   // NOPERM: the natural row order (PCY_GEMM_PERM=0, A/B measurements)
+  constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
   extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
   char* smem = smem_dyn;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -633,7 +897,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   const int kbeg = SPLITK ? split * (a.K / a.splits) : 0;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
   stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
-  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
+  stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -654,7 +918,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     if (((F8 && !PCY_F8_VARIANT) || (!F8 && !(PCY_BIG_VARIANT & 1))) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
       stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
     if constexpr (F8) {
       i32x8 xf[WTM];
@@ -668,13 +932,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
-        const i32x8 wf = cat_frag(lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq), lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, 4 + fq));
+        const i32x8 wf = cat_frag(lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), fq), lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), 4 + fq));
 #pragma unroll
         for (int j = 0; j < WTM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         if (PCY_F8_VARIANT && i == WTN / 2 - 1 && kt + 1 < nk) {
           __builtin_amdgcn_s_setprio(0);
-          stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
+          stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
           __builtin_amdgcn_s_setprio(1);
         }
       }
@@ -686,11 +950,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
-        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
         if ((PCY_BIG_VARIANT & 1) && !(PCY_BIG_VARIANT & 4) && kt + 1 < nk) {   // one operand's stage behind each kb's fragment reads
           char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
           if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
+          else stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
         }
         if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -737,6 +1001,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       const int m = m0 + wm * WTM * 16 + j * 16 + fr;
       sx[j] = a.sa[m < a.M ? m : a.M - 1];
     }
+    if constexpr (!PERM) {
 #pragma unroll
     for (int i = 0; i < WTN; ++i) {
       const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
@@ -747,11 +1012,15 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
         for (int j = 0; j < WTM; ++j) acc[i][j][r] = (acc[i][j][r] * sx[j]) * sw;
       }
     }
+    }
     // the epilogue in two halves of 64 features: its up-front residual loads (64 VGPRs for the whole 64 x 128 wave tile)
     // plus the scale registers would spill
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<4, WTM>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, sx);
+      else if constexpr (PERM) gemm_epilogue_perm<EPI, 4, WTM, 1>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, nullptr, sx);
+      else gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+    }
     return;
   }
   if constexpr (WIDE) {
@@ -771,10 +1040,13 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   }
   if constexpr (EPI == EPI_GELU_ESM) {
     gelu_lut_to_lds<512>(smem);
-    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    if constexpr (PERM) gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
     return;
   }
-  gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
+  if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
+  else if constexpr (PERM) gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
+  else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
 // Persistent variant of gemm_kernel_big for the ESM fc1 GEMM (EPI_GELU_ESM, K = 1280: 20 k-steps per tile, so the first-stage
@@ -786,10 +1058,12 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 // idles, once per tile round.  Out of phase, a CU's epilogue shares the memory system with 7/8 of the chip in its mainloop; the
 // queue makes the late starters take fewer tiles, so the stagger does not come back as a tail.  a.tile_ctr: 9 zeroed words
 // (8 XCD heads + an exit counter; the last workgroup to leave zeroes them again).
-template <int EPI, bool F8 = false, bool DQ = false>
+template <int EPI, bool F8 = false, bool DQ = false, bool NOPERM = false>
 __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
+  constexpr bool PERM = !NOPERM;   // as in gemm_kernel_big
+  constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
   extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
   char* smem = smem_dyn;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -827,7 +1101,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   const int nk = F8 ? a.K / 128 : a.K / BK;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
   stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
+  stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
   const int fr = lane & 15, fq = lane >> 4;
   for (int vb = blockIdx.x; DQ ? true : (PERSIST ? vb < ntiles : vb == (int)blockIdx.x); vb += gridDim.x) {
   if (DQ && threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);   // the NEXT tile: the answer is read after the mainloop's barriers
@@ -844,7 +1118,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
     if ((F8 || !(PCY_BIG_VARIANT & 1)) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
       stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
     if constexpr (F8) {
       i32x8 xf[WTM];
@@ -853,7 +1127,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
         xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
-        const i32x8 wf = cat_frag(lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, fq), lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, 4 + fq));
+        const i32x8 wf = cat_frag(lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), fq), lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), 4 + fq));
 #pragma unroll
         for (int j = 0; j < WTM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
@@ -865,11 +1139,11 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
-        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK>(Wcur, wn * WTN * 16 + i * 16 + fr, kb * 4 + fq);
+        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
         if ((PCY_BIG_VARIANT & 1) && kt + 1 < nk) {
           char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
           if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+          else stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
         }
         if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -891,7 +1165,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   if (have_next) {
     tile_origin<TBM, TBN>(a, DQ ? run_start + nj : tile_of(nvb), nm0, nn0);
     stage_tile<BK, TBM, NW>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
-    stage_tile<BK, TBN, NW>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
+    stage_tile<BK, TBN, NW, SWW>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
   }
   if constexpr (F8) {
     // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
@@ -901,6 +1175,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
       const int m = m0 + wm * WTM * 16 + j * 16 + fr;
       sx[j] = a.sa[m < a.M ? m : a.M - 1];
     }
+    if constexpr (!PERM) {
 #pragma unroll
     for (int i = 0; i < WTN; ++i) {
       const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
@@ -911,16 +1186,23 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
         for (int j = 0; j < WTM; ++j) acc[i][j][r] = (acc[i][j][r] * sx[j]) * sw;
       }
     }
+    }
     // the epilogue in two halves of 64 features: its up-front residual loads (64 VGPRs for the whole 64 x 128 wave tile)
     // plus the scale registers would spill
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<4, WTM>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, sx);
+      else if constexpr (PERM) gemm_epilogue_perm<EPI, 4, WTM, 1>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, nullptr, sx);
+      else gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
+    }
   } else if constexpr (EPI == EPI_GELU_ESM) {
     gelu_lut_to_lds<512>(smem + TILE_A + TILE_W);
-    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
+    if constexpr (PERM) gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
+    else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
   } else {
-    gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
+    if constexpr (!PERM) gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
+    else if constexpr (EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
+    else gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
   }
   m0 = nm0; n0 = nn0;
   if (DQ && !have_next) break;
@@ -935,6 +1217,22 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
 unsigned long long g_pcy_dispatch[PCY_DISPATCH_N] = {};
 namespace {
 
+// PCY_GEMM_PERM=0 (read per call: interleaved A/B in one process): the 256 x 256 kernels with the natural W row order and the
+// 8-byte epilogue of the first rounds; same bits either way
+// PCY_GEMM_PERM = mask of the epilogues that use the permuted order: 1 STORE, 2 RESID, 4 ESM GELU, 8 SwiGLU, 16 the fp8 kernels.
+// Measured in one process, interleaved (tools/ab_esm_env.py, tools/ab_llama_env.py): ESM2-650M encoder at 25 x 1026 tokens 535 -> 553
+// proteins/s with 1 | 2 | 4 (K = 1280: a tile is 20 k-steps, the epilogue a fifth of it); Llama-3-8B prefill (K = 4096 / 14336) 64 x 450
+// tokens 1048 TFLOP/s with every mask, one 512-token prompt 10.43 -> 10.53 ms with the SwiGLU form (8), fp8 1804 -> 1793 TFLOP/s with
+// 16 -- so the default is 7: the bf16 STORE / RESID / ESM-GELU epilogues.
+#ifndef PCY_GEMM_PERM_DEFAULT
+#define PCY_GEMM_PERM_DEFAULT 7
+#endif
+inline bool gemm_noperm(int epi, bool f8) {
+  const char* e = getenv("PCY_GEMM_PERM");
+  const int mask = e ? atoi(e) : PCY_GEMM_PERM_DEFAULT;
+  const int bit = epi == EPI_STORE ? 1 : epi == EPI_RESID ? 2 : epi == EPI_GELU_ESM ? 4 : epi == EPI_SWIGLU ? 8 : 0;
+  return !(mask & bit) || (f8 && !(mask & 16));
+}
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   constexpr int smem = 2 * (256 + 256) * 64 * 2;
@@ -950,6 +1248,15 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
     configured = true;
   }
   ++g_pcy_dispatch[PCY_DISPATCH_GEMM_FP8];
+  if (gemm_noperm(EPI, true)) {
+    static bool configured_n = false;
+    if (!configured_n) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      configured_n = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, false, true>), dim3(tiles_big), dim3(512), smem, s, b);
+    return;
+  }
   hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
@@ -1009,6 +1316,22 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         }
         ++g_pcy_dispatch[EPI == EPI_GELU_ESM ? PCY_DISPATCH_GEMM_BIG_PERSIST : PCY_DISPATCH_GEMM_BIG];
         hipLaunchKernelGGL((gemm_kernel_big<EPI, false, true>), dim3(tiles_big), dim3(512), smem_w, s, b);
+        return;
+      }
+      if (gemm_noperm(EPI, false)) {
+        static bool configured_n = false;
+        if (!configured_n) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          configured_n = true;
+        }
+        if constexpr (EPI == EPI_GELU_ESM) {
+          ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
+          hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, true>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
+        } else {
+          ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
+          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, true>), dim3(tiles_big), dim3(512), smem, s, b);
+        }
         return;
       }
       if constexpr (EPI == EPI_GELU_ESM) {

@@ -151,7 +151,12 @@ struct PcyAttnArgs {
   int nseq, max_len, H, Hkv, dh, causal;
   float scale;                           // multiplied into bf16 scores, then rounded (1.0 = none)
   int vt_pad64;                          // every sequence's Vt slice starts at a multiple of 8 and is zero-padded to a multiple of 64 keys
+  // optional, single-pass kernel only: V token-major (head h at column vcol0 + h*dh) -- set instead of vt / vt_cu / vt_total, no
+  // transposed copy is made at all (vt_pad64 still says "the caller may take the single-pass kernel")
+  const bf16_t* v; int ldv; int vcol0;
 };
+// PCY_FA_VROW=0 (read per call): the single-pass attention reads a transposed copy of V (the first form) instead of V itself
+bool pcy_attn_fast_vrow();
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a);
 // the single-pass kernel (pcy_attn_fast.h) covers this call unless PCY_ESM_ATTN=exact asks for the reference's rounding points
 bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv);
