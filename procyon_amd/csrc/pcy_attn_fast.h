@@ -95,10 +95,12 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
 // ABL != 0: measurement variants with parts of the work removed (wrong results; PCY_FA_ABL, tools/bench_attn_esm.py):
 //   1 no O rescale, 2 no exponentials, 4 no P.V MFMAs, 8 no Q.K^T MFMAs, 16 no Vt fragment reads, 32 no K fragment reads, 64 no DMA
 // VROW: V is read where the qkv projection left it (token-major rows, a.v / a.ldv / a.vcol0) -- no transposed copy.  A V tile lands in
-// LDS as [64 keys][64 dh] (128-byte rows, the two 64-byte halves of a row swapped when bit 1 of the key is set) and the A operand of
-// O^T = Vt.P^T comes from two ds_read_b64_tr_b16: a 16-lane group supplies the addresses of a [4 keys][16 dh] block (lane L: key L >> 2,
-// dh 4 (L & 3) ..) and lane i receives column i = 4 consecutive keys of ONE dh (lane map pinned by tools/probes/tr_read_map.hip); the
-// half swap puts the four 64-byte row pieces of the 32 lanes that share an LDS cycle on four different bank quarters.
+// LDS as [16 key quads][4 dh blocks][4 keys][16 dh] (128-byte blocks; the LDS-DMA image is lane-linear, so the order is made on the
+// SOURCE addresses) and the A operand of O^T = Vt.P^T comes from two ds_read_b64_tr_b16: a 16-lane group supplies the addresses of one
+// [4 keys][16 dh] block (lane L: key L >> 2, dh 4 (L & 3) .. = byte 8 L of the block) and lane i receives column i = 4 consecutive keys of
+// ONE dh (lane map pinned by tools/probes/tr_read_map.hip).  The 32 lanes that share an LDS cycle read 256 contiguous bytes.
+// (first form: [64 keys][64 dh] rows with the 64-byte halves swapped on bit 1 of the key -- conflict-free by the bank formula, but the
+// kernel ran 17 us per layer slower than over the transposed copy)
 typedef __attribute__((ext_vector_type(4))) short fa_s16x4;
 template <int ABL, bool VROW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fast64_kernel(PcyAttnArgs a, int nchunk) {
@@ -136,14 +138,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   typedef const __attribute__((address_space(1))) void* gptr_t;
   // Staging addresses are per-thread constants plus a tile offset (recomputing row / chunk / clamp per tile cost ~40 of the ~450
   // instructions of a tile); only the ragged last tile clamps its key rows.
-  const bf16_t* kp[2]; const bf16_t* vp[2]; int srow[2], schunk[2], vchunk[2];
+  const bf16_t* kp[2]; const bf16_t* vp[2]; int srow[2], schunk[2], vrow[2], vchunk[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = i * 256 + tid, row = slot >> 3, cp = slot & 7;
     srow[i] = row; schunk[i] = (cp ^ ((row >> 1) & 7)) * 8;
-    vchunk[i] = (cp ^ (((row >> 1) & 1) << 2)) * 8;     // (VROW) the 64-byte halves of a key row swap with bit 1 of the key
+    // (VROW) 16-byte slot of the tile image -> the (key, dh chunk) it holds: slot = ((key >> 2) * 4 + dh16) * 8 + (key & 3) * 2 + (dhc & 1)
+    vrow[i] = (slot >> 5) * 4 + ((slot >> 1) & 3);
+    vchunk[i] = (((slot >> 3) & 3) * 2 + (slot & 1)) * 8;
     kp[i] = kglob + (size_t)row * a.ldk + schunk[i];
-    vp[i] = VROW ? vglob + (size_t)row * a.ldv + vchunk[i] : vglob + (size_t)row * a.vt_total + schunk[i];
+    vp[i] = VROW ? vglob + (size_t)vrow[i] * a.ldv + vchunk[i] : vglob + (size_t)row * a.vt_total + schunk[i];
   }
   const size_t ktile_stride = (size_t)KT * a.ldk, vtile_stride = VROW ? (size_t)KT * a.ldv : (size_t)KT;
   auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
@@ -156,7 +160,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       if (clamp) {
         int key = kt * KT + srow[i]; key = key < len ? key : len - 1;
         ks = kglob + (size_t)key * a.ldk + schunk[i];
-        if (VROW) vs = vglob + (size_t)key * a.ldv + vchunk[i];   // (rows beyond the sequence: any finite values, their P is 0)
+        if (VROW) {   // (rows beyond the sequence: any finite values, their P is 0)
+          int vk = kt * KT + vrow[i]; vk = vk < len ? vk : len - 1;
+          vs = vglob + (size_t)vk * a.ldv + vchunk[i];
+        }
       }
       __builtin_amdgcn_global_load_lds((gptr_t)ks, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)vs, (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
@@ -169,15 +176,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int row = krow + 32 * sub;
     return *reinterpret_cast<const bf16x8*>(buf + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
   };
-  // (VROW) byte offset of this lane's 8-byte piece in the [4 keys][16 dh] block its 16-lane group supplies, dh tile t = 0 / 1
-  const int vl = lane & 15, vsw = (vl >> 3) & 1;
-  const int vbase = (8 * half + (vl >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (vl & 3)) * 2;
-  const int voff[2] = {vbase + (vsw << 6), vbase + ((vsw ^ 1) << 6)};
+  // (VROW) byte offset of this lane's 8-byte piece: block (key quad 2 half + .., dh block (lane >> 4) & 1 + ..), byte 8 (lane & 15)
+  const int vbase = half * 1024 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
   auto vfrag = [&](const char* buf, int t, int sub, int c) __attribute__((always_inline)) {
     if (ABL & 16) return qf[1][t + 2 * c];
     if constexpr (VROW) {
       typedef __attribute__((address_space(3))) fa_s16x4* tr_ptr_t;
-      const char* p = buf + TILE + voff[t] + (32 * sub + 16 * c) * 128;
+      const char* p = buf + TILE + vbase + ((8 * sub + 4 * c) * 4 + 2 * t) * 128;   // key quad 8 sub + 4 c (+ 2 half) + u, dh block 2 t (+ ..)
       const fa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(p));
       const fa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(p + 4 * 128));
       typedef __attribute__((ext_vector_type(8))) short s16x8_t;

@@ -554,3 +554,89 @@ def test_gemm_epilogue_through_lds_bit_identical(ctx, monkeypatch, epi):
         outs.append(ctx.gemm(A, W, b, r, epi).cpu())
         assert _dispatch(L.DISPATCH_GEMM_BIG) + _dispatch(L.DISPATCH_GEMM_BIG_PERSIST) == n0 + 1     # the 256 x 256 kernels
     assert torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------- round 3, later: row order of the 256 x 256 GEMM, V path of the attention
+@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(2048 + 300, 1280 + 256 + 8, 1280), (2304, 2560, 2560)])
+def test_gemm_permuted_row_order_bit_identical(ctx, monkeypatch, M, N, K, epi):
+    """PCY_GEMM_PERM (mask per epilogue): the 256 x 256 kernels read the W rows in an order that leaves a lane 8 consecutive features
+    (16-byte epilogue pieces) -- a relabelling of MFMA rows, so every epilogue (plain, residual, ESM GELU, SwiGLU; ragged M and N
+    edges) must give the bits of the natural order."""
+    from procyon_amd import _lib as L
+    from procyon_amd.engine import interleave_gate_up
+    A, b = rnd(M, K, seed=1).cuda(), rnd(N, seed=3).cuda()
+    if epi == 4:
+        N = N // 32 * 32
+        W = interleave_gate_up(rnd(N // 2, K, seed=2, std=0.05), rnd(N // 2, K, seed=4, std=0.05)).cuda()
+        b = None
+    else:
+        W = rnd(N, K, seed=2, std=0.05).cuda()
+    r = rnd(M, N, seed=5).cuda() if epi == 1 else None
+    outs = []
+    for mask in ("0", "31"):
+        monkeypatch.setenv("PCY_GEMM_PERM", mask)
+        n0 = _dispatch(L.DISPATCH_GEMM_BIG) + _dispatch(L.DISPATCH_GEMM_BIG_PERSIST)
+        outs.append(ctx.gemm(A, W, b, r, epi).cpu())
+        assert _dispatch(L.DISPATCH_GEMM_BIG) + _dispatch(L.DISPATCH_GEMM_BIG_PERSIST) == n0 + 1     # the 256 x 256 kernels
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("epi", [0, 1, 4])
+def test_gemm_fp8_permuted_row_order_bit_identical(ctx, monkeypatch, epi):
+    """the same for the e4m3 kernels (dequantisation scales applied inside the permuted epilogue)"""
+    from procyon_amd import _lib as L
+    from procyon_amd.engine import interleave_gate_up
+    M, N, K = 700, 1536 + 64, 1024
+    a8, sa = ctx.quant_rows_fp8(rnd(M, K, seed=1).cuda())
+    W = rnd(N, K, seed=2, std=0.05)
+    if epi == 4:
+        W = interleave_gate_up(W[: N // 2].contiguous(), rnd(N // 2, K, seed=4, std=0.05))
+    q8, sw = ctx.quant_rows_fp8(W.cuda())
+    r = rnd(M, N, seed=5).cuda() if epi == 1 else None
+    outs = []
+    for mask in ("0", "31"):
+        monkeypatch.setenv("PCY_GEMM_PERM", mask)
+        n0 = _dispatch(L.DISPATCH_GEMM_FP8)
+        outs.append(ctx.gemm_fp8(a8, sa, q8, sw, resid=r, epi=epi).cpu())
+        assert _dispatch(L.DISPATCH_GEMM_FP8) == n0 + 1
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+def test_esm_layer_row_order_and_v_path_bit_identical(monkeypatch):
+    """encoder level, one full-width ESM2-650M layer over ragged packed proteins (the only way to the fused-rotary epilogue): natural vs
+    permuted W row order, and the single-pass attention reading V token-major (ds_read_b64_tr_b16) vs from a transposed copy -- all
+    four combinations the same bits."""
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig, EsmEngine
+    kw = dict(d=1280, n_layers=2, n_heads=20, ffn=5120)
+    eng = EsmEngine(synth.esm_state_dict(**kw, device="cuda"), EsmConfig(**kw))
+    toks = synth.protein_tokens([1024, 300, 77, 65, 1, 640], seed=4)
+    monkeypatch.setenv("PCY_ESM_ATTN", "fast")
+    outs = {}
+    for mask in ("0", "7", "31"):
+        for vrow in ("0", "1"):
+            monkeypatch.setenv("PCY_GEMM_PERM", mask)
+            monkeypatch.setenv("PCY_FA_VROW", vrow)
+            outs[(mask, vrow)] = eng.hidden_states(toks).cpu()
+    keep = toks != 1
+    ref = outs[("0", "0")]
+    assert torch.isfinite(ref[keep].float()).all()
+    for key, o in outs.items():
+        assert torch.equal(o[keep].view(torch.int16), ref[keep].view(torch.int16)), key
+
+
+@pytest.mark.parametrize("lens", [[1026], [64, 1, 33, 700, 257, 1026, 63, 65, 128]])
+def test_attention_single_pass_v_token_major_bit_identical(ctx, monkeypatch, lens):
+    """op level: `attn_fast64_kernel<VROW>` (V tiles [keys][dh] in LDS, transposing reads) against the same kernel over a transposed
+    copy of V -- the same MFMA operands, so the same bits; V columns at a head offset inside a wider row (as in qkv)."""
+    H, dh = 3, 64
+    n = sum(lens)
+    q, k, v = rnd(n, H * dh, seed=1, std=0.35).cuda(), rnd(n, H * dh, seed=2).cuda(), rnd(n, H * dh, seed=3).cuda()
+    monkeypatch.setenv("PCY_ESM_ATTN", "fast")
+    outs = []
+    for vrow in ("0", "1"):
+        monkeypatch.setenv("PCY_FA_VROW", vrow)
+        outs.append(ctx.attention(q, k, v, lens, H, H, dh, False, 1.0).cpu())
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
