@@ -1343,6 +1343,8 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
         hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
       } else {
+        // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
+        // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
         hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
       }
