@@ -23,10 +23,10 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 
 // The ESM GELU chain (five bf16 tensors, pcy_common.h::gelu_esm_chain) is a FUNCTION bf16 -> bf16, so the fc1 epilogue looks
 // it up instead of evaluating ~45 VALU instructions per output (139 of the 591 us of that GEMM at M = 32832):
-// g_gelu_lut[s*3072 + (|bits| - (110 << 7))] for 2^-17 <= |x| < 2^7, filled once per device by the chain itself (bit-identical
-// by construction); values outside the table take the chain.  Once the mainloop has ended the table (12 KiB) is copied over the
-// dead tile buffers in LDS and gathered with ds_read_u16.
-constexpr int GELU_LUT_E0 = 110, GELU_LUT_HALF = 24 * 128, GELU_LUT_N = 2 * GELU_LUT_HALF;
+// g_gelu_lut[s*4096 + (|bits| - (102 << 7))] for 2^-25 <= |x| < 2^7 (32 exponents: 4096 entries = 8 KiB per sign), filled once per
+// device by the chain itself (bit-identical by construction); values outside the table take closed forms.  Once the mainloop has
+// ended the table is copied over the dead tile buffers in LDS and gathered with ds_read_u16.
+constexpr int GELU_LUT_E0 = 102, GELU_LUT_HALF = 32 * 128, GELU_LUT_N = 2 * GELU_LUT_HALF;
 __device__ uint16_t g_gelu_lut[GELU_LUT_N];
 __global__ void gelu_lut_build_kernel() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,16 +42,28 @@ __device__ __forceinline__ void gelu_lut_to_lds(char* lds) {
     reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(g_gelu_lut)[i];
   __syncthreads();
 }
+// SPARSE image (persistent 256 x 256 kernel): the positive half at `pos`, the negative half 64 KiB further, so that the entry of the
+// 16-bit pattern b sits at  pos - 2 (E0 << 7) + 2 b  for either sign -- the gather address is the pattern shifted left by one.
+constexpr int GELU_SPARSE_NEG = 32768;   // elements between the halves
+template <int NT>
+__device__ __forceinline__ void gelu_lut_to_lds_sparse(char* pos) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < GELU_LUT_HALF * 2 / 16; i += NT) {
+    reinterpret_cast<uint4*>(pos)[i] = reinterpret_cast<const uint4*>(g_gelu_lut)[i];
+    reinterpret_cast<uint4*>(pos + GELU_SPARSE_NEG * 2)[i] = reinterpret_cast<const uint4*>(g_gelu_lut + GELU_LUT_HALF)[i];
+  }
+  __syncthreads();
+}
 // Branch-free (a divergent fall-back to the chain at each of the 128 unrolled call sites made hipcc keep the epilogue as a
 // loop and move the accumulators to scratch: 591 -> 2593 us).  Outside the table the chain has closed forms:
 //   |x| <  2^-17: erf term rounds away, 1 + t3 = 1          -> bf16(x * 0.5)
 //   |x| >= 2^7  : erf = +-1 -> t4 = 2 or 0                  -> x   or   bf16(x * 0.5) * 0  (= -0, NaN for -inf, as the chain)
-__device__ __forceinline__ float gelu_esm_lut(float v /* bf16-valued */, const uint16_t* lut) {
+__device__ __forceinline__ float gelu_esm_lut(float v /* bf16-valued */, const uint16_t* lut, int neg_off = GELU_LUT_HALF) {
   const uint32_t b = __float_as_uint(v) >> 16;
   const uint32_t mag = b & 0x7fffu;
   const uint32_t idx = mag - (uint32_t)(GELU_LUT_E0 << 7);
   const bool in = idx < (uint32_t)GELU_LUT_HALF;
-  const float t = __uint_as_float((uint32_t)lut[(in ? idx : 0u) + ((b >> 15) ? GELU_LUT_HALF : 0)] << 16);
+  const float t = __uint_as_float((uint32_t)lut[(in ? idx : 0u) + ((b >> 15) ? neg_off : 0)] << 16);
   const float half = rbf(v * 0.5f);
   const float big = (b >> 15) ? half * 0.0f : v;
   const float out = mag < (uint32_t)(GELU_LUT_E0 << 7) ? half : big;
@@ -354,7 +366,8 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 }
 template <int EPI, int WTN, int WTM, int JBR = 2>
 __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int mw, int nw, int fr, int fq,
-                                                   const uint16_t* gelu_lut = nullptr, const float* sx = nullptr) {
+                                                   const uint16_t* gelu_lut = nullptr, const float* sx = nullptr,
+                                                   int gelu_neg_off = GELU_LUT_HALF) {
   // sx != nullptr (fp8 kernels): the accumulators are still raw; token j's scale sx[j] and the feature scales a.sw are applied
   // here, (acc * sx) * sw as in oracle/fp8_ref.py, feature scales fetched per tile pair (all 32 of a wave tile up front spill)
   constexpr int NP = WTN / 2;
@@ -371,9 +384,10 @@ __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (
     for (int hg = 0; hg < NH; ++hg) {
       const int n1 = nw + hg * 64 + fq * 8;
       const int nc = (a.bias && n1 + 40 <= a.N) ? n1 : 0;
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      unpack8(a.bias ? *reinterpret_cast<const uint4*>(a.bias + nc) : z, b1[hg]);
-      unpack8(a.bias ? *reinterpret_cast<const uint4*>(a.bias + nc + 32) : z, b2[hg]);
+      uint4 u1 = make_uint4(0, 0, 0, 0), u2 = u1;
+      if (a.bias) { u1 = *reinterpret_cast<const uint4*>(a.bias + nc); u2 = *reinterpret_cast<const uint4*>(a.bias + nc + 32); }
+      unpack8(u1, b1[hg]);
+      unpack8(u2, b2[hg]);
     }
     int pj[WTM];
 #pragma unroll
@@ -517,7 +531,7 @@ __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (
         }
         if (EPI == EPI_GELU_ESM) {
 #pragma unroll
-          for (int x = 0; x < 8; ++x) v[x] = gelu_lut ? gelu_esm_lut(v[x], gelu_lut) : gelu_esm_chain(v[x]);
+          for (int x = 0; x < 8; ++x) v[x] = gelu_lut ? gelu_esm_lut(v[x], gelu_lut, gelu_neg_off) : gelu_esm_chain(v[x]);
         }
         if (vec_ok) {
           *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = pack8(v);
@@ -529,6 +543,55 @@ __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (
       }
     }
   }
+}
+
+// ESM-GELU epilogue, fast form (persistent kernel, W rows in wperm_row order, sparse table image): bias add + bf16 rounding as packed
+// pairs, then per output  address = pattern << 1  and one ds_read_u16 -- no per-element range test, no closed forms: the lane keeps
+// the packed minimum / maximum of the magnitudes it looked up and the wave votes once at the end; `false` = some value of this wave's
+// tile lay outside 2^-25 <= |x| < 2^7 (or was not finite) and the caller redoes the tile with the select form (same stores again).
+// An out-of-range pattern reads a stale tile byte or beyond the allocation (LDS returns 0 there): discarded either way.
+// ~6 VALU + 1 gather per output instead of ~22 + 1.
+typedef unsigned short gelu_u16x2 __attribute__((ext_vector_type(2)));
+template <int WTN, int WTM>
+__device__ __forceinline__ bool gemm_epilogue_perm_gelu_fast(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int mw, int nw, int fr, int fq,
+                                                             const char* lut_pos) {
+  constexpr int NP = WTN / 2;
+  const char* lut0 = lut_pos - 2 * (GELU_LUT_E0 << 7);   // entry of pattern b at lut0 + 2 b
+  float bias[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int n = nw + p * 32 + fq * 8;
+    uint4 bb = make_uint4(0, 0, 0, 0);   // (`cond ? *p : zero` becomes a load through a selected POINTER, the zero in scratch)
+    if (a.bias && n + 8 <= a.N) bb = *reinterpret_cast<const uint4*>(a.bias + n);
+    unpack8(bb, bias[p]);
+  }
+  gelu_u16x2 mn = {0xffff, 0xffff}, mx = {0, 0};
+#pragma unroll
+  for (int j = 0; j < WTM; ++j) {
+    const int m = mw + j * 16 + fr;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int n = nw + p * 32 + fq * 8;
+      if (n + 8 > a.N) continue;
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = q >> 1, r = (q & 1) * 2;
+        const uint32_t w = pack_bf(acc[2 * p + t][j][r] + bias[p][t * 4 + r], acc[2 * p + t][j][r + 1] + bias[p][t * 4 + r + 1]);
+        const gelu_u16x2 mag = __builtin_bit_cast(gelu_u16x2, w & 0x7fff7fffu);
+        mn = __builtin_elementwise_min(mn, mag);
+        mx = __builtin_elementwise_max(mx, mag);
+        const uint32_t lo = *reinterpret_cast<const uint16_t*>(lut0 + ((w & 0xffffu) << 1));
+        const uint32_t hi = *reinterpret_cast<const uint16_t*>(lut0 + ((w >> 15) & 0x1fffeu));
+        o[q] = lo | (hi << 16);
+      }
+      *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  constexpr unsigned LO = GELU_LUT_E0 << 7, HI = (GELU_LUT_E0 << 7) + GELU_LUT_HALF;
+  const bool ok = mn[0] >= LO && mn[1] >= LO && mx[0] < HI && mx[1] < HI;
+  return __all(ok);
 }
 
 // SwiGLU epilogue over W rows in wperm_row_swiglu order: nwp = first PACKED row of the wave's tile (or of its half), the lane's
@@ -1196,9 +1259,22 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
       else gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
     }
   } else if constexpr (EPI == EPI_GELU_ESM) {
-    gelu_lut_to_lds<512>(smem + TILE_A + TILE_W);
-    if constexpr (PERM) gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
-    else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
+    if constexpr (PERM) {
+      // sparse table image: positive half over the dead stage buffer 1, negative half 64 KiB further (the launcher allocates 8 KiB
+      // behind the two stage buffers); the fast form where the store can be whole 16-byte pieces, redone with the select form by
+      // the (rare) waves that met a value outside the table
+      char* lut_pos = smem + TILE_A + TILE_W;
+      gelu_lut_to_lds_sparse<512>(lut_pos);
+      const bool vec16 = (a.ldc % 8 == 0) && (a.N % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                         (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && !a.gelu_select;
+      bool done = false;
+      if (vec16) done = gemm_epilogue_perm_gelu_fast<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, lut_pos);
+      if (!done)
+        gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(lut_pos), nullptr, GELU_SPARSE_NEG);
+    } else {
+      gelu_lut_to_lds<512>(smem + TILE_A + TILE_W);
+      gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
+    }
   } else {
     if constexpr (!PERM) gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
     else if constexpr (EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
@@ -1335,13 +1411,16 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         return;
       }
       if constexpr (EPI == EPI_GELU_ESM) {
+        constexpr int smem_g = smem + GELU_LUT_HALF * 2;   // the negative half of the sparse table image ends 8 KiB behind the stage buffers
         static bool configured_p = false;
         if (!configured_p) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_g);
           configured_p = true;
         }
+        const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (A/B, tests)
+        b.gelu_select = gs && atoi(gs) == 1;
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
-        hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
+        hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem_g, s, b);
       } else {
         // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
         // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)

@@ -640,3 +640,36 @@ def test_attention_single_pass_v_token_major_bit_identical(ctx, monkeypatch, len
         outs.append(ctx.attention(q, k, v, lens, H, H, dh, False, 1.0).cpu())
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("select", ["0", "1"])
+def test_gemm_esm_gelu_fast_table_epilogue_every_in_range_value(ctx, monkeypatch, select):
+    """The persistent 256 x 256 ESM-GELU kernel looks a wave tile up WITHOUT per-element range tests when every value of the tile lies
+    inside the table (2^-25 <= |x| < 2^7; pattern << 1 is the gather address of a sparse table image) and redoes the tile with the
+    select form otherwise (test_gemm_esm_gelu_epilogue_every_bf16_value feeds every pattern: always the select form).  Here every one of
+    the 2 x 4096 in-range patterns, only those, through the kernel -- all waves take the fast form (PCY_GELU_SELECT=1: none does) --
+    against the reference's op-by-op bf16 chain, bit for bit; a second matrix with ONE out-of-range value per 64 x 128 wave tile."""
+    import math
+    from procyon_amd import _lib as L
+    mag = torch.arange(102 << 7, (102 + 32) << 7, dtype=torch.int32)
+    bits = torch.cat([mag, mag | 0x8000]).to(torch.int16)            # 8192 patterns
+    vals = bits.view(BF).repeat(16)                                    # 131072 values
+    W = vals.view(2048, 64).contiguous()                               # out[m][n] = W[n][m % 64]
+    M = 2048
+    A = torch.zeros(M, 64, dtype=BF)
+    A[torch.arange(M), torch.arange(M) % 64] = 1.0
+    monkeypatch.setenv("PCY_GELU_SELECT", select)
+    n0 = _dispatch(L.DISPATCH_GEMM_BIG_PERSIST)
+    out = ctx.gemm(A.cuda(), W.cuda(), torch.zeros(2048, dtype=BF).cuda(), None, 3).cpu()
+    assert _dispatch(L.DISPATCH_GEMM_BIG_PERSIST) == n0 + 1
+    x = W.t().contiguous()[torch.arange(M) % 64]
+    ref = x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # one tiny / one huge value somewhere in every wave tile: those waves fall back, the result is the same function
+    W2 = W.clone()
+    W2[::128, 3] = 1e-9
+    W2[64::128, 5] = -300.0
+    out2 = ctx.gemm(A.cuda(), W2.cuda(), torch.zeros(2048, dtype=BF).cuda(), None, 3).cpu()
+    x2 = W2.t().contiguous()[torch.arange(M) % 64]
+    ref2 = x2 * 0.5 * (1.0 + torch.erf(x2 / math.sqrt(2.0)))
+    assert torch.equal(out2.view(torch.int16), ref2.view(torch.int16))
