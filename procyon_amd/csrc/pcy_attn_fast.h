@@ -150,9 +150,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     vp[i] = VROW ? vglob + (size_t)vrow[i] * a.ldv + vchunk[i] : vglob + (size_t)row * a.vt_total + schunk[i];
   }
   const size_t ktile_stride = (size_t)KT * a.ldk, vtile_stride = VROW ? (size_t)KT * a.ldv : (size_t)KT;
+  // VROW form: the pieces as buffer loads -- resources based at the sequence's first K / V row of this head (SGPRs), the lane's byte
+  // offset inside a tile (32 bits, constant), the tile as the instruction's scalar offset; the wave index in an SGPR so that the LDS
+  // destination (M0) is scalar arithmetic.  (The Vt form keeps global_load_lds.)
+  const int wave_s = VROW ? __builtin_amdgcn_readfirstlane(wave) : wave;
+  __amdgpu_buffer_rsrc_t krs, vrs;
+  int kvo[2], vvo[2];
+  if constexpr (VROW) {
+    krs = __builtin_amdgcn_make_buffer_rsrc((void*)kglob, 0, 0x7fffffff, 0x00020000);
+    vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vglob, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { kvo[i] = (srow[i] * a.ldk + schunk[i]) * 2; vvo[i] = (vrow[i] * a.ldv + vchunk[i]) * 2; }
+  }
   auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
     if (ABL & 64) return;
     const bool clamp = (kt + 1) * KT > len;
+    if constexpr (VROW) {
+      if (!clamp) {
+        const int ks_off = kt * KT * a.ldk * 2, vs_off = kt * KT * a.ldv * 2;   // (a sequence's K / V rows span < 2 GiB)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr_t)(buf + (i * 4 + wave_s) * 1024), 16, kvo[i], ks_off, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr_t)(buf + TILE + (i * 4 + wave_s) * 1024), 16, vvo[i], vs_off, 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bf16_t* ks = kp[i] + kt * ktile_stride;
@@ -165,8 +188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
           vs = vglob + (size_t)vk * a.ldv + vchunk[i];
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lds_ptr_t)(buf + (i * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lds_ptr_t)(buf + TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ks, (lds_ptr_t)(buf + (i * 4 + wave_s) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lds_ptr_t)(buf + TILE + (i * 4 + wave_s) * 1024), 16, 0, 0);
     }
   };
   // A-operand row (lane & 31) of S^T  ->  key of the 32-key block

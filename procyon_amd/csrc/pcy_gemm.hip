@@ -100,10 +100,27 @@ __device__ __forceinline__ int wperm_row_swiglu(int i, int q) {
 template <int EPI>
 __device__ __forceinline__ int wperm(int i, int q) { return EPI == EPI_SWIGLU ? wperm_row_swiglu(i, q) : wperm_row(i, q); }
 
-template <int BK, int ROWS = 128, int NW = 4, int SW = 0>
+// STG = 1: the pieces go out as `buffer_load_dwordx4 ... offen lds` -- a buffer resource based at the tile's first row (wave-uniform,
+// SGPRs), the lane's byte offset inside the tile (32 bits, the same for every k-step: computed once per tile) and the k offset as
+// the instruction's SCALAR offset.  The global_load_lds form (STG = 0) carries a 64-bit address per lane and piece, which the k-loop
+// re-forms with a v_lshl_add_u64 per piece; with the wave index read into an SGPR (readfirstlane) the LDS destination (M0) is
+// scalar arithmetic as well instead of a VGPR add + v_readfirstlane per piece.
+template <int BK, int ROWS = 128, int NW = 4, int SW = 0, int STG = 0>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = ROWS / RPI;
+  if constexpr (STG == 1) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + (size_t)row0 * ld), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NINST / NW; ++i) {
+      const int inst = wave * (NINST / NW) + i;
+      const int r = inst * RPI + lane / CPR;
+      const int c = (lane % CPR) ^ swz<BK, SW>(r);
+      const int rl = row0 + r < nrows_valid ? r : nrows_valid - 1 - row0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_tile + inst * 1024), 16, (rl * ld + c * 8) * 2, k0 * 2, 0, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NINST / NW; ++i) {
     const int inst = wave * (NINST / NW) + i;
@@ -930,7 +947,7 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
 // SPLITK: grid = tiles x a.splits, workgroup (tile, split) accumulates k in [split * K / splits, +K / splits) and stores its fp32
 // partial tile to a.splitk_ws[split] (finished by gemm_splitk_epilogue / the finish + norm kernel, as for gemm_splitk_kernel: same
 // k order per element, same bits); EPI is then ignored.
-template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false, bool NOPERM = false>
+template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false, bool NOPERM = false, int STG = 0>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
   extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
   char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = STG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = SPLITK ? gridDim.x / a.splits : gridDim.x, bid = SPLITK ? blockIdx.x % nwg : blockIdx.x;
   const int split = SPLITK ? blockIdx.x / nwg : 0;
@@ -959,8 +976,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   const int nk = F8 ? a.K / 128 : (SPLITK ? a.K / a.splits / BK : a.K / BK);
   const int kbeg = SPLITK ? split * (a.K / a.splits) : 0;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
-  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
-  stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
+  stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
+  stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -980,8 +997,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 #endif
     if (((F8 && !PCY_F8_VARIANT) || (!F8 && !(PCY_BIG_VARIANT & 1))) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
     if constexpr (F8) {
       i32x8 xf[WTM];
@@ -991,7 +1008,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       // PCY_F8_VARIANT 1: the A stage behind the x fragment reads, the W stage after half of the MFMAs, priority raised
       // (measured no better than the plain order on the fp8 prefill: 1609-1615 vs 1619-1620 TFLOP/s; off)
       if (PCY_F8_VARIANT && kt + 1 < nk)
-        stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
+        stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
       if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
@@ -1001,7 +1018,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         if (PCY_F8_VARIANT && i == WTN / 2 - 1 && kt + 1 < nk) {
           __builtin_amdgcn_s_setprio(0);
-          stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
+          stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
           __builtin_amdgcn_s_setprio(1);
         }
       }
@@ -1016,8 +1033,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
         for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
         if ((PCY_BIG_VARIANT & 1) && !(PCY_BIG_VARIANT & 4) && kt + 1 < nk) {   // one operand's stage behind each kb's fragment reads
           char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
+          if (kb == 0) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+          else stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
         }
         if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1121,7 +1138,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
 // idles, once per tile round.  Out of phase, a CU's epilogue shares the memory system with 7/8 of the chip in its mainloop; the
 // queue makes the late starters take fewer tiles, so the stagger does not come back as a tail.  a.tile_ctr: 9 zeroed words
 // (8 XCD heads + an exit counter; the last workgroup to leave zeroes them again).
-template <int EPI, bool F8 = false, bool DQ = false, bool NOPERM = false>
+template <int EPI, bool F8 = false, bool DQ = false, bool NOPERM = false, int STG = 0>
 __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
@@ -1129,7 +1146,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
   extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
   char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = STG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // workgroup b computes tiles b, b + gridDim.x, ... (gridDim.x = min(tiles, CUs), a multiple of 8 or the whole grid, so b % 8
   // -- the XCD -- is the same for all of them and each XCD still walks one contiguous run of the rasterised tile order).  The
@@ -1163,8 +1180,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
   const int nk = F8 ? a.K / 128 : a.K / BK;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
-  stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
+  stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
   const int fr = lane & 15, fq = lane >> 4;
   for (int vb = blockIdx.x; DQ ? true : (PERSIST ? vb < ntiles : vb == (int)blockIdx.x); vb += gridDim.x) {
   if (DQ && threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);   // the NEXT tile: the answer is read after the mainloop's barriers
@@ -1180,8 +1197,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
     const char* Wcur = Acur + TILE_A;
     if ((F8 || !(PCY_BIG_VARIANT & 1)) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
     if constexpr (F8) {
       i32x8 xf[WTM];
@@ -1205,8 +1222,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
         for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
         if ((PCY_BIG_VARIANT & 1) && kt + 1 < nk) {
           char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-          if (kb == 0) stage_tile<BK, TBM, NW>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW, SWW>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+          if (kb == 0) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+          else stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
         }
         if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1227,8 +1244,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
   const bool have_next = DQ ? nj < run_len : (PERSIST && nvb < ntiles);
   if (have_next) {
     tile_origin<TBM, TBN>(a, DQ ? run_start + nj : tile_of(nvb), nm0, nn0);
-    stage_tile<BK, TBM, NW>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
-    stage_tile<BK, TBN, NW, SWW>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
+    stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
+    stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
   }
   if constexpr (F8) {
     // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
@@ -1309,6 +1326,10 @@ inline bool gemm_noperm(int epi, bool f8) {
   const int bit = epi == EPI_STORE ? 1 : epi == EPI_RESID ? 2 : epi == EPI_GELU_ESM ? 4 : epi == EPI_SWIGLU ? 8 : 0;
   return !(mask & bit) || (f8 && !(mask & 16));
 }
+// LDS-DMA pieces of the bf16 256 x 256 kernels as buffer loads with a scalar k offset (stage_tile, STG = 1); PCY_GEMM_STG=0 (read per
+// call) = the global_load_lds form.  Interleaved A/B: ESM2-650M batch 41.2 -> 40.6 ms, Llama-3-8B prefill 64 x 450 tokens 1048 -> 1055
+// TFLOP/s, one 512-token prompt unchanged; 16-40 VGPRs fewer.
+inline bool gemm_stg() { const char* e = getenv("PCY_GEMM_STG"); return !(e && atoi(e) == 0); }
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   constexpr int smem = 2 * (256 + 256) * 64 * 2;
@@ -1420,11 +1441,29 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (A/B, tests)
         b.gelu_select = gs && atoi(gs) == 1;
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
+        if (gemm_stg()) {
+          static bool configured_s = false;
+          if (!configured_s) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_g);
+            configured_s = true;
+          }
+          hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, false, 1>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem_g, s, b);
+          return;
+        }
         hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem_g, s, b);
       } else {
         // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
         // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
+        if (gemm_stg()) {
+          static bool configured_s = false;
+          if (!configured_s) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            configured_s = true;
+          }
+          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, false, 1>), dim3(tiles_big), dim3(512), smem, s, b);
+          return;
+        }
         hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
       }
     }
