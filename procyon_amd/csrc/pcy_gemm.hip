@@ -657,10 +657,13 @@ __device__ __forceinline__ void gemm_epilogue_perm_swiglu(const PcyGemmArgs& a, 
   }
 }
 
+#ifndef PCY_STG_SMALL
+#define PCY_STG_SMALL 1   // the 128 x 128 / 64 x 64 / K-split kernels stage with buffer loads too (stage_tile, STG = 1)
+#endif
 template <int EPI, int BK>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];  // [buf][A|W][128*BK] bf16: 64 KiB (BK=64) / 32 KiB (BK=32)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
   // contiguous run of tiles that share A/W panels in its private L2 (bijective remap).
@@ -680,8 +683,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
   const int nk = a.K / BK;
   constexpr int TILE_B = BM * BK * 2;  // 16 KiB; buffer b: A at b*2*TILE_B, W right after it
 
-  stage_tile<BK>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK>(a.W, a.K, n0, a.N, 0, smem + TILE_B, wave, lane);
+  stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, 0, smem + TILE_B, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -695,8 +698,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     // ESM wo 638 vs 641, Llama qkv T512 482 vs 530 TFLOP/s)
     if ((!PCY_G128_VARIANT || BK != 64) && kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
-      stage_tile<BK>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
+      stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
     }
 #pragma unroll
     for (int kb = 0; kb < BK / 32; ++kb) {
@@ -707,8 +710,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
       for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
       if (PCY_G128_VARIANT && BK == 64 && kt + 1 < nk) {   // as in gemm_kernel_big: half of the next stage behind each kb's reads
         char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
-        if (kb == 0) stage_tile<BK>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-        else stage_tile<BK>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
+        if (kb == 0) stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+        else stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
       }
       if (PCY_G128_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_small(PcyGemmArgs a)
   constexpr int BK = 64, TM = 64, TN = 64, WTM = 2, WTN = 2;
   constexpr int TILE_A = TM * BK * 2, TILE_W = TN * BK * 2;   // 8 KiB each
   __shared__ __attribute__((aligned(1024))) char smem[2 * (TILE_A + TILE_W)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
@@ -752,8 +755,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_small(PcyGemmArgs a)
 #pragma unroll
     for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nk = a.K / BK;
-  stage_tile<BK, TM, 4>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TN, 4>(a.W, a.K, n0, a.N, 0, smem + TILE_A, wave, lane);
+  stage_tile<BK, TM, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, 0, smem, wave, lane);
+  stage_tile<BK, TN, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, 0, smem + TILE_A, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -762,8 +765,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_small(PcyGemmArgs a)
     const char* Wcur = Acur + TILE_A;
     if (kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TM, 4>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TN, 4>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      stage_tile<BK, TM, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, TN, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
     }
 #pragma unroll
     for (int kb = 0; kb < BK / 32; ++kb) {
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel_small(PcyGemmArgs a)
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(PcyGemmArgs a, int splits, int k_per_split) {
   constexpr int BK = 64;
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * BM * BK * 2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles = gridDim.x / splits;
   const int split = blockIdx.x / tiles, bid = blockIdx.x % tiles;
@@ -812,8 +815,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(PcyGemmArgs a
   const int kbeg = split * k_per_split;
   const int nk = k_per_split / BK;
   constexpr int TILE_B = BM * BK * 2;
-  stage_tile<BK>(a.A, a.lda, m0, a.M, kbeg, smem, wave, lane);
-  stage_tile<BK>(a.W, a.K, n0, a.N, kbeg, smem + TILE_B, wave, lane);
+  stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, kbeg, smem, wave, lane);
+  stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, kbeg, smem + TILE_B, wave, lane);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -822,8 +825,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_splitk_kernel(PcyGemmArgs a
     const char* Wcur = Acur + TILE_B;
     if (kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
-      stage_tile<BK>(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK>(a.W, a.K, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_B, wave, lane);
+      stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+      stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_B, wave, lane);
     }
 #pragma unroll
     for (int kb = 0; kb < BK / 32; ++kb) {
@@ -1350,6 +1353,15 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
     if (!configured_n) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       configured_n = true;
+    }
+    if (gemm_stg()) {
+      static bool configured_ns = false;
+      if (!configured_ns) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured_ns = true;
+      }
+      hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, false, true, 1>), dim3(tiles_big), dim3(512), smem, s, b);
+      return;
     }
     hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, false, true>), dim3(tiles_big), dim3(512), smem, s, b);
     return;
