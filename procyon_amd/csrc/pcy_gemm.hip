@@ -391,7 +391,9 @@ __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (
   const bool vec_ok = (a.ldc % 8 == 0) && (a.N % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
                       (a.resid == nullptr || (a.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(a.resid) & 15) == 0)) &&
                       (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
-  if constexpr (EPI == EPI_STORE) if (a.rope_cos != nullptr) {
+  // (a wave tile that lies entirely behind the rotated columns -- the V third of a qkv projection -- takes the plain path below: no
+  // position / table loads; rot = false gives the same bits)
+  if constexpr (EPI == EPI_STORE) if (a.rope_cos != nullptr && (nw < a.rope_ncols || a.rope_noskip)) {
     // fused rotary (head_dim 64; callers guarantee N % 64 == 0 and 16-byte aligned rows): a head = 4 tiles, the lane holds
     // e = fq*8 + [0, 8) in tiles (4hg, 4hg+1) and the partners e + 32 in tiles (4hg+2, 4hg+3).  Loads first: bias, positions,
     // then per token four 16-byte pieces of its cos / sin rows (shared by every head).
@@ -1504,6 +1506,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (a0.M <= 0 || a0.N <= 0) return;
   PcyGemmArgs a = a0;
+  { const char* e = getenv("PCY_ROPE_VSKIP"); a.rope_noskip = e && atoi(e) == 0; }   // (A/B: 0 = table loads for the V tiles too)
   const int tiles_n = (a.N + BN - 1) / BN;
   const long panel = (long)BN * a.K * 2;
   long gn = (5L << 19) / panel;           // 2.5 MiB of W panels per group

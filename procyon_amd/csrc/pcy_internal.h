@@ -104,6 +104,7 @@ struct PcyGemmArgs {
   unsigned* tile_ctr;
   int wide_epi;         // set by the launcher: the 256 x 256 kernel's plain / residual epilogue goes through LDS (whole-row stores)
   int splits;           // set by the launcher (split-K forms): number of K ranges, partial sums in splitk_ws [splits][M][N]
+  int rope_noskip;      // set by the launcher (PCY_ROPE_VSKIP=0): the fused-rotary epilogue loads its tables for un-rotated wave tiles too
   int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the persistent ESM-GELU kernel skips the fast table epilogue
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
