@@ -109,7 +109,7 @@ template <int BK, int ROWS = 128, int NW = 4, int SW = 0, int STG = 0>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = ROWS / RPI;
-  if constexpr (STG == 1) {
+  if constexpr (STG >= 1) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g + (size_t)row0 * ld), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NINST / NW; ++i) {
@@ -983,8 +983,75 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
   stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
   stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
+  if constexpr (STG == 2 && !F8) {
+    // Software-pipelined k-loop: the fragments of a 32-k sub-step are read from LDS while the MFMAs of the sub-step BEFORE it run --
+    // the row of W fragments i is reloaded (for the next sub-step) as soon as its four MFMAs are issued, the four x fragments are
+    // double buffered (+16 VGPRs) -- so no sub-step starts with every wave of the CU waiting for its first ds_read_b128 (the
+    // lock-step loop: all eight waves issue 12 reads each right behind the barrier while the matrix pipes idle).  One barrier per
+    // k-step as before, placed between the two sub-steps: behind it stage kt+1 has landed (read by the second sub-step's prefetch)
+    // and every wave is done reading stage kt's buffer, into which the DMA of stage kt+2 then goes.
+    if (nk > 1) {
+      stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + BK, smem + TILE_A + TILE_W, wave, lane);
+      stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + BK, smem + TILE_A + TILE_W + TILE_A, wave, lane);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 (this wave's first eight pieces) has landed, stage 1 may be in flight
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+    bf16x8 xa[WTM], xb[WTM], wf[WTN];
+    auto xrow = [&](int j) { return wm * WTM * 16 + j * 16 + fr; };
+    auto wrow = [&](int i) { return wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr); };
+#pragma unroll
+    for (int j = 0; j < WTM; ++j) xa[j] = lds_frag<BK>(smem, xrow(j), fq);
+#pragma unroll
+    for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(smem + TILE_A, wrow(i), fq);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* Acur = smem + cur * (TILE_A + TILE_W);
+      const char* Wcur = Acur + TILE_A;
+      // (the last k-step prefetches from its own buffer: unused, but the loop body stays free of branches)
+      const char* Anxt = smem + (kt + 1 < nk ? cur ^ 1 : cur) * (TILE_A + TILE_W);
+      const char* Wnxt = Anxt + TILE_A;
+      // sub-step 0: MFMAs on (xa, wf); prefetch sub-step 1 of this stage into (xb, wf)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) {
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xa[j], acc[i][j], 0, 0, 0);
+        wf[i] = lds_frag<BK, SWW>(Wcur, wrow(i), 4 + fq);
+        if (i < WTM) xb[i] = lds_frag<BK>(Acur, xrow(i), 4 + fq);
+      }
+      // (left alone hipcc sinks all twelve reads behind the 29th MFMA: pin 4 MFMAs : 2 or 1 reads)
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#pragma unroll
+      for (int i = WTM; i < WTN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();   // (lgkmcnt(0): this wave's reads of stage kt are complete; vmcnt(0): its pieces of stage kt+1 have landed)
+      // (the eight pieces in front of the sub-step; spreading them over the MFMA rows with sched_group_barrier(0x020) made hipcc
+      // cluster them -- each needs its own M0 -- and undo the MFMA : read interleave below)
+      if (kt + 2 < nk) {
+        stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
+        stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
+      }
+      // sub-step 1: MFMAs on (xb, wf); prefetch sub-step 0 of stage kt+1 into (xa, wf)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < WTN; ++i) {
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xb[j], acc[i][j], 0, 0, 0);
+        wf[i] = lds_frag<BK, SWW>(Wnxt, wrow(i), fq);
+        if (i < WTM) xa[i] = lds_frag<BK>(Anxt, xrow(i), fq);
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#pragma unroll
+      for (int i = WTM; i < WTN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const char* Acur = smem + cur * (TILE_A + TILE_W);
@@ -1060,6 +1127,7 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     }
     __syncthreads();
   }
+  }   // (lock-step loop)
   if constexpr (SPLITK) {   // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
     float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
 #pragma unroll
@@ -1335,6 +1403,15 @@ inline bool gemm_noperm(int epi, bool f8) {
 // call) = the global_load_lds form.  Interleaved A/B: ESM2-650M batch 41.2 -> 40.6 ms, Llama-3-8B prefill 64 x 450 tokens 1048 -> 1055
 // TFLOP/s, one 512-token prompt unchanged; 16-40 VGPRs fewer.
 inline bool gemm_stg() { const char* e = getenv("PCY_GEMM_STG"); return !(e && atoi(e) == 0); }
+// The software-pipelined k-loop of gemm_kernel_big (STG = 2; STORE / RESID / SwiGLU epilogues) where K is long: interleaved A/B on the
+// Llama-3-8B prefill of 64 x 450 tokens (K = 4096 / 14336) 1059 -> 1092 TFLOP/s; at K = 1280 its two-stage prologue costs what the loop
+// gains (ESM2-650M batch 40.7 vs 40.6 ms; stand-alone qkv 214 -> 229 us, fc1 shape 287 -> 300 us).  PCY_GEMM_STG=2 forces it for every
+// K, =1 / =0 switch it off.
+inline bool gemm_pipe(int K) {
+  const char* e = getenv("PCY_GEMM_STG");
+  if (e) return atoi(e) == 2;
+  return K >= 4096;
+}
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   constexpr int smem = 2 * (256 + 256) * 64 * 2;
@@ -1469,6 +1546,15 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
         // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
+        if (gemm_pipe(a.K)) {
+          static bool configured_p2 = false;
+          if (!configured_p2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            configured_p2 = true;
+          }
+          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, false, 2>), dim3(tiles_big), dim3(512), smem, s, b);
+          return;
+        }
         if (gemm_stg()) {
           static bool configured_s = false;
           if (!configured_s) {
