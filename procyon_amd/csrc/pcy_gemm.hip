@@ -1420,6 +1420,7 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   const int tn = (a.N + 255) / 256;
   long gnb = (5L << 19) / ((long)256 * a.K);
   if (gnb < 2) gnb = 2;
+  { const char* ge = getenv("PCY_GEMM_GN"); if (ge && atoi(ge) > 0) gnb = atoi(ge); }
   b.gn = (int)(gnb > tn ? tn : gnb);
   static bool configured = false;
   if (!configured) {
@@ -1476,6 +1477,16 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
     const int tn = (a.N + 255) / 256;
     long gnb = (5L << 19) / ((long)256 * a.K * 2);
     if (gnb < 2) gnb = 2;
+    // The 32 workgroups an XCD runs at a time walk K together, so what its L2 has to hold is the current k-window of their panels, not
+    // whole panels: 8 row tiles x 4 column tiles share 12 panels where 16 x 2 share 18.  Measured (interleaved, PCY_GEMM_GN): ESM2-650M
+    // batch 40.2 -> 39.7 ms with groups of 5 (N = 1280: the whole row) instead of 4 / 2; Llama-3-8B prefill 64 x 450 tokens 375.8 ->
+    // 372.3 ms with 4 instead of 2 (5, 6: neutral; 16: -4 %); one 512-token prompt (two row tiles) is best left at 2.
+    if (a.M >= 2048) {
+      long want = a.K <= 2560 ? 5 : 4;
+      if (tn <= 6) want = tn;
+      if (gnb < want) gnb = want;
+    }
+    { const char* ge = getenv("PCY_GEMM_GN"); if (ge && atoi(ge) > 0) gnb = atoi(ge); }   // (A/B: column tiles per rasterisation group)
     b.gn = (int)(gnb > tn ? tn : gnb);
     {
       static bool configured = false;
