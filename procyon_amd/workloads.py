@@ -142,15 +142,19 @@ def run_config5(model, pairs=256, chunk=64, fp8=True):
             eng.quantize_fp8()
         score_pairs(model, chunk, chunk)
         _sync()
-        t0 = time.perf_counter()
-        y, lg = score_pairs(model, pairs, chunk)
-        _sync()
-        out[mode] = (y.cpu(), time.perf_counter() - t0, lg.cpu())
+        best = None
+        for _ in range(2):          # two passes, the faster one is reported (a shared box now and then loses a third of a pass)
+            t0 = time.perf_counter()
+            y, lg = score_pairs(model, pairs, chunk)
+            _sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[mode] = (y.cpu(), best, lg.cpu())
     if fp8:
         eng.set_fp8(False)
     per_tok = 2 * cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d + 3 * cfg.d * cfg.ffn)
     flop = pairs * (per_tok * T + 4 * cfg.n_layers * cfg.n_heads * cfg.head_dim * T * T / 2)
-    res = {"pairs": pairs, "slots_per_prompt": 6, "prompt_tokens": T, "bf16_pairs_per_s": round(pairs / out["bf16"][1], 1),
+    res = {"pairs": pairs, "slots_per_prompt": 6, "prompt_tokens": T, "timing": "best of 2 passes", "bf16_pairs_per_s": round(pairs / out["bf16"][1], 1),
            "bf16_prefill_TFLOPs": round(flop / out["bf16"][1] / 1e12, 1), "bf16_mfma_frac_of_2.5PF": round(flop / out["bf16"][1] / 2.5e15, 3)}
     if fp8:
         y16, y8, l16, l8 = out["bf16"][0], out["fp8"][0], out["bf16"][2], out["fp8"][2]
