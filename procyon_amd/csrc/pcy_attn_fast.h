@@ -41,6 +41,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // <= 256: harmless for bf16's 8-bit exponent and the fp32 sums; m cancels in O / l).  After the first blocks no wave takes that
 // branch on ordinary data; tests/test_gpu_round3.py forces it with spiked keys.
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// (inline asm: hipcc's hazard recognizer does not see that it READS MFMA results.  The kernel's schedule always has another group's
+// MFMA chain between a Q.K^T and the softmax of its scores; an experiment that ran ONE query group per wave put the softmax right behind
+// its own Q.K^T and read half-written accumulators -- bits that changed from launch to launch.  Keep that distance.)
 __device__ __forceinline__ float fa_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 template <bool MASKED, int ABL = 0>
 __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[2], int key0, int half, int len) {
