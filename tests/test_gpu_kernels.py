@@ -390,11 +390,12 @@ def test_gemm_esm_gelu_epilogue_every_bf16_value(ctx, M):
 
 
 @pytest.mark.parametrize("epi", [0, 1, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2100, 1536, 2560), (2304, 5120, 1280)])
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (2100, 1536, 2560), (2304, 5120, 1280), (2100, 1536, 4096), (2048, 1280, 4160)])
 def test_gemm_256x256_kernels_vs_oracle(ctx, M, N, K, epi):
     """The 256x256 kernels -- gemm_kernel_big<STORE | RESID | SWIGLU> and gemm_kernel_big_persist<GELU_ESM>: the ESM retrieval leg
     and every batched prefill GEMM -- directly against the oracle's Linear (+ residual / ESM GELU / SwiGLU), with the dispatch
-    asserted (M >= 2048, N >= 1280; M = 2100 leaves a ragged last row tile)."""
+    asserted (M >= 2048, N >= 1280; M = 2100 leaves a ragged last row tile; K >= 4096 takes the software-pipelined k-loop, 4160 = an odd
+    number of k-steps)."""
     from procyon_amd import _lib as L
     from procyon_amd.engine import interleave_gate_up
     A, W, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, std=0.05), rnd(N, seed=3, std=0.1), rnd(M, N, seed=4)
