@@ -255,8 +255,8 @@ def main():
     for _ in range(2):   # two passes, the faster one is reported (a shared box now and then loses a third of a pass: 40 -> 55 ms per batch)
         barrier(); t0 = time.perf_counter()
         allz = embed_sharded(model, tok_fn, nprot, batch_size=rb)
-        barrier(); dt = time.perf_counter() - t0
-        rt = dt if rt is None else min(rt, dt)
+        barrier(); dt_r = time.perf_counter() - t0
+        rt = dt_r if rt is None else min(rt, dt_r)
     assert allz.shape[0] == nprot
     # the same leg with the exact-rounding two-pass attention (PCY_ESM_ATTN=exact: the reference's bf16 rounding points op for op;
     # the default is the single-pass kernel, held to the fp32 evaluation instead -- DESIGN.md section 4)
@@ -267,8 +267,8 @@ def main():
         for _ in range(2):
             barrier(); t0 = time.perf_counter()
             embed_sharded(model, tok_fn, nprot, batch_size=rb)
-            barrier(); dt = time.perf_counter() - t0
-            rt_exact = dt if rt_exact is None else min(rt_exact, dt)
+            barrier(); dt_r = time.perf_counter() - t0
+            rt_exact = dt_r if rt_exact is None else min(rt_exact, dt_r)
         os.environ["PCY_ESM_ATTN"] = "fast"
     # the gathered [N_total, D] matrix against single-rank embeddings of a sample of its rows (first / middle / last protein:
     # the last one lives on the last rank): a protein's embedding does not depend on its batch mates, so the rows must be EQUAL
