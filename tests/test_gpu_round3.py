@@ -678,3 +678,31 @@ def test_gemm_esm_gelu_fast_table_epilogue_every_in_range_value(ctx, monkeypatch
     x2 = W2.t().contiguous()[torch.arange(M) % 64]
     ref2 = x2 * 0.5 * (1.0 + torch.erf(x2 / math.sqrt(2.0)))
     assert torch.equal(out2.view(torch.int16), ref2.view(torch.int16))
+
+
+def test_bench_line_contract_and_internal_consistency():
+    """`bench.py` (the driver's contract): ONE JSON line with the contract's keys, and numbers that agree with each other -- value x
+    ms_per_step = tokens per step (an edit of the retrieval leg once overwrote the headline's elapsed time), roofline.frac =
+    achieved / peak < 1, achieved = bytes / launch time.  A reduced run: 25 retrieval proteins, no configs block, no CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-configs", "--no-cpu-baseline",
+                          "--retrieval-proteins", "25"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "tokens/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and "workload" in d["config"]
+    tokens = 256
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - tokens) < 0.02 * tokens, (d["value"], d["ms_per_step"])
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0.3 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["bytes_per_launch"] / 1e9 / (r["avg_launch_us"] / 1e6)) < 0.01 * r["achieved"]
+    assert d["retrieval"]["proteins_per_s"] > 0 and d["retrieval"]["n_proteins"] == 25
