@@ -1449,6 +1449,25 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
+template <int EPI, bool NOPERM, int STG>
+void launch_big_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, int smem) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, NOPERM, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, NOPERM, STG>), grid, dim3(512), smem, s, b);
+}
+template <int EPI, bool NOPERM, int STG>
+void launch_big_persist_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, int smem) {
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, NOPERM, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, NOPERM, STG>), grid, dim3(512), smem, s, b);
+}
+
 #ifndef PCY_BIG_MIN_N
 #define PCY_BIG_MIN_N 1280   // with the split + priority schedule the 256 x 256 kernel also wins at N = K = 1280 (ESM wo: 167-177 -> 152-157 us)
 #endif
@@ -1517,65 +1536,31 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         hipLaunchKernelGGL((gemm_kernel_big<EPI, false, true>), dim3(tiles_big), dim3(512), smem_w, s, b);
         return;
       }
-      if (gemm_noperm(EPI, false)) {
-        static bool configured_n = false;
-        if (!configured_n) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          configured_n = true;
-        }
-        if constexpr (EPI == EPI_GELU_ESM) {
-          ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
-          hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, true>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem, s, b);
-        } else {
-          ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
-          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, true>), dim3(tiles_big), dim3(512), smem, s, b);
-        }
-        return;
-      }
+      // row order (PCY_GEMM_PERM mask) x staging / loop form (PCY_GEMM_STG): every combination is its own instantiation
+      const bool noperm = gemm_noperm(EPI, false);
       if constexpr (EPI == EPI_GELU_ESM) {
-        constexpr int smem_g = smem + GELU_LUT_HALF * 2;   // the negative half of the sparse table image ends 8 KiB behind the stage buffers
-        static bool configured_p = false;
-        if (!configured_p) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_g);
-          configured_p = true;
-        }
+        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
         const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (A/B, tests)
         b.gelu_select = gs && atoi(gs) == 1;
-        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
-        if (gemm_stg()) {
-          static bool configured_s = false;
-          if (!configured_s) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_g);
-            configured_s = true;
-          }
-          hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, false, 1>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem_g, s, b);
-          return;
-        }
-        hipLaunchKernelGGL((gemm_kernel_big_persist<EPI>), dim3(tiles_big > 256 ? 256 : tiles_big), dim3(512), smem_g, s, b);
+        const dim3 gp(tiles_big > 256 ? 256 : tiles_big);
+        if (noperm) launch_big_persist_variant<EPI, true, 0>(s, b, gp, smem);
+        else if (gemm_stg()) launch_big_persist_variant<EPI, false, 1>(s, b, gp, smem + GELU_LUT_HALF * 2);   // (+ the negative half of the sparse table image)
+        else launch_big_persist_variant<EPI, false, 0>(s, b, gp, smem + GELU_LUT_HALF * 2);
       } else {
         // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
         // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
-        if (gemm_pipe(a.K)) {
-          static bool configured_p2 = false;
-          if (!configured_p2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            configured_p2 = true;
-          }
-          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, false, 2>), dim3(tiles_big), dim3(512), smem, s, b);
-          return;
+        const int stg = gemm_pipe(a.K) ? 2 : (gemm_stg() ? 1 : 0);
+        const dim3 g(tiles_big);
+        if (noperm) {
+          if (stg == 2) launch_big_variant<EPI, true, 2>(s, b, g, smem);
+          else if (stg == 1) launch_big_variant<EPI, true, 1>(s, b, g, smem);
+          else launch_big_variant<EPI, true, 0>(s, b, g, smem);
+        } else {
+          if (stg == 2) launch_big_variant<EPI, false, 2>(s, b, g, smem);
+          else if (stg == 1) launch_big_variant<EPI, false, 1>(s, b, g, smem);
+          else launch_big_variant<EPI, false, 0>(s, b, g, smem);
         }
-        if (gemm_stg()) {
-          static bool configured_s = false;
-          if (!configured_s) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            configured_s = true;
-          }
-          hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, false, 1>), dim3(tiles_big), dim3(512), smem, s, b);
-          return;
-        }
-        hipLaunchKernelGGL((gemm_kernel_big<EPI>), dim3(tiles_big), dim3(512), smem, s, b);
       }
     }
     return;
