@@ -1031,21 +1031,36 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       __syncthreads();   // (lgkmcnt(0): this wave's reads of stage kt are complete; vmcnt(0): its pieces of stage kt+1 have landed)
       // (the eight pieces in front of the sub-step; spreading them over the MFMA rows with sched_group_barrier(0x020) made hipcc
       // cluster them -- each needs its own M0 -- and undo the MFMA : read interleave below)
-      if (kt + 2 < nk) {
+#ifndef PCY_PIPE_SPLIT_DMA
+#define PCY_PIPE_SPLIT_DMA 1   // 0: all eight pieces of stage kt+2 right behind the barrier (the first form)
+#endif
+      if ((!PCY_PIPE_SPLIT_DMA) && kt + 2 < nk) {
         stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
         stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
       }
       // sub-step 1: MFMAs on (xb, wf); prefetch sub-step 0 of stage kt+1 into (xa, wf)
+      if (PCY_PIPE_SPLIT_DMA && kt + 2 < nk) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < WTN; ++i) {
+      for (int i = 0; i < WTM; ++i) {
 #pragma unroll
         for (int j = 0; j < WTM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xb[j], acc[i][j], 0, 0, 0);
         wf[i] = lds_frag<BK, SWW>(Wnxt, wrow(i), fq);
-        if (i < WTM) xa[i] = lds_frag<BK>(Anxt, xrow(i), fq);
+        xa[i] = lds_frag<BK>(Anxt, xrow(i), fq);
       }
 #pragma unroll
       for (int i = 0; i < WTM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+      if (PCY_PIPE_SPLIT_DMA) {   // the W half of stage kt+2 behind the first four rows (the A half went out in front of them)
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 2 < nk) stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
+        __builtin_amdgcn_s_setprio(1);
+      }
+#pragma unroll
+      for (int i = WTM; i < WTN; ++i) {
+#pragma unroll
+        for (int j = 0; j < WTM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xb[j], acc[i][j], 0, 0, 0);
+        wf[i] = lds_frag<BK, SWW>(Wnxt, wrow(i), fq);
+      }
 #pragma unroll
       for (int i = WTM; i < WTN; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
       __builtin_amdgcn_s_setprio(0);
@@ -1403,14 +1418,16 @@ inline bool gemm_noperm(int epi, bool f8) {
 // call) = the global_load_lds form.  Interleaved A/B: ESM2-650M batch 41.2 -> 40.6 ms, Llama-3-8B prefill 64 x 450 tokens 1048 -> 1055
 // TFLOP/s, one 512-token prompt unchanged; 16-40 VGPRs fewer.
 inline bool gemm_stg() { const char* e = getenv("PCY_GEMM_STG"); return !(e && atoi(e) == 0); }
-// The software-pipelined k-loop of gemm_kernel_big (STG = 2; STORE / RESID / SwiGLU epilogues) where K is long: interleaved A/B on the
-// Llama-3-8B prefill of 64 x 450 tokens (K = 4096 / 14336) 1059 -> 1092 TFLOP/s; at K = 1280 its two-stage prologue costs what the loop
-// gains (ESM2-650M batch 40.7 vs 40.6 ms; stand-alone qkv 214 -> 229 us, fc1 shape 287 -> 300 us).  PCY_GEMM_STG=2 forces it for every
-// K, =1 / =0 switch it off.
+// The software-pipelined k-loop of gemm_kernel_big (STG = 2; STORE / RESID / SwiGLU epilogues), the default.  Interleaved A/B against the
+// lock-step loop over the same buffer-load staging (STG = 1): Llama-3-8B prefill 64 x 450 tokens 1068 -> 1143 TFLOP/s, one 512-token
+// prompt 10.40 -> 9.97 ms, ESM2-650M batch 40.3 -> 39.55 ms (its first form, all eight DMA pieces in front of the second sub-step, gave
+// +2.7 % on the Llama prefill and nothing at K = 1280; with the A half in front and the W half behind the fourth MFMA row it pays at every
+// K).  PCY_GEMM_STG=1 / =0 switch it off.
 inline bool gemm_pipe(int K) {
   const char* e = getenv("PCY_GEMM_STG");
   if (e) return atoi(e) == 2;
-  return K >= 4096;
+  (void)K;
+  return true;
 }
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
