@@ -1642,7 +1642,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
         constexpr int smem = 2 * (256 + 256) * 64 * 2;
         static bool configured = false;
         if (!configured) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI_STORE, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI_STORE, false, false, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
           configured = true;
         }
         PcyGemmArgs b = a;
@@ -1651,7 +1651,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
         if (gnb < 2) gnb = 2;
         b.gn = (int)(gnb > tn ? tn : gnb);
         b.splits = splits;
-        hipLaunchKernelGGL((gemm_kernel_big<EPI_STORE, false, false, true>), dim3(((a.M + 255) / 256) * tn * splits), dim3(512), smem, s, b);
+        hipLaunchKernelGGL((gemm_kernel_big<EPI_STORE, false, false, true, false, 2>), dim3(((a.M + 255) / 256) * tn * splits), dim3(512), smem, s, b);
       } else
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
