@@ -1207,9 +1207,21 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     return;
   }
   if constexpr (EPI == EPI_GELU_ESM) {
-    gelu_lut_to_lds<512>(smem);
-    if constexpr (PERM) gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(smem));
-    else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    if constexpr (PERM) {
+      // the fast table epilogue of the persistent kernel (sparse image: positive half over stage buffer 0, negative half over buffer 1:
+      // every buffer is dead here); the select form as the fallback
+      __syncthreads();
+      gelu_lut_to_lds_sparse<512>(smem);
+      const bool vec16 = (a.ldc % 8 == 0) && (a.N % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                         (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && !a.gelu_select;
+      bool done = false;
+      if (vec16) done = gemm_epilogue_perm_gelu_fast<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, smem);
+      if (!done)
+        gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(smem), nullptr, GELU_SPARSE_NEG);
+    } else {
+      gelu_lut_to_lds<512>(smem);
+      gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
+    }
     return;
   }
   if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
@@ -1559,6 +1571,15 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
         const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (A/B, tests)
         b.gelu_select = gs && atoi(gs) == 1;
+        // One tile per workgroup on the pipelined k-loop (default) or the tile loop of gemm_kernel_big_persist (PCY_GELU_PERSIST=1, read per
+        // call): with the fast table epilogue in both, interleaved 39.36 vs 39.60 ms per ESM2-650M batch -- what the tile loop gains
+        // by requesting the next tile's first stage under the epilogue, the pipelined loop gains inside the tile.  (The dispatch counter
+        // keeps one slot for both: "the ESM-GELU 256 x 256 kernel".)
+        const char* gpe = getenv("PCY_GELU_PERSIST");
+        if (!(gpe && atoi(gpe) == 1) && !noperm && gemm_pipe(a.K)) {
+          launch_big_variant<EPI, false, 2>(s, b, dim3(tiles_big), smem);
+          return;
+        }
         const dim3 gp(tiles_big > 256 ? 256 : tiles_big);
         if (noperm) launch_big_persist_variant<EPI, true, 0>(s, b, gp, smem);
         else if (gemm_stg()) launch_big_persist_variant<EPI, false, 1>(s, b, gp, smem + GELU_LUT_HALF * 2);   // (+ the negative half of the sparse table image)
