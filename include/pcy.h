@@ -207,7 +207,8 @@ int pcy_llama_prefill(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, cons
 /* The same prefill that additionally materialises what `LlamaPostTokenization.forward` hands back besides the logits
  * (pmc_llama.py:575-596, `output_hidden_states=True`): hidden_all_out [L+1][B*T][d] bf16 = the embeddings, the output of layers
  * 0..L-2 and the final-normed output of layer L-1.  logit_rows may name every row (the reference's [B,T,V] logits): more than 64
- * rows take the lm_head as an MFMA GEMM. */
+ * rows take the lm_head as an MFMA GEMM -- on THIS entry point only; pcy_llama_prefill always uses the fused-norm GEMV, so a row's
+ * logits there do not depend on the number of rows requested. */
 int pcy_llama_prefill_all(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const void* embeds, const uint8_t* keep,
                           const int32_t* pos, const int32_t* cu, const int32_t* vt_cu, int B, int T, const int32_t* logit_rows,
                           int n_logit_rows, void* logits_out, void* hidden_all_out);

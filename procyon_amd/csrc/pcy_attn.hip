@@ -1061,15 +1061,22 @@ void launch_dec_g(hipStream_t s, const PcyDecAttnArgs& a) {
 
 }  // namespace
 
-bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv) {
+// ONE predicate for the single-pass kernel, shared by pcy_attention, pcy_esm_encode and the launcher: shape (head_dim 64, bidirectional,
+// unmasked, unit scale, no grouped heads) AND every alignment the kernel's 16-byte / 8-byte accesses need.  A caller that lays out Vt
+// (or skips the transposed copy) for the fast kernel therefore knows the launcher will take it -- it cannot decline afterwards and
+// leave the two-pass kernels with a buffer that was never written.
+bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv, int ldq, int qcol0, int ldk, int kcol0, int ldo) {
   const char* e = getenv("PCY_ESM_ATTN");   // "exact" = the reference's rounding points (two-pass kernel); read per call: tests compare
   if (e && e[0] == 'e') return false;
-  return dh == 64 && !causal && !has_keep && scale == 1.0f && H == Hkv;
+  if (!(dh == 64 && !causal && !has_keep && scale == 1.0f && H == Hkv)) return false;
+  return ((ldq | ldk | qcol0 | kcol0) % 8) == 0 && ldo % 4 == 0;
 }
-bool pcy_attn_fast_vrow() { const char* e = getenv("PCY_FA_VROW"); return !(e && atoi(e) == 0); }
+// ... and for reading V token-major where the projection wrote it (PCY_FA_VROW=0: from the transposed copy)
+bool pcy_attn_fast_vrow(int ldv, int vcol0) { const char* e = getenv("PCY_FA_VROW"); return !(e && atoi(e) == 0) && ((ldv | vcol0) % 8) == 0; }
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
-  if (a.vt_pad64 && pcy_attn_fast_eligible(a.dh, a.causal, a.keep != nullptr, a.scale, a.H, a.Hkv) && pcy_launch_attn_fast64(s, a, true)) {
+  if (a.vt_pad64 && pcy_attn_fast_eligible(a.dh, a.causal, a.keep != nullptr, a.scale, a.H, a.Hkv, a.ldq, a.qcol0, a.ldk, a.kcol0, a.ldo) &&
+      pcy_launch_attn_fast64(s, a, true)) {
     ++g_pcy_dispatch[PCY_DISPATCH_ATTN_FAST];
     return;
   }

@@ -41,9 +41,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // <= 256: harmless for bf16's 8-bit exponent and the fp32 sums; m cancels in O / l).  After the first blocks no wave takes that
 // branch on ordinary data; tests/test_gpu_round3.py forces it with spiked keys.
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-// (inline asm: hipcc's hazard recognizer does not see that it READS MFMA results.  The kernel's schedule always has another group's
-// MFMA chain between a Q.K^T and the softmax of its scores; an experiment that ran ONE query group per wave put the softmax right behind
-// its own Q.K^T and read half-written accumulators -- bits that changed from launch to launch.  Keep that distance.)
+// (inline asm: hipcc's hazard recognizer does not see that it READS MFMA results -- an experiment that ran ONE query group per wave put
+// an all-asm softmax right behind its own Q.K^T and read half-written accumulators, bits that changed from launch to launch.  The
+// chain in fa_softmax_block therefore STARTS with a compiler-visible reader of the accumulators, see there.)
 __device__ __forceinline__ float fa_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 template <bool MASKED, int ABL = 0>
 __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, f32x16 (&o)[2], bf16x8 (&pf)[2], int key0, int half, int len) {
@@ -59,7 +59,11 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
       v[e] = key < len ? v[e] : -INFINITY;
     }
   }
-  float bm = fa_max3(v[0], v[1], v[2]);
+  // The FIRST reader of the Q.K^T accumulators is a compiler-visible instruction (v_add_f32 with +0.0: not foldable without nsz, and
+  // harmless -- it can only turn a -0.0 maximum into +0.0, which exp2(s - m) does not see): hipcc's hazard recognizer pads the
+  // MFMA -> VALU wait states in front of IT, and every asm v_max3 below depends on its result, so none of them can be scheduled
+  // ahead of the padding whatever the surrounding schedule looks like.  (fmed3(a, b, +inf) is folded into three canonicalising v_max.)
+  float bm = fa_max3(v[0] + 0.0f, v[1], v[2]);
 #pragma unroll
   for (int e = 3; e < 15; e += 2) bm = fa_max3(bm, v[e], v[e + 1]);
   bm = fa_max3(bm, v[15], v[15]);
@@ -325,8 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   }
 }
 
-// true when the launch was taken: head_dim 64, bidirectional, unmasked, unit scale, every sequence's Vt slice padded to a multiple
-// of 64 keys (so that a whole 64-key tile of Vt can be fetched; the pad columns are zero)
+// The caller has checked pcy_attn_fast_eligible (shape + alignment; pcy_attn.hip) and, for the token-major V form, pcy_attn_fast_vrow;
+// the tests below restate it and can only fail for a caller that skipped the predicate.  Vt form: every sequence's slice padded to a
+// multiple of 64 keys (so that a whole 64-key tile of Vt can be fetched; the pad columns are zero), vt_total a multiple of 8.
 inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_pad64) {
   if (a.dh != 64 || a.causal || a.keep || a.scale != 1.0f || a.H != a.Hkv || !vt_pad64) return false;
   if ((a.ldq | a.ldk | a.qcol0 | a.kcol0) % 8 || a.ldo % 4) return false;
@@ -338,14 +343,17 @@ inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_
     return true;
   }
   if (a.vt_total % 8) return false;
-  const char* e = getenv("PCY_FA_ABL");   // measurement variants (wrong results)
+#ifdef PCY_FA_ABL_BUILD   // measurement variants with parts of the work removed (WRONG results; tools/bench_attn_abl.py builds with it)
+  const char* e = getenv("PCY_FA_ABL");
   const int abl = e ? atoi(e) : 0;
   switch (abl) {
-#define FA_CASE(V) case V: hipLaunchKernelGGL(attn_fast64_kernel<V>, grid, dim3(256), 0, s, a, nchunk); break;
+#define FA_CASE(V) case V: hipLaunchKernelGGL(attn_fast64_kernel<V>, grid, dim3(256), 0, s, a, nchunk); return true;
     FA_CASE(1) FA_CASE(2) FA_CASE(3) FA_CASE(4) FA_CASE(8) FA_CASE(12) FA_CASE(48) FA_CASE(64) FA_CASE(112) FA_CASE(15) FA_CASE(127)
 #undef FA_CASE
-    default: hipLaunchKernelGGL(attn_fast64_kernel<0>, grid, dim3(256), 0, s, a, nchunk); break;
+    default: break;
   }
+#endif
+  hipLaunchKernelGGL(attn_fast64_kernel<0>, grid, dim3(256), 0, s, a, nchunk);
   return true;
 }
 

@@ -659,7 +659,7 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
   if ((Hkv * dh) % 64 || H % Hkv) return fail(1, "pcy_attention: Hkv*dh must be a multiple of 64 and Hkv | H");
   // the single-pass kernel wants every sequence's Vt slice zero-padded to a multiple of 64 keys: it lays Vt out itself (offsets
   // computed on the device from cu), whatever vt_cu / vt_total the caller passed
-  const bool fast = pcy_attn_fast_eligible(dh, causal, keep != nullptr, scale, H, Hkv);
+  const bool fast = pcy_attn_fast_eligible(dh, causal, keep != nullptr, scale, H, Hkv, ldq, qcol0, ldk, kcol0, ldo);
   int32_t* vt_cu64 = nullptr;
   if (fast) {
     int ntok_ub = 0;   // upper bound of the token count: nseq * max_len
@@ -669,7 +669,7 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
   if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096)) return r;
   bf16_t* vt = reinterpret_cast<bf16_t*>(c->ws);
   // the single-pass kernel reads V token-major where it is (PCY_FA_VROW=0: from a transposed copy, as the other kernels do)
-  const bool vrow = fast && pcy_attn_fast_vrow() && ldv % 8 == 0 && vcol0 % 8 == 0;
+  const bool vrow = fast && pcy_attn_fast_vrow(ldv, vcol0);
   if (fast && !vrow) {
     vt_cu64 = reinterpret_cast<int32_t*>(c->ws + align_up((size_t)Hkv * dh * vt_total * 2, 256));
     pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
@@ -860,7 +860,7 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   if (d % 64 || F % 64) return fail(1, "pcy_esm_encode: d and ffn must be multiples of 64");
   if (ntok <= 0) return 0;
   // single-pass attention (default at head_dim 64): Vt slices zero-padded to 64 keys, laid out by the engine itself
-  const bool fast = pcy_attn_fast_eligible(dh, 0, false, 1.0f, H, H);
+  const bool fast = pcy_attn_fast_eligible(dh, 0, false, 1.0f, H, H, 3 * d, 0, 3 * d, d, d);
   if (fast) vt_total = (int)align_up((size_t)ntok + 64 * (size_t)nseq, 8);
   const size_t need = align_up((size_t)ntok * d * 2, 256) * 3 + align_up((size_t)ntok * 3 * d * 2, 256) +
                       align_up((size_t)ntok * F * 2, 256) + align_up((size_t)d * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096;
@@ -873,7 +873,7 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   bf16_t* act = cv.take<bf16_t>((size_t)ntok * F);
   bf16_t* vt = cv.take<bf16_t>((size_t)d * vt_total);
   int32_t* vt_cu64 = cv.take<int32_t>((size_t)nseq + 1);
-  const bool vrow = fast && pcy_attn_fast_vrow();   // the single-pass kernel reads V out of qkv: no transposed copy
+  const bool vrow = fast && pcy_attn_fast_vrow(3 * d, 2 * d);   // the single-pass kernel reads V out of qkv: no transposed copy
   if (fast && !vrow) {
     pcy_launch_vt_offsets(c->stream, cu, nseq, 64, vt_cu64);
     vt_cu = vt_cu64;
@@ -1036,9 +1036,11 @@ int llama_prefill_impl(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* 
     pcy_launch_acc_rows(s, hsum_tmp, d, nullptr, hsum, n_sum_rows, d, 0);
     pcy_launch_acc_finish(s, hsum, (bf16_t*)hidden_sum_out, (size_t)n_sum_rows * d);
   }
-  if (n_logit_rows > 64 && logits_out) {
-    // many rows (the reference's full [B,T,V] logits): final norm of those rows, then lm_head as an MFMA GEMM -- the GEMV would
-    // stream the 1 GB matrix once per 32 rows
+  if (hall && n_logit_rows > 64 && logits_out) {
+    // pcy_llama_prefill_all with many rows (the reference's full [B,T,V] logits): final norm of those rows, then lm_head as an MFMA
+    // GEMM -- the GEMV would stream the 1 GB matrix once per 32 rows.  ONLY on this entry point: the GEMM accumulates in another
+    // order than the fused-norm GEMV, and a row's logits from pcy_llama_prefill must not depend on how many rows were asked for
+    // (QA / pair scoring with 64 or 65 rows: same bits per row; tests/test_gpu_round4.py).
     pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
     pcy_launch_rmsnorm(s, lastx, (const bf16_t*)m->final_norm, lastx, n_logit_rows, d, m->rms_eps, m->rms_cast);
     linear(s, lastx, d, (const bf16_t*)m->lm_head, nullptr, nullptr, 0, (bf16_t*)logits_out, m->vocab, n_logit_rows, m->vocab, d, EPI_STORE);

@@ -1497,12 +1497,17 @@ void launch_big_persist_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, 
   hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, NOPERM, STG>), grid, dim3(512), smem, s, b);
 }
 
+#include "pcy_gemm_mid.h"
+
 #ifndef PCY_BIG_MIN_N
 #define PCY_BIG_MIN_N 1280   // with the split + priority schedule the 256 x 256 kernel also wins at N = K = 1280 (ESM wo: 167-177 -> 152-157 us)
 #endif
 template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  if constexpr (EPI != EPI_GELU_ERF) {
+    if (a.mid_cfg > 0 && launch_mid<EPI, false>(s, a, a.mid_cfg)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
+  }
   constexpr int big_min_m = 2048;
   // 256x256 tiles pay off where the mainloop dominates (measured, M = 32832: qkv 734 -> 804, fc2 827 -> 911 TFLOP/s);
   // for N = K = 1280 they do not; the ESM GELU epilogue is a wash since the rational erf (fc1 679 vs 700)
@@ -1627,6 +1632,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (a0.M <= 0 || a0.N <= 0) return;
   PcyGemmArgs a = a0;
   { const char* e = getenv("PCY_ROPE_VSKIP"); a.rope_noskip = e && atoi(e) == 0; }   // (A/B: 0 = table loads for the V tiles too)
+  if (a.mid_cfg == 0) { const char* e = getenv("PCY_GEMM_MID"); if (e) a.mid_cfg = atoi(e); }   // (tools / tests: force a gemm_kernel_mid configuration)
   const int tiles_n = (a.N + BN - 1) / BN;
   const long panel = (long)BN * a.K * 2;
   long gn = (5L << 19) / panel;           // 2.5 MiB of W panels per group

@@ -106,11 +106,12 @@ struct PcyGemmArgs {
   int splits;           // set by the launcher (split-K forms): number of K ranges, partial sums in splitk_ws [splits][M][N]
   int rope_noskip;      // set by the launcher (PCY_ROPE_VSKIP=0): the fused-rotary epilogue loads its tables for un-rotated wave tiles too
   int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the persistent ESM-GELU kernel skips the fast table epilogue
+  int mid_cfg;          // > 0: this configuration of gemm_kernel_mid (pcy_gemm_mid.h); 0: the launcher's own choice
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // launch counters per kernel family (pcy_debug_dispatch_count)
 enum { PCY_DISPATCH_GEMM_128 = 0, PCY_DISPATCH_GEMM_64 = 1, PCY_DISPATCH_GEMM_BIG = 2, PCY_DISPATCH_GEMM_BIG_PERSIST = 3,
-       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_BD_CHAIN = 7, PCY_DISPATCH_N = 8 };
+       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_BD_CHAIN = 7, PCY_DISPATCH_GEMM_MID = 8, PCY_DISPATCH_N = 9 };
 extern unsigned long long g_pcy_dispatch[PCY_DISPATCH_N];
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)
@@ -158,10 +159,10 @@ struct PcyAttnArgs {
   const bf16_t* v; int ldv; int vcol0;
 };
 // PCY_FA_VROW=0 (read per call): the single-pass attention reads a transposed copy of V (the first form) instead of V itself
-bool pcy_attn_fast_vrow();
+bool pcy_attn_fast_vrow(int ldv, int vcol0);
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a);
 // the single-pass kernel (pcy_attn_fast.h) covers this call unless PCY_ESM_ATTN=exact asks for the reference's rounding points
-bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv);
+bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int H, int Hkv, int ldq, int qcol0, int ldk, int kcol0, int ldo);
 // vt_cu_out[q] = sum over earlier sequences of their length rounded up to `pad` (vt_cu_out[nseq] = total), on the device
 void pcy_launch_vt_offsets(hipStream_t s, const int32_t* cu, int nseq, int pad, int32_t* vt_cu_out);
 

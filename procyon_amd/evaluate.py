@@ -242,15 +242,19 @@ class ProcyonRetrievalEval:
 
     @staticmethod
     def _query_is_sequence(dataset):
-        """text queries keep their id under input.text, AASeqDataset (PPI) queries under input.seq (procyon.py:248-253,268-276).
-        The dataset classes are the reference's; they are told apart by name (or by the `query_is_sequence` attribute a stand-in
-        loader may set)."""
+        """text queries keep their id under input.text, AASeqDataset (PPI) queries under input.seq (procyon.py:241-246,268-276).
+        The dataset classes are the reference's (not importable here): they are told apart by walking the class's MRO by NAME --
+        subclasses and wrappers that inherit from them are recognised as `isinstance` would -- AASeqTextUnifiedDataset first, as the
+        reference checks it first.  A stand-in loader sets the `query_is_sequence` attribute instead.  Anything else raises the
+        reference's ValueError."""
         if hasattr(dataset, "query_is_sequence"):
             return bool(dataset.query_is_sequence)
-        name = type(dataset).__name__
-        if name == "AASeqDataset":
+        names = [k.__name__ for k in type(dataset).__mro__]
+        if "AASeqTextUnifiedDataset" in names:
+            return False
+        if "AASeqDataset" in names:
             return True
-        return False
+        raise ValueError(f"unexpected dataset type: {type(dataset)}")
 
     @torch.no_grad()
     def _get_query_embeddings(self, query_loader, query_order):

@@ -339,7 +339,7 @@ class UnifiedProCyon:
         ret_rows = ret_idx[:, :real].reshape(-1).nonzero()[:, 0] if sum_all else None   # flat b*T + t, row-major like boolean indexing
         outputs = self.text_encoder(input_embeds=emb, attn_masks=attn_masks[:, :real], full_labels=full_labels,
                                     logit_positions=answer_pos if not retrieval else torch.zeros(B, dtype=torch.long),
-                                    want_hidden=retrieval and not sum_all, hidden_sum_positions=ret_rows)
+                                    want_hidden=retrieval and not sum_all, hidden_sum_positions=ret_rows, lazy_hidden=True)
         out = {'outputs': outputs, 'text_toks': input_ids, 'full_labels': full_labels if get_full_labels else None,
                'contrastive_out': None, 'contrastive_loss': None, 'answer_positions': answer_pos}
         if retrieval:

@@ -33,13 +33,12 @@ class _Past:
 
 
 class _HiddenStates:
-    """`outputs.hidden_states` (pmc_llama.py:575,584 `output_hidden_states=True`): the L+1 tuple of [B,T,d] tensors -- embeddings,
-    outputs of layers 0..L-2, final-normed output of layer L-1.  The engine's fast path keeps only what the shipped configuration
-    reads, `hidden_states[-1]` (ret_token_access='last', model_unified.py:556-559); ANY other access -- another index,
-    iteration, `torch.stack(hidden_states, -1)` of ret_token_access='all' (:560-563), len() -- materialises the whole tuple by
-    running the (deterministic) prefill once more with every layer's state written out.  So a caller that keeps the reference's
-    `UnifiedProCyon` and swaps only this sub-module (INTEGRATION.md route B) sees the reference's object, and callers that read
-    [-1] pay nothing."""
+    """Lazy stand-in for `outputs.hidden_states`, handed out ONLY when the caller asks for it (`lazy_hidden=True`: the engine-backed
+    `UnifiedProCyon`, which reads `hidden_states[-1]` alone -- ret_token_access='last', model_unified.py:556-559).  It keeps the last
+    state; any other access (another index, iteration, len()) materialises the whole tuple by running the (deterministic) prefill once
+    more with every layer's state written out.  It is NOT a tuple -- `torch.stack(obj, -1)` rejects it -- which is why a caller that
+    passes the reference's arguments only (INTEGRATION.md route B: the reference's own `UnifiedProCyon` over this sub-module, whose
+    ret_token_access='all' branch does `torch.stack(outputs.hidden_states, dim=-1)`, model_unified.py:563) gets a real tuple."""
 
     def __init__(self, n, last, materialise):
         self._n, self._last, self._mat, self._all = n, last, materialise, None
@@ -66,8 +65,11 @@ class LlamaPostTokenization:
     -> object with .logits, .past_key_values, .hidden_states, .loss   (pmc_llama.py:546-596).
 
     Exactly one of input_embeds / input_ids (:562).  With the reference's arguments only, the returned object is the
-    reference's: `.logits` [B,T,V] for every row and `.hidden_states` the L+1 tuple (lazily materialised, see _HiddenStates).
+    reference's: `.logits` [B,T,V] for every row and `.hidden_states` a real `tuple` of the L+1 [B,T,d] tensors (the wrapper always
+    runs its model with `output_hidden_states=True`, pmc_llama.py:575,584) -- embeddings, outputs of layers 0..L-2, final-normed
+    output of layer L-1.
     Extensions used by the engine-backed `UnifiedProCyon` (never required):
+      * `lazy_hidden=True`: `.hidden_states` is a `_HiddenStates` (the last state only, the rest materialised on access).
       * `logit_positions`: LongTensor [B] -> logits only at those positions ([B,1,V]); the reference always materialises
         [B,T,V] (1 GB per 2048-token row).  None = all rows.
       * `want_hidden=False` skips the final hidden state, `hidden_sum_positions` asks for the sum over all L+1 states at
@@ -91,7 +93,7 @@ class LlamaPostTokenization:
 
     def forward(self, input_embeds=None, input_ids=None, attn_masks=None, full_labels=None, past_key_values=None,
                 use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None,
-                output_hidden_states=False):
+                output_hidden_states=False, lazy_hidden=False):
         assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
         eng = self.engine
         if past_key_values is None:
@@ -111,10 +113,9 @@ class LlamaPostTokenization:
                 _, hall = eng.prefill_all(embeds_dev, attn_masks, eng.new_cache(B, T), None)
                 return [hall[i] for i in range(L1)]
 
-            if output_hidden_states:
+            if output_hidden_states or not lazy_hidden:
                 logits, hall = eng.prefill_all(embeds_dev, attn_masks, cache, rows)
-                states = [hall[i] for i in range(L1)]
-                hs = _HiddenStates(L1, states[-1], lambda: states)
+                hs = tuple(hall[i] for i in range(L1))
                 if hidden_sum_positions is not None:
                     flat = hall.view(L1, B * T, -1)[:, hidden_sum_positions.to(eng.device).long()]
                     hsum = flat.float().sum(0).to(hall.dtype)

@@ -105,7 +105,7 @@ def load_caption_table(caption_fpath: Optional[str] = None, caption_dir: Optiona
     """the caption table(s) `qa_filter_captions.py` accepts (:22-36)"""
     if caption_fpath is not None:
         if caption_fpath.endswith("tsv.gz"):
-            return pd.read_csv(caption_fpath, compression="gzip", sep="\\t")
+            return pd.read_csv(caption_fpath, compression="gzip", sep="\t")
         if caption_fpath.endswith(".pickle") or caption_fpath.endswith(".pkl"):
             return pd.read_pickle(caption_fpath)
         if caption_fpath.endswith(".csv"):

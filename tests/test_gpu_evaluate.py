@@ -16,7 +16,7 @@ class _Loader(list):
 
     def __init__(self, batches, collate_fn=None):
         super().__init__(batches)
-        self.dataset = SimpleNamespace(aaseq_type="protein")
+        self.dataset = SimpleNamespace(aaseq_type="protein", query_is_sequence=False)
         self.collate_fn = collate_fn
 
 

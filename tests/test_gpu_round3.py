@@ -340,15 +340,19 @@ def test_llama_forward_full_logits_and_hidden_states_tuple():
     out = enc(input_embeds=emb.cuda(), attn_masks=mask)
     ref = LR.llama_forward(sd, LR.LlamaGeom(**kw), inputs_embeds=emb, attn_mask=mask, want_hidden=True)
     assert out.logits.shape == (B, T, 331) and len(out.hidden_states) == kw["n_layers"] + 1
+    assert isinstance(out.hidden_states, tuple)                # torch.stack takes tuples / lists of tensors only
     valid = mask.bool()
     assert rel_err(out.logits.cpu()[valid], ref["logits"][valid]) < 1e-2
-    hs = [h.cpu() for h in out.hidden_states]                  # iteration materialises the tuple
+    hs = [h.cpu() for h in out.hidden_states]
     assert torch.equal(hs[0], emb)
     for i, (a, b) in enumerate(zip(hs, ref["hidden_states"])):
         assert a.shape == (B, T, 256) and rel_err(a[valid], b[valid]) < 6e-3, i
-    assert torch.equal(out.hidden_states[-1].cpu(), hs[-1])    # the fast path's last state == the materialised one
-    # what ret_token_access='all' does with it (model_unified.py:560-563)
-    summed = torch.stack(list(out.hidden_states), dim=-1).sum(dim=-1).cpu()
+    # the engine-backed model's fast path (lazy_hidden=True): the last state == the tuple's, other accesses materialise the rest
+    lazy = enc(input_embeds=emb.cuda(), attn_masks=mask, lazy_hidden=True)
+    assert not isinstance(lazy.hidden_states, tuple) and torch.equal(lazy.hidden_states[-1].cpu(), hs[-1])
+    assert torch.equal(lazy.hidden_states[1].cpu(), hs[1]) and len(lazy.hidden_states) == len(hs)
+    # what ret_token_access='all' does with it, EXACTLY as the reference writes it (model_unified.py:563)
+    summed = torch.stack(out.hidden_states, dim=-1).sum(dim=-1).cpu()
     assert rel_err(summed[valid], torch.stack(ref["hidden_states"], dim=-1).sum(dim=-1)[valid]) < 6e-3
     # eager form + the engine's row-limited sum agree with the tuple
     out2 = enc(input_embeds=emb.cuda(), attn_masks=mask, output_hidden_states=True, hidden_sum_positions=torch.tensor([3, 80]))

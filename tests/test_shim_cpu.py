@@ -335,3 +335,19 @@ def test_input_builders_match_the_reference_functions(tmp_path, g11, monkeypatch
             continue
         out = SI.jsonable(fn(data_args=DataArgs(), **c["kwargs"]))
         assert out == c["out"], (c["fn"], c["kwargs"], out, c["out"])
+
+
+def test_retrieval_plugin_tells_query_datasets_apart_like_isinstance():
+    """`_get_query_embeddings` (procyon.py:241-246): AASeqTextUnifiedDataset -> text ids, AASeqDataset -> sequence ids, anything else
+    ValueError.  The reference classes are not importable here, so the mirror walks the MRO by name: subclasses count, as with isinstance."""
+    import pytest
+    from procyon_amd.evaluate import ProcyonRetrievalEval
+    AASeqDataset = type("AASeqDataset", (), {})
+    AASeqTextUnifiedDataset = type("AASeqTextUnifiedDataset", (), {})
+    Sub = type("MyPPI", (AASeqDataset,), {})
+    Both = type("Odd", (AASeqTextUnifiedDataset, AASeqDataset), {})
+    f = ProcyonRetrievalEval._query_is_sequence
+    assert f(AASeqDataset()) is True and f(Sub()) is True
+    assert f(AASeqTextUnifiedDataset()) is False and f(Both()) is False
+    with pytest.raises(ValueError, match="unexpected dataset type"):
+        f(object())
