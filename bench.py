@@ -285,21 +285,26 @@ def main():
                  "collective": "one RCCL all-gather through pcy_allgather" if dist else "none (single rank)", "gather_checked_rows": 3}
 
     # ---- BASELINE configs[3] (batch-32 mixed-length generation, 4a equal and 4b ragged prompts) and configs[4] (pair scoring) ----
+    # At N > 1 (or PCY_BENCH_FORCE_DIST=1) the 32 rows / the 256 pairs are SPLIT across the ranks (contiguous
+    # chunks in rank order, one final all-gather of the token ids / probabilities) -- the 1 -> 8 GPU scaling curve of configs[3].
     configs = None
-    if not a.no_configs and a.geometry == "full" and world == 1:
+    batched_roofline = None
+    if not a.no_configs and a.geometry == "full":
         from procyon_amd import workloads as WL
         model.text_encoder.max_new_tokens = 512
-        batched_roofline = WL.batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512)
+        if not dist:
+            batched_roofline = WL.batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512)
         configs = {"config3_4a_batch32_mixed_residues_T512": WL.run_config4(model, new_tokens=512, ragged=False),
                    "config3_4b_batch32_ragged_prompts": WL.run_config4(model, new_tokens=512, ragged=True),
                    "config4_pair_scoring_256": WL.run_config5(model, pairs=256, chunk=64, fp8=True)}
-        # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like
-        # regime instead of the chaotic random-init one), LAST because it rewrites the decoder's weights in place
-        WL.damp_residual_branches(model, 0.25)
-        acc = WL.run_config5(model, pairs=128, chunk=64, fp8=True)
-        configs["config4_fp8_accuracy_damped_model"] = {k: acc[k] for k in ("pairs", "answer_logits_rel_err_fp8_vs_bf16",
-                                                                              "yes_no_agreement_fp8_vs_bf16", "mean_abs_dP_yes")}
-        configs["config4_fp8_accuracy_damped_model"]["residual_branch_scale"] = 0.25
+        if not dist:
+            # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like
+            # regime instead of the chaotic random-init one), LAST because it rewrites the decoder's weights in place
+            WL.damp_residual_branches(model, 0.25)
+            acc = WL.run_config5(model, pairs=128, chunk=64, fp8=True)
+            configs["config4_fp8_accuracy_damped_model"] = {k: acc[k] for k in ("pairs", "answer_logits_rel_err_fp8_vs_bf16",
+                                                                                  "yes_no_agreement_fp8_vs_bf16", "mean_abs_dP_yes")}
+            configs["config4_fp8_accuracy_damped_model"]["residual_branch_scale"] = 0.25
 
     if rank == 0:
         out = {"metric": "phenotype-gen tokens/sec (ProCyon-Full greedy generation, end to end)", "value": round(value, 2),
@@ -311,6 +316,7 @@ def main():
                "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
         if configs is not None:
             out["configs"] = configs
+        if batched_roofline is not None:
             out["batched_decode_roofline"] = batched_roofline
         if not a.no_cpu_baseline and a.geometry == "full" and world == 1:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.tokens, a.residues, a.prompt)

@@ -12,6 +12,8 @@
 //     ESM op-by-op GELU, SwiGLU on 16-row interleaved gate/up weights)
 //   * any M and N (row clamping + predicated stores), K % 64 == 0
 #include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
 #include "pcy_internal.h"
 
 namespace {
@@ -1608,6 +1610,26 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
     }
     return;
   }
+  // Mid-M (128 <= M < 2048 and the 256 x 256 tiling under-fills the chip: one 1024-residue protein, one 512-token prompt): the GEMM is
+  // ONE round of tiles, so the tile shape is chosen for CU fill and the k-loop for latency -- gemm_kernel_mid (pcy_gemm_mid.h), shape
+  // by a cost model fitted on tools/bench_gemm_mid.py (cold weights): rounds(tiles / 256 CUs) x tile area / efficiency, efficiency
+  // 0.6 / 0.8 / 1.0 for 8 waves of 32 x 32 / 32 x 64 / 64 x 64.  Same bits as the kernels below (same k order per element).
+  // In the encoder (rocprofv3 kernel time per 1024-residue protein, tools/insitu_ab.py): 5.97 -> 4.78 ms; o + fc2 38.9 -> 22.5 us avg.
+  if constexpr (EPI != EPI_GELU_ERF) {
+    if (a.mid_cfg == 0 && a.M >= 128) {
+      static const int cand[3][4] = {{5, 128, 64, 6}, {3, 128, 128, 8}, {6, 256, 128, 10}};   // id, TM, TN, 10 x efficiency
+      int best = 0;
+      double best_cost = 0;
+      for (int i = 0; i < 3; ++i) {
+        const int fn = cand[i][2] / 2 / 16;   // feature tiles per wave (two waves along N in all three)
+        if (a.rope_cos != nullptr && fn % 4 != 0) continue;
+        const long t = (long)((a.M + cand[i][1] - 1) / cand[i][1]) * ((a.N + cand[i][2] - 1) / cand[i][2]);
+        const double cost = (double)((t + 255) / 256) * cand[i][1] * cand[i][2] * 10.0 / cand[i][3];
+        if (!best || cost < best_cost) { best = cand[i][0]; best_cost = cost; }
+      }
+      if (best && launch_mid<EPI, false>(s, a, best)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
+    }
+  }
   // fewer than 192 tiles of 128 x 128 (of 512 slots): 64 x 64 tiles -- four times the workgroups, same arithmetic per element
   if constexpr (EPI != EPI_SWIGLU) {
     if (tiles < 192 && a.rope_cos == nullptr) {
@@ -1632,7 +1654,17 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (a0.M <= 0 || a0.N <= 0) return;
   PcyGemmArgs a = a0;
   { const char* e = getenv("PCY_ROPE_VSKIP"); a.rope_noskip = e && atoi(e) == 0; }   // (A/B: 0 = table loads for the V tiles too)
-  if (a.mid_cfg == 0) { const char* e = getenv("PCY_GEMM_MID"); if (e) a.mid_cfg = atoi(e); }   // (tools / tests: force a gemm_kernel_mid configuration)
+  if (a.mid_cfg == 0) {   // tools / tests: force a gemm_kernel_mid configuration -- "5" for every GEMM, or per shape "3840x1280=6,1280x5120=5" (N x K)
+    const char* e = getenv("PCY_GEMM_MID");
+    if (e && !strchr(e, 'x')) a.mid_cfg = atoi(e);
+    else if (e) {
+      char key[48];
+      snprintf(key, sizeof(key), "%dx%d=", a.N, a.K);
+      const char* hit = strstr(e, key);
+      if (hit && (hit == e || hit[-1] == ',')) a.mid_cfg = atoi(hit + strlen(key));
+      else a.mid_cfg = -1;   // (-1: the launcher's pre-round-4 choice, for the shapes the map does not name)
+    }
+  }
   const int tiles_n = (a.N + BN - 1) / BN;
   const long panel = (long)BN * a.K * 2;
   long gn = (5L << 19) / panel;           // 2.5 MiB of W panels per group
@@ -1647,7 +1679,19 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     return;
   }
   // split-K: few tiles, long K, plain / residual epilogue, a workspace supplied by the caller
-  if (a.splitk_ws && (a.epi == EPI_STORE || a.epi == EPI_RESID) && a.rope_cos == nullptr && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+  // (tools: PCY_GEMM_MID_SK="4096x14336=5:4" = gemm_kernel_mid configuration 5 with 4 K ranges for that N x K)
+  int sk_cfg = 0, sk_splits = 0;
+  if (const char* e = getenv("PCY_GEMM_MID_SK")) {
+    char key[48];
+    snprintf(key, sizeof(key), "%dx%d=", a.N, a.K);
+    const char* hit = strstr(e, key);
+    if (hit && (hit == e || hit[-1] == ',')) {
+      sk_cfg = atoi(hit + strlen(key));
+      const char* c = strchr(hit, ':');
+      sk_splits = c ? atoi(c + 1) : 0;
+    }
+  }
+  if (a.mid_cfg <= 0 && a.splitk_ws && (a.epi == EPI_STORE || a.epi == EPI_RESID) && a.rope_cos == nullptr && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (a.resid == nullptr || a.ldr % 4 == 0)) {
     const int tiles = ((a.M + BM - 1) / BM) * tiles_n;
     // the split count depends on (N, K) only -- sized for four row tiles (one 512-token prompt) -- so that a row's result
@@ -1663,9 +1707,20 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     int splits = 1;
     if (big_rule) while (splits < 8 && tiles_ref * splits * 2 <= 256 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
     else while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    // (a 2-way split buys less than its finish launch costs: Llama-3-8B qkv at one 512-token prompt 41.3 + 6.4 us split vs 41.9 us as one
+    // gemm_kernel_mid launch -- and the rule stays a function of (N, K) only)
+    if (splits == 2 && !big_rule) splits = 1;
+    if (sk_cfg > 0 && sk_splits > 0 && a.K % (sk_splits * 64) == 0) splits = sk_splits;
     if (splits > 1 && (size_t)splits * a.M * a.N * 4 <= a.splitk_ws_bytes) {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_SPLITK];
-      if (big_rule && a.M > 256) {
+      bool mid_done = false;
+      if (sk_cfg > 0) {
+        PcyGemmArgs b = a;
+        b.splits = splits;
+        mid_done = launch_mid<EPI_STORE, true>(s, b, sk_cfg);
+      }
+      if (mid_done) {
+      } else if (big_rule && a.M > 256) {
         constexpr int smem = 2 * (256 + 256) * 64 * 2;
         static bool configured = false;
         if (!configured) {

@@ -22,20 +22,20 @@
 template <int N>
 __device__ __forceinline__ void mid_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int LEFT, int PPS, class F>
-__device__ __forceinline__ void mid_tail(int& kt, int nk, F&& compute) {
-  if (nk - 1 - kt == LEFT) {
-    mid_wait_vmcnt<LEFT * PPS>();
-    __builtin_amdgcn_s_barrier();
-    compute(kt);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ++kt;
+// s_waitcnt vmcnt(left * PPS) for a run-time `left` in [0, MAXL] (the immediate has to be a constant: a chain of compares that
+// folds away where `left` is an unrolled loop variable)
+template <int PPS, int MAXL>
+__device__ __forceinline__ void mid_wait_left(int left) {
+  if constexpr (MAXL >= 0) {
+    if (left == MAXL) { mid_wait_vmcnt<MAXL * PPS>(); return; }
+    mid_wait_left<PPS, MAXL - 1>(left);
   }
-  if constexpr (LEFT > 0) mid_tail<LEFT - 1, PPS>(kt, nk, compute);
 }
 
+// (the body is a __device__ function: buffer-resource builtins written directly inside a __global__ template make the HOST pass drop the
+// kernel's stub without a diagnostic -- undefined symbol at load time)
 template <int EPI, int TM, int TN, int WM, int WN, int S, bool SPLITK>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) {
+__device__ __forceinline__ void gemm_mid_body(const PcyGemmArgs& a) {
   constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
   constexpr int FM = TM / WM / 16, FN = TN / WN / 16;            // MFMA tiles per wave: FM token tiles x FN feature tiles
   constexpr int TILE_A = TM * BK * 2, TILE_W = TN * BK * 2, STAGE = TILE_A + TILE_W;
@@ -124,7 +124,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   // tail: the last min(nk, S - 1) stages, nothing left to issue; stage kt has landed when only the nk - 1 - kt younger ones are in flight
-  mid_tail<S - 2, PPS>(kt, nk, compute);
+#pragma unroll
+  for (int left = S - 2; left >= 0; --left) {
+    if (nk - 1 - kt == left) {
+      mid_wait_left<PPS, S - 2>(left);
+      __builtin_amdgcn_s_barrier();
+      compute(kt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++kt;
+    }
+  }
 
   if constexpr (SPLITK) {   // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
     float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
@@ -151,6 +160,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) {
   }
   gemm_epilogue<EPI, FN, FM, (FN % 4 == 0)>(a, acc, m0, n0, wm, wn, fr, fq);
 }
+template <int EPI, int TM, int TN, int WM, int WN, int S, bool SPLITK>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) { gemm_mid_body<EPI, TM, TN, WM, WN, S, SPLITK>(a); }
 
 // configurations (id -> TM, TN, WM, WN, S); LDS = S x (TM + TN) x 128 B <= 160 KiB
 #define PCY_MID_CONFIGS(X)                                                                                        \

@@ -1,4 +1,4 @@
-"""Data-parallel retrieval embedding (BASELINE config 3).
+"""Data-parallel retrieval embedding (BASELINE config 3) and row-split generation / pair scoring (configs 4, 5); SURVEY.md section 8e.
 
 Proteins are independent units, so the target set is cut into contiguous chunks of ceil(N/W) per rank (the tail
 padded by wrap-around so every rank holds the same count), each rank embeds its chunk with no data-path
@@ -7,6 +7,11 @@ rebuilds the [N, D] matrix in the original order on every rank.  These are the s
 `SequentialDistributedSampler` (/root/reference/procyon/data/samplers.py:154-196) + gather at
 /root/reference/procyon/training/trainIT.py:1594-1610 (whose receive list aliases ONE buffer W times, :1604;
 the evident intent -- W distinct slots in rank order -- is what is built).
+
+Generation and pair scoring do not shard a row: the B rows of a batch are split across the ranks the same way (contiguous chunks in
+rank order, wrap-around tail), every rank runs its rows with the 8B weights replicated, no cross-GPU traffic inside the loop, and ONE
+final all-gather collects the token ids / probabilities (`run_sharded_rows`; SURVEY.md section 8e "split the B rows across GPUs ...
+optional final gather of token ids").
 """
 from __future__ import annotations
 
@@ -103,3 +108,37 @@ def embed_sharded(model_or_fn, token_fn, n_total, batch_size=None, rank=None, wo
     full = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
     td.all_gather_into_tensor(full, local, group=group)   # host tensors (gloo): torch's collective
     return full[:n_total]
+
+
+def all_gather_rows(local, n_total, group=None):
+    """[n_local, ...] on every rank (equal n_local) -> [n_total, ...] in rank order on every rank: the path's one collective.
+    Device tensors under backend "nccl" go through the C ABI (`pcy_allgather`: RCCL over xGMI on the engine's stream, any dtype --
+    it moves bytes); host tensors (gloo) through torch's collective; without a process group the input is returned."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()):
+        return local[:n_total]
+    local = local.contiguous()
+    if local.is_cuda and td.get_backend(group) == "nccl":
+        return _comm_for(group).all_gather(local)[:n_total]
+    world = td.get_world_size(group)
+    full = torch.empty(world * local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
+    td.all_gather_into_tensor(full, local, group=group)
+    return full[:n_total]
+
+
+def run_sharded_rows(row_fn, n_rows, rank=None, world=None, group=None):
+    """Split rows [0, n_rows) of a batch across the process group (`shard_indices`: contiguous, rank order, wrap-around tail so
+    every rank runs the same count), call row_fn(list_of_row_indices) -> tensor [len(idx), ...] on this rank's rows, and return
+    the [n_rows, ...] result on every rank after ONE all-gather.  BASELINE configs[3]: the 32 generation rows over 1 -> 8 GPUs."""
+    import torch.distributed as td
+    dist = td.is_available() and td.is_initialized()
+    if world is None:
+        world = td.get_world_size(group) if dist else 1
+    if rank is None:
+        rank = td.get_rank(group) if dist else 0
+    mine = shard_indices(n_rows, rank, world)
+    local = row_fn(mine)
+    assert local.shape[0] == len(mine), (local.shape, len(mine))
+    if world == 1 and not dist:
+        return local[:n_rows]
+    return all_gather_rows(local, n_rows, group)

@@ -24,7 +24,9 @@ def _words(n, salt):
     return [f"w{(salt + 31 * i) % 50000}" for i in range(n)]
 
 
-def config4_inputs(ragged=False, rows=32, seed=7):
+def config4_inputs(ragged=False, rows=32, seed=7, subset=None):
+    """The `rows` synthetic rows of config 4 (always drawn for the WHOLE batch, so a rank that runs `subset` of them sees exactly the
+    rows the single-GPU run gives those indices); make() builds the input dict of the subset (default: all rows)."""
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(256, 2049, (rows,), generator=g).tolist()
     prot = synth.protein_tokens(lens, seed=seed)
@@ -33,29 +35,60 @@ def config4_inputs(ragged=False, rows=32, seed=7):
     for b in range(rows):
         n = plen[b] - 2                      # words + <|protein|> + [ANSWER]
         instr.append(" ".join(_words(n // 2, 17 * b) + ["<|protein|>"] + _words(n - n // 2, 13 * b + 5)) + " [ANSWER]")
+    sel = list(range(rows)) if subset is None else list(subset)
 
     def make():
-        return {"data": {"seq": prot.clone(), "seq_idx": torch.arange(rows), "text": [], "drug": None},
-                "input": {"seq": [[b] for b in range(rows)], "text": [[] for _ in range(rows)], "drug": None},
-                "target": {"seq": None, "text": None, "drug": None}, "instructions": list(instr)}
+        return {"data": {"seq": prot[torch.tensor(sel)].clone(), "seq_idx": torch.arange(len(sel)), "text": [], "drug": None},
+                "input": {"seq": [[b] for b in range(len(sel))], "text": [[] for _ in sel], "drug": None},
+                "target": {"seq": None, "text": None, "drug": None}, "instructions": [instr[b] for b in sel]}
     return make, lens, plen
 
 
-def run_config4(model, new_tokens=512, ragged=False, rows=32):
-    make, lens, plen = config4_inputs(ragged, rows)
+def run_config4(model, new_tokens=512, ragged=False, rows=32, group=None):
+    """One GPU: the whole batch.  Under a process group (bench.py --gpus N): the `rows` rows split across the ranks
+    (`distributed.run_sharded_rows`: contiguous chunks in rank order, /root/reference/procyon/data/samplers.py:154-196), every rank
+    generates its rows, one all-gather of the int32 token ids; the time is the slowest rank's (barrier on both sides)."""
+    import torch.distributed as td
+    from .distributed import run_sharded_rows, shard_indices
+    dist = td.is_available() and td.is_initialized()
+    world = td.get_world_size(group) if dist else 1
+    rank = td.get_rank(group) if dist else 0
+    _, lens, plen = config4_inputs(ragged, rows)
+    dev = model.text_encoder.engine.device
+
+    def gen(idx):
+        make, _, _ = config4_inputs(ragged, rows, subset=idx)
+        toks, *_ = model.generate(make(), max_len=new_tokens, method="greedy")
+        assert toks.shape == (len(idx), 1, new_tokens)
+        t = toks.to(torch.int32)
+        return t.to(dev) if dist and td.get_backend(group) == "nccl" else t
+
+    def barrier():
+        if dist:
+            td.barrier(group)
+        _sync()
     # warm-up = the same call: besides first-launch effects it makes the host allocator hold the pinned logits record of this shape
     # ([new_tokens, rows, vocab] bf16 = 4.2 GB at 32 x 512, written by the decode steps themselves because the reference returns the
     # per-step logits on the CPU); its first allocation costs ~0.4 s, every later call of a serving loop reuses it
-    model.generate(make(), max_len=new_tokens, method="greedy")
-    _sync()
+    gen(shard_indices(rows, rank, world))
+    barrier()
     t0 = time.perf_counter()
-    toks, *_ = model.generate(make(), max_len=new_tokens, method="greedy")
-    _sync()
+    toks = run_sharded_rows(gen, rows, rank, world, group)
+    barrier()
     dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev if td.get_backend(group) == "nccl" else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.MAX, group=group)
+        dt = float(t)
     assert toks.shape == (rows, 1, new_tokens)
-    return {"rows": rows, "residues_min_max": [min(lens), max(lens)], "protein_chunks": int(sum((n + 1023) // 1024 for n in lens)),
-            "prompt_tokens": "ragged %d-%d, left-padded" % (min(plen), max(plen)) if ragged else 512, "new_tokens": new_tokens,
-            "seconds": round(dt, 3), "tokens_per_s": round(rows * new_tokens / dt, 1)}
+    out = {"rows": rows, "residues_min_max": [min(lens), max(lens)], "protein_chunks": int(sum((n + 1023) // 1024 for n in lens)),
+           "prompt_tokens": "ragged %d-%d, left-padded" % (min(plen), max(plen)) if ragged else 512, "new_tokens": new_tokens,
+           "seconds": round(dt, 3), "tokens_per_s": round(rows * new_tokens / dt, 1)}
+    if dist:
+        out.update(rows_per_rank=len(shard_indices(rows, rank, world)), ranks=world, scaling="strong (32 rows split across the ranks)",
+                   collective="one all-gather of the int32 token ids" + (" (RCCL through pcy_allgather)" if td.get_backend(group) == "nccl" else ""),
+                   token_checksum=int(toks.to(torch.int64).sum()))
+    return out
 
 
 def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
@@ -96,19 +129,22 @@ def config5_inputs(pairs=256, chunk=64, seed=7):
     tmpl = (" ".join(_words(140, 1)) + " <|protein|> binds <|protein|> ? [ANSWER] yes " + " ".join(_words(140, 2)) +
             " <|protein|> binds <|protein|> ? [ANSWER] no " + " ".join(_words(140, 3)) + " <|protein|> binds <|protein|> ? [ANSWER]")
 
-    def make(lo):
+    def make(lo, cnt=None):
+        cnt = chunk if cnt is None else cnt
         return {"data": {"seq": prot.clone(), "seq_idx": torch.arange(prot.shape[0]), "text": [], "drug": None},
-                "input": {"seq": [[0, 1, 0, 2, 0, 3 + lo + i] for i in range(chunk)], "text": [[] for _ in range(chunk)], "drug": None},
-                "target": {"seq": None, "text": None, "drug": None}, "instructions": [tmpl] * chunk}
+                "input": {"seq": [[0, 1, 0, 2, 0, 3 + lo + i] for i in range(cnt)], "text": [[] for _ in range(cnt)], "drug": None},
+                "target": {"seq": None, "text": None, "drug": None}, "instructions": [tmpl] * cnt}
     return make, len(tmpl.split())
 
 
-def score_pairs(model, pairs=256, chunk=64):
-    """-> (P(yes), P(no)) [pairs, 2] fp32 and a 1/61 sample of every answer-row logit vector"""
+def score_pairs(model, pairs=256, chunk=64, first=0, count=None):
+    """-> (P(yes), P(no)) [count, 2] fp32 and a 1/61 sample of every answer-row logit vector, for pairs [first, first + count) of the
+    `pairs`-pair workload (default: all of them), `chunk` prompts per forward call"""
     make, _ = config5_inputs(pairs, chunk)
+    count = pairs if count is None else count
     ys, ls = [], []
-    for lo in range(0, pairs, chunk):
-        lg = model.forward(make(lo), retrieval=False)["outputs"].logits[:, 0].float()
+    for lo in range(first, first + count, chunk):
+        lg = model.forward(make(lo, min(chunk, first + count - lo)), retrieval=False)["outputs"].logits[:, 0].float()
         p = lg.softmax(-1)
         ys.append(torch.stack([p[:, model.yes_token], p[:, model.no_token]], 1))
         ls.append(lg[:, ::61].clone())
@@ -130,9 +166,18 @@ def damp_residual_branches(model, scale):
     eng._keep8 = []
 
 
-def run_config5(model, pairs=256, chunk=64, fp8=True):
+def run_config5(model, pairs=256, chunk=64, fp8=True, group=None):
     """pairs/s with bf16 weights and on the fp8 weight path, algorithmic TFLOP/s of the Llama prefill part (2 * params * tokens
-    + attention), and how far the fp8 path's answers are from the bf16 path's"""
+    + attention), and how far the fp8 path's answers are from the bf16 path's.  Under a process group the pairs are split across the
+    ranks (contiguous chunks, rank order) and the [pairs, 2] probabilities gathered once ("split pairs")."""
+    import torch.distributed as td
+    from .distributed import all_gather_rows, shard_indices
+    dist = td.is_available() and td.is_initialized()
+    world = td.get_world_size(group) if dist else 1
+    rank = td.get_rank(group) if dist else 0
+    assert pairs % world == 0, "pair scoring splits an equal number of pairs to every rank"
+    mine = shard_indices(pairs, rank, world)
+    first, count = mine[0], len(mine)
     eng = model.text_encoder.engine
     cfg = eng.cfg
     _, T = config5_inputs(pairs, chunk)
@@ -140,16 +185,26 @@ def run_config5(model, pairs=256, chunk=64, fp8=True):
     for mode in (("bf16", "fp8") if fp8 else ("bf16",)):
         if mode == "fp8":
             eng.quantize_fp8()
-        score_pairs(model, chunk, chunk)
+        score_pairs(model, pairs, chunk, first, min(chunk, count))
         _sync()
         best = None
         for _ in range(2):          # two passes, the faster one is reported (a shared box now and then loses a third of a pass)
+            if dist:
+                td.barrier(group)
+            _sync()
             t0 = time.perf_counter()
-            y, lg = score_pairs(model, pairs, chunk)
+            y, lg = score_pairs(model, pairs, chunk, first, count)
+            if dist:
+                y, lg = all_gather_rows(y, world * count, group), all_gather_rows(lg, world * count, group)
+                td.barrier(group)
             _sync()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        out[mode] = (y.cpu(), best, lg.cpu())
+        if dist:
+            t = torch.tensor([best], device=y.device)
+            td.all_reduce(t, op=td.ReduceOp.MAX, group=group)
+            best = float(t)
+        out[mode] = (y.cpu()[:pairs], best, lg.cpu()[:pairs])
     if fp8:
         eng.set_fp8(False)
     per_tok = 2 * cfg.n_layers * (cfg.d * (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.head_dim + cfg.n_heads * cfg.head_dim * cfg.d + 3 * cfg.d * cfg.ffn)
@@ -163,4 +218,7 @@ def run_config5(model, pairs=256, chunk=64, fp8=True):
                     "answer_logits_rel_err_fp8_vs_bf16": round(float((l8 - l16).norm() / l16.norm()), 4),
                     "yes_no_agreement_fp8_vs_bf16": round(float(((y16[:, 0] > y16[:, 1]) == (y8[:, 0] > y8[:, 1])).float().mean()), 4),
                     "mean_abs_dP_yes": float((y8[:, 0] - y16[:, 0]).abs().mean())})
+    if dist:
+        res.update(ranks=world, pairs_per_rank=count, scaling="strong (the pairs split across the ranks)",
+                   collective="one all-gather of the [pairs, 2] probabilities")
     return res

@@ -43,3 +43,61 @@ def test_single_pass_attention_is_launch_to_launch_bit_stable():
     ref = eng.hidden_states(toks).clone()
     for _ in range(24):
         assert torch.equal(eng.hidden_states(toks), ref)
+
+
+# ---------------------------------------------------------------------------------------------- gemm_kernel_mid (pcy_gemm_mid.h)
+@pytest.fixture(scope="module")
+def ctx():
+    from procyon_amd.engine import Context
+    return Context.get()
+
+
+def _rnd(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(BF)
+
+
+def _mid_count(ctx):
+    from procyon_amd import _lib as L
+    return int(ctx.lib.pcy_debug_dispatch_count(L.DISPATCH_GEMM_MID))
+
+
+@pytest.mark.parametrize("epi", [0, 1, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 1280), (1026, 1280, 5120), (1026, 3840, 1280), (2047, 1280, 1280), (512, 4096, 4096), (333, 992, 192)])
+def test_mid_m_gemm_is_dispatched_and_bit_identical_to_the_small_tile_kernels(ctx, monkeypatch, M, N, K, epi):
+    """128 <= M < 2048 below a full round of 256 x 256 tiles (one 1024-residue protein: /root/reference/procyon/model/esm.py:517-538 at
+    batch 1; one 512-token prompt: /root/reference/procyon/model/pmc_llama.py:571-588): the launcher takes gemm_kernel_mid (asserted)
+    and the result is BIT-identical to the 128 x 128 / 64 x 64 kernels it replaces (PCY_GEMM_MID=-1) -- same k order per element, so
+    the encoder's packing invariance carries over.  (Those kernels are held to the oracle by test_gpu_kernels.py::test_gemm, which
+    now reaches the mid kernel at four of its five shapes as well.)"""
+    from procyon_amd.engine import interleave_gate_up
+    A, W, b, r = _rnd(M, K, seed=1), _rnd(N, K, seed=2, std=0.05), _rnd(N, seed=3, std=0.1), _rnd(M, N, seed=4)
+    if epi == 4:
+        Wd, bias, res = interleave_gate_up(W[: N // 2].contiguous().cuda(), _rnd(N // 2, K, seed=5, std=0.05).cuda()), None, None
+    else:
+        Wd, bias, res = W.cuda(), b.cuda(), (r.cuda() if epi == 1 else None)
+    monkeypatch.delenv("PCY_GEMM_MID", raising=False)
+    n0 = _mid_count(ctx)
+    out = ctx.gemm(A.cuda(), Wd, bias, res, epi)
+    assert _mid_count(ctx) == n0 + 1
+    monkeypatch.setenv("PCY_GEMM_MID", "-1")
+    old = ctx.gemm(A.cuda(), Wd, bias, res, epi)
+    assert _mid_count(ctx) == n0 + 1
+    assert torch.equal(out, old)
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 13)))
+def test_every_mid_m_configuration_is_bit_identical(ctx, monkeypatch, cfg):
+    """all tile shapes / wave layouts / ring depths of gemm_kernel_mid on a ragged problem (M, N not multiples of any tile; 5 k-steps:
+    shorter than the deepest ring), residual epilogue, against the 128 x 128 kernel"""
+    M, N, K = 777, 1096, 320
+    A, W, b, r = _rnd(M, K, seed=1).cuda(), _rnd(N, K, seed=2, std=0.05).cuda(), _rnd(N, seed=3, std=0.1).cuda(), _rnd(M, N, seed=4).cuda()
+    monkeypatch.setenv("PCY_GEMM_MID", "-1")
+    ref = ctx.gemm(A, W, b, r, 1)
+    monkeypatch.setenv("PCY_GEMM_MID", str(cfg))
+    n0 = _mid_count(ctx)
+    out = ctx.gemm(A, W, b, r, 1)
+    assert _mid_count(ctx) == n0 + 1
+    assert torch.equal(out, ref)
+    for _ in range(8):          # the counted-vmcnt ring: launch-to-launch stable
+        assert torch.equal(ctx.gemm(A, W, b, r, 1), ref)

@@ -18,7 +18,11 @@ cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,3,4,5,6,7,8,9,10,11,12").spl
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, K, epi in shapes:
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    # COLD weights, as inside the encoder / the prefill (every layer has its own): rotate over enough copies to outgrow the 256 MiB
+    # Infinity Cache, so that every launch streams its W panels from HBM; the activations stay hot (the previous kernel wrote them)
+    nW = max(2, min(96, int(700e6 / (N * K * 2)) + 1)) if os.environ.get("COLD", "1") != "0" else 1
+    Ws = [(torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16() for _ in range(nW)]
+    W = Ws[0]
     bias = (torch.randn(N, device="cuda", generator=g) * 0.1).bfloat16() if epi != L.EPI_SWIGLU else None
     Nout = N // 2 if epi == L.EPI_SWIGLU else N
     resid = torch.randn(M, Nout, device="cuda", generator=g).bfloat16() if epi == L.EPI_RESID else None
@@ -35,12 +39,12 @@ for name, M, N, K, epi in shapes:
     for rnd in range(5):
         for c in [0] + cfgs:
             os.environ["PCY_GEMM_MID"] = str(c)
-            for _ in range(2): ctx.gemm(A, W, bias, resid, epi, out=out)
-            ctx.timer_start(); n = 20
-            for _ in range(n): ctx.gemm(A, W, bias, resid, epi, out=out)
+            for i in range(2): ctx.gemm(A, Ws[i % nW], bias, resid, epi, out=out)
+            ctx.timer_start(); n = 24
+            for i in range(n): ctx.gemm(A, Ws[(i + 2) % nW], bias, resid, epi, out=out)
             times[c].append(ctx.timer_stop() / n * 1e3)
     fl = 2.0 * M * N * K
-    print(f"--- {name}: M={M} N={N} K={K} epi={epi}")
+    print(f"--- {name}: M={M} N={N} K={K} epi={epi}  ({nW} weight copies)")
     for c in [0] + cfgs:
         t = statistics.median(times[c])
         print(f"  cfg {c:2d}: {t:7.1f} us (min {min(times[c]):7.1f})  {fl / t / 1e6:7.1f} TF/s  {'' if c == 0 else ('bit-equal' if ok[c] else 'DIFFERS')}", flush=True)
