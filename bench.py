@@ -195,6 +195,20 @@ def main():
     pre_ms = ctx.timer_stop() / 5
     phases.update(prefill_kernels_ms=pre_ms, prefill_TFLOPs=prefill_flop / 1e12 / (pre_ms / 1e3),
                   prefill_mfma_frac_of_2500TF=prefill_flop / 1e12 / (pre_ms / 1e3) / 2500.0)
+    # the encoder alone, HIP events (ESM2 over the one protein + pooling; `encode_project_splice_ms` above is wall clock and includes the
+    # host side: tokenising, packing, the projector and the splice)
+    esm_eng = model.protein_seq_encoder.engine
+    for _ in range(3):
+        esm_eng.forward(prot)
+    ctx.timer_start()
+    for _ in range(5):
+        esm_eng.forward(prot)
+    enc_ms = ctx.timer_stop() / 5
+    S_ = a.residues + 2
+    enc_flop = (2 * 648806400 * S_ + 168960 * S_ * S_) if a.geometry == "full" else None
+    phases.update(encode_kernels_ms=enc_ms)
+    if enc_flop:
+        phases.update(encode_TFLOPs=enc_flop / 1e12 / (enc_ms / 1e3), encode_mfma_frac_of_2500TF=enc_flop / 1e12 / (enc_ms / 1e3) / 2500.0)
     logits, _ = eng.prefill(emb, mask, cache, "last")
     st.logits.copy_(logits); st.pos.fill_(a.prompt)
     eng.pick(cache, st, 1, advance_pos=False)

@@ -69,6 +69,21 @@ struct pcy_ctx {
   char* beam_ws = nullptr;            // scratch of pcy_beam_step (its own allocation: never aliases the decode workspace)
   size_t beam_ws_bytes = 0;
 
+  // Replayed launch chains of the short-sequence encoder (pcy_esm_encode of ONE protein = 230 launches of 5-35 us: on a busy host the
+  // launch rate, not the GPU, sets the time -- measured 6.1 to 11 ms per call across gpurun boxes for 4.8 ms of kernels).  A slot is keyed
+  // on every pointer and size that is baked into the launches; a key is captured the SECOND time it is seen (a stream of proteins of
+  // ever-changing length never pays for captures it would not reuse).
+  struct GraphSlot { uint64_t key[16]; hipGraphExec_t exec; unsigned long long stamp; };
+  static constexpr int N_GSLOTS = 8;
+  GraphSlot gslots[N_GSLOTS] = {};
+  unsigned long long gstamp = 0;
+  void drop_gslots() {
+    for (auto& g : gslots) {
+      if (g.exec) hipGraphExecDestroy(g.exec);
+      g = GraphSlot{};
+    }
+  }
+
   int reserve(size_t bytes) {
     // PCY_DEBUG_POISON_WS=1 (tests): fill the workspace with NaN patterns before every use -- a kernel that reads a workspace
     // location before writing it then fails deterministically instead of depending on what the allocator handed out
@@ -81,6 +96,7 @@ struct pcy_ctx {
       ws = nullptr; ws_bytes = 0;
     }
     drop_graph();
+    drop_gslots();
     bytes = align_up(bytes + (bytes >> 3), 1 << 20);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws), bytes));
     ws_bytes = bytes;
@@ -535,6 +551,7 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (!c) return;
   hipStreamSynchronize(c->stream);
   c->drop_graph();
+  c->drop_gslots();
   if (c->ws) hipFree(c->ws);
   if (c->xwg_err) hipHostFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
@@ -850,9 +867,89 @@ int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, voi
   return check_launch("pcy_mlp_forward");
 }
 
+static int esm_encode_enqueue(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
+                              const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out);
+// tokens at or below which pcy_esm_encode replays a captured launch chain (PCY_ESM_GRAPH=0: always launch by launch; read per call)
+static int esm_graph_max_tokens() {
+  const char* e = getenv("PCY_ESM_GRAPH");
+  if (e && atoi(e) == 0) return 0;
+  return (e && atoi(e) > 1) ? atoi(e) : 4200;
+}
 int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                    const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {
   PCY_STICKY(c);
+  if (ntok <= 0 || ntok > esm_graph_max_tokens() || !c->cap_stream)
+    return esm_encode_enqueue(c, m, tokens, pos, cu, vt_cu, ntok, nseq, max_len, vt_total, mask_pads, hidden_out);
+  // everything a launch of the chain bakes in: argument pointers, sizes, the model's arrays, the workspace base, and the run-time
+  // switches that select kernels (read per launch from the environment: a changed switch is another key)
+  auto envh = [](const char* n) { const char* e = getenv(n); uint64_t h = 1469598103934665603ull; for (; e && *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ull; return h; };
+  uint64_t key[16] = {(uint64_t)(uintptr_t)tokens, (uint64_t)(uintptr_t)pos, (uint64_t)(uintptr_t)cu, (uint64_t)(uintptr_t)vt_cu,
+                      (uint64_t)(uintptr_t)hidden_out, (uint64_t)(uintptr_t)m->layers, (uint64_t)(uintptr_t)m->embed,
+                      ((uint64_t)(uint32_t)ntok << 32) | (uint32_t)nseq, ((uint64_t)(uint32_t)max_len << 32) | (uint32_t)vt_total,
+                      ((uint64_t)(uint32_t)m->d << 32) | (uint32_t)m->ffn, ((uint64_t)(uint32_t)m->n_layers << 32) | (uint32_t)m->n_heads,
+                      (uint64_t)mask_pads | ((uint64_t)m->rope_mode << 8), 0 /* workspace base, below */,
+                      envh("PCY_ESM_ATTN") ^ (envh("PCY_FA_VROW") << 1), envh("PCY_GEMM_MID") ^ (envh("PCY_GEMM_PERM") << 1) ^ (envh("PCY_GEMM_STG") << 2),
+                      envh("PCY_GELU_SELECT") ^ (envh("PCY_ROPE_VSKIP") << 1) ^ (envh("PCY_DEBUG_POISON_WS") << 2)};
+  // the workspace is sized (and possibly re-allocated: every slot is dropped then) before the key is final
+  {
+    const int d = m->d, F = m->ffn;
+    const size_t vtt = align_up((size_t)ntok + 64 * (size_t)nseq, 8) > (size_t)vt_total ? align_up((size_t)ntok + 64 * (size_t)nseq, 8) : (size_t)vt_total;
+    const size_t need = align_up((size_t)ntok * d * 2, 256) * 3 + align_up((size_t)ntok * 3 * d * 2, 256) + align_up((size_t)ntok * F * 2, 256) +
+                        align_up((size_t)d * vtt * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096;
+    if (int r = c->reserve(need)) return r;
+  }
+  key[12] = (uint64_t)(uintptr_t)c->ws;
+  pcy_ctx::GraphSlot* slot = nullptr;
+  for (auto& g : c->gslots)
+    if (g.stamp && memcmp(g.key, key, sizeof(key)) == 0) { slot = &g; break; }
+  if (slot && slot->exec) {
+    slot->stamp = ++c->gstamp;
+    ++g_pcy_dispatch[PCY_DISPATCH_ESM_GRAPH];
+    HIP_TRY(hipGraphLaunch(slot->exec, c->stream));
+    return 0;
+  }
+  if (!slot) {   // first sight of this key: remember it (evicting the least recently used slot), run launch by launch
+    slot = &c->gslots[0];
+    for (auto& g : c->gslots)
+      if (g.stamp < slot->stamp) slot = &g;
+    if (slot->exec) hipGraphExecDestroy(slot->exec);
+    *slot = pcy_ctx::GraphSlot{};
+    memcpy(slot->key, key, sizeof(key));
+    slot->stamp = ++c->gstamp;
+    return esm_encode_enqueue(c, m, tokens, pos, cu, vt_cu, ntok, nseq, max_len, vt_total, mask_pads, hidden_out);
+  }
+  // second sight: capture (on the capture stream -- the caller's may be the legacy stream), then replay on the caller's stream
+  pcy_gemm_prepare(c->stream);   // one-time device tables must not be built inside the capture
+  hipGraph_t g = nullptr;
+  hipStream_t user = c->stream;
+  c->stream = c->cap_stream;
+  hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+  int rc = 0;
+  if (e0 == hipSuccess) {
+    rc = esm_encode_enqueue(c, m, tokens, pos, cu, vt_cu, ntok, nseq, max_len, vt_total, mask_pads, hidden_out);
+    e0 = hipStreamEndCapture(c->cap_stream, &g);
+  }
+  c->stream = user;
+  if (e0 != hipSuccess || rc != 0 || !g) {   // could not capture: forget the key, run launch by launch
+    (void)hipGetLastError();
+    if (g) hipGraphDestroy(g);
+    *slot = pcy_ctx::GraphSlot{};
+    return esm_encode_enqueue(c, m, tokens, pos, cu, vt_cu, ntok, nseq, max_len, vt_total, mask_pads, hidden_out);
+  }
+  e0 = hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e0 != hipSuccess) {
+    (void)hipGetLastError();
+    *slot = pcy_ctx::GraphSlot{};
+    return esm_encode_enqueue(c, m, tokens, pos, cu, vt_cu, ntok, nseq, max_len, vt_total, mask_pads, hidden_out);
+  }
+  slot->stamp = ++c->gstamp;
+  ++g_pcy_dispatch[PCY_DISPATCH_ESM_GRAPH];
+  HIP_TRY(hipGraphLaunch(slot->exec, c->stream));
+  return 0;
+}
+static int esm_encode_enqueue(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
+                              const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {
   const int d = m->d, H = m->n_heads, F = m->ffn;
   if (d % H) return fail(1, "pcy_esm_encode: d %% heads");
   const int dh = d / H;

@@ -1650,6 +1650,16 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
 
 }  // namespace
 
+void pcy_gemm_prepare(hipStream_t s) {
+  static bool lut_built[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !lut_built[dev]) {   // once per device, on the caller's stream (ordered before the first use)
+    hipLaunchKernelGGL(gelu_lut_build_kernel, dim3((GELU_LUT_N + 255) / 256), dim3(256), 0, s);
+    lut_built[dev] = true;
+  }
+}
+
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (a0.M <= 0 || a0.N <= 0) return;
   PcyGemmArgs a = a0;
@@ -1755,13 +1765,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     case EPI_RESID: launch<EPI_RESID>(s, a); break;
     case EPI_GELU_ERF: launch<EPI_GELU_ERF>(s, a); break;
     case EPI_GELU_ESM: {
-      static bool lut_built[64] = {};
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      if (dev >= 0 && dev < 64 && !lut_built[dev]) {   // once per device, on the caller's stream (ordered before the first use)
-        hipLaunchKernelGGL(gelu_lut_build_kernel, dim3((GELU_LUT_N + 255) / 256), dim3(256), 0, s);
-        lut_built[dev] = true;
-      }
+      pcy_gemm_prepare(s);
       launch<EPI_GELU_ESM>(s, a);
       break;
     }

@@ -109,9 +109,12 @@ struct PcyGemmArgs {
   int mid_cfg;          // > 0: this configuration of gemm_kernel_mid (pcy_gemm_mid.h); 0: the launcher's own choice
 };
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
+// builds the one-time device tables of the GEMM epilogues (the ESM GELU table) on `s` if this device has none yet -- callers that
+// CAPTURE a chain of launches call it first, so that the build is not recorded into the graph
+void pcy_gemm_prepare(hipStream_t s);
 // launch counters per kernel family (pcy_debug_dispatch_count)
 enum { PCY_DISPATCH_GEMM_128 = 0, PCY_DISPATCH_GEMM_64 = 1, PCY_DISPATCH_GEMM_BIG = 2, PCY_DISPATCH_GEMM_BIG_PERSIST = 3,
-       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_BD_CHAIN = 7, PCY_DISPATCH_GEMM_MID = 8, PCY_DISPATCH_N = 9 };
+       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_BD_CHAIN = 7, PCY_DISPATCH_GEMM_MID = 8, PCY_DISPATCH_ESM_GRAPH = 9, PCY_DISPATCH_N = 10 };
 extern unsigned long long g_pcy_dispatch[PCY_DISPATCH_N];
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)

@@ -301,8 +301,10 @@ class _Stager:
         self.events = [None] * self.SLOTS
         self.i = 0
 
-    def upload(self, arrays):
-        """arrays: CPU int32 tensors -> list of device int32 tensors (views of one device buffer, 256-byte aligned)."""
+    def upload(self, arrays, into=None):
+        """arrays: CPU int32 tensors -> list of device int32 tensors (views of one device buffer, 256-byte aligned).
+        `into`: a persistent device uint8 buffer to copy into instead of a fresh one (same sizes -> the views keep their addresses
+        from call to call: what a replayed launch chain needs)."""
         offs, total = [], 0
         for a in arrays:
             offs.append(total)
@@ -320,7 +322,7 @@ class _Stager:
         for a, o in zip(arrays, offs):
             n = a.numel() * 4
             host[o:o + n].view(torch.int32).copy_(a.contiguous().view(-1))
-        devbuf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        devbuf = torch.empty(total, dtype=torch.uint8, device=self.device) if into is None else into[:total]
         devbuf.copy_(host[:total], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
@@ -332,11 +334,11 @@ class _Stager:
 _stagers = {}
 
 
-def _h2d_many(arrays, dev):
+def _h2d_many(arrays, dev, into=None):
     dev = torch.device(dev)
     if dev.type != "cuda":
         return [a.to(dev) for a in arrays]
-    if os.environ.get("PCY_STAGER", "1") == "0":      # A/B: a pinned copy per array and call (the previous behaviour)
+    if into is None and os.environ.get("PCY_STAGER", "1") == "0":      # A/B: a pinned copy per array and call (the previous behaviour)
         outs = []
         for a in arrays:
             src = a.contiguous().pin_memory()
@@ -347,7 +349,7 @@ def _h2d_many(arrays, dev):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _stagers:
         _stagers[key] = _Stager(dev)
-    return _stagers[key].upload(arrays)
+    return _stagers[key].upload(arrays, into)
 
 
 class KVCache:
@@ -690,6 +692,7 @@ class EsmEngine:
         self.fw, self.fb = g("esm.encoder.emb_layer_norm_after.weight"), g("esm.encoder.emb_layer_norm_after.bias")
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.rope_theta, cfg.max_len, dev, cfg.rope_inv_freq_bf16)
         self._keep = []
+        self._enc_slots = {}
         arr = (L.EsmLayer * cfg.n_layers)()
         for l in range(cfg.n_layers):
             p = f"esm.encoder.layer.{l}."
@@ -712,6 +715,8 @@ class EsmEngine:
         self.desc = L.EsmDesc(cfg.d, cfg.n_layers, cfg.n_heads, cfg.ffn, cfg.vocab, cfg.ln_eps,
                               1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
                               self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
+
+    GRAPH_MAX_TOKENS = 4200     # = the engine's own bound (pcy_esm_encode, PCY_ESM_GRAPH)
 
     def preferred_batch(self, tokens_per_protein, lo=16, hi=40, n_cu=256):
         """Proteins per engine call for retrieval-style bulk encoding ("batch size chosen by the engine", BASELINE configs[2]).
@@ -756,12 +761,24 @@ class EsmEngine:
         if pk["max_len"] > self.cfg.max_len:
             raise ValueError(f"sequence of {pk['max_len']} tokens exceeds the rotary table ({self.cfg.max_len})")
         names = ("tokens", "pos", "cu", "vt_cu")
-        t = dict(zip(names, _h2d_many([pk[k] for k in names], dev)))
-        hidden = torch.empty(pk["ntok"], self.cfg.d, dtype=BF16, device=dev)
+        # Short inputs (one protein: 230 launches of 5-35 us) are replayed from a captured launch chain inside pcy_esm_encode, which
+        # needs the SAME device addresses from call to call: persistent index / output buffers per (tokens, sequences), a few shapes kept
+        slot = None
+        if dev.type == "cuda" and pk["ntok"] <= self.GRAPH_MAX_TOKENS:
+            key = (pk["ntok"], pk["nseq"])
+            slot = self._enc_slots.pop(key, None)
+            if slot is None:
+                nbytes = 2 * ((pk["ntok"] * 4 + 255) // 256 * 256) + 2 * (((pk["nseq"] + 1) * 4 + 255) // 256 * 256)
+                slot = dict(idx=torch.empty(nbytes, dtype=torch.uint8, device=dev), hidden=torch.empty(pk["ntok"], self.cfg.d, dtype=BF16, device=dev))
+            self._enc_slots[key] = slot                      # (most recently used last)
+            while len(self._enc_slots) > 8:
+                self._enc_slots.pop(next(iter(self._enc_slots)))
+        t = dict(zip(names, _h2d_many([pk[k] for k in names], dev, into=None if slot is None else slot["idx"])))
+        hidden = torch.empty(pk["ntok"], self.cfg.d, dtype=BF16, device=dev) if slot is None else slot["hidden"]
         L.check(self.ctx.lib.pcy_esm_encode(self.ctx.h, C.byref(self.desc), _p(t["tokens"]), _p(t["pos"]), _p(t["cu"]), _p(t["vt_cu"]),
                                             pk["ntok"], pk["nseq"], pk["max_len"], pk["vt_total"], int(mask_pads), _p(hidden)),
                 "pcy_esm_encode")
-        return hidden
+        return hidden if slot is None else hidden.clone()    # (the persistent buffer is rewritten by the next call of this shape)
 
     def hidden_states(self, rows, mask_pads=True):
         """rows int64 [B',S] -> padded [B',S,d] representations (pad slots zero-filled; test helper)."""
