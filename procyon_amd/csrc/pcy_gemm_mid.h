@@ -16,6 +16,10 @@
 //   * one workgroup per CU by LDS size; 4 or 8 waves;
 //   * same per-element arithmetic as every other bf16 GEMM here (16x16x32 MFMA over ascending k, fp32 accumulation, the shared
 //     epilogues): a row's bits do not depend on which kernel / tile shape computed it -- the packing invariance of the encoder holds.
+//   * (tried, dropped: a software-pipelined form -- fragments of the next 32-k sub-step read under the MFMAs of the current one, two
+//     register sets, the counted wait one stage earlier -- bit-identical and 8-25 % SLOWER at every shape (o 11.9 -> 13.6 us, fc2 33.9 ->
+//     40.4, fc1 28.0 -> 30.9, Llama qkv 41.0 -> 43.7): two waves per SIMD already cover each other's LDS latency, the earlier wait costs a
+//     stage of prefetch depth)
 //   * SPLITK: grid = tiles x a.splits, fp32 partial tiles to a.splitk_ws (finished by gemm_splitk_epilogue / the finish + norm kernel).
 #pragma once
 
