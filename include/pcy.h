@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 6
+#define PCY_ABI_VERSION 7
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -277,6 +277,39 @@ int pcy_beam_step(pcy_ctx*, const void* logits, int vocab, int B, int beam, int 
                   const pcy_beam_state* state);
 /* KV rows gather for beam search: cache[:, dst] = cache[:, src[dst]] over slots [0,t) (model_unified.py:830-832) */
 int pcy_kv_reorder(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const int32_t* src_rows, int B, int t);
+
+/* ---- fp32 operator family: the arithmetic of the reference's callers that never call `.bfloat16()` ----
+ * /root/reference/examples/paper_analyses/protpep_qa_scores.py:55-58 (`model.eval().to(device)`: fp32 weights, every torch op in
+ * fp32 -- the loop that defines BASELINE configs[4]), /root/reference/scripts/qa_filter_captions.py:17-18 and
+ * /root/reference/scripts/caption_bulk.py:72-73.  Every pointer is a DEVICE pointer to fp32 (ids / pos / cu: int32, keep: uint8);
+ * calls enqueue on the context's stream.  The host side (procyon_amd/engine_f32.py) strings these together op for op like the fp32
+ * evaluation of the reference's modules: ESM2 encoder (esm.py:504-538) -> ProteinPooler (:131-173) -> create_mlp projectors
+ * (model_utils.py:13-41) -> splice (model_unified.py:1135-1175) -> Llama prefill (pmc_llama.py:546-596).  Cached decode stays bf16. */
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ resid[M,N]); W is nn.Linear's [out, in]; act 0 = none, 1 = gelu
+ * x * 0.5 * (1 + erf(x / sqrt 2)) (nn.GELU and the ESM gelu coincide in fp32).  bias / resid may be NULL; resid may alias C.
+ * Matrix cores on exact fp32 products (v_mfma_f32_16x16x4_f32) when K % 16 == 0 and rows are 16-byte aligned, a plain kernel otherwise. */
+int pcy_f32_linear(pcy_ctx*, const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* C, int ldc,
+                   int M, int N, int K, int act);
+/* torch.nn.functional.layer_norm / HF LlamaRMSNorm (w * (x * rsqrt(mean(x^2) + eps))) over rows of d */
+int pcy_f32_layernorm(pcy_ctx*, const float* x, const float* w, const float* b, float* y, int rows, int d, float eps);
+int pcy_f32_rmsnorm(pcy_ctx*, const float* x, const float* w, float* y, int rows, int d, float eps);
+/* rotary embedding in place on heads [col0, col0 + nh*dh) of every row: x <- x' cos[pos] + rotate_half(x') sin[pos], x' = x * prescale
+ * (prescale 0 = none; ESM scales q by dh^-1/2 BEFORE the rotation, esm2 multihead attention); cos / sin tables fp32 [n_pos, dh] */
+int pcy_f32_rope(pcy_ctx*, float* buf, int ld, int col0, int nh, int dh, const int32_t* pos, const float* cos_t, const float* sin_t, int ntok,
+                 float prescale);
+/* out[r] = soft_map && soft_map[r] >= 0 ? soft[soft_map[r]] : table[ids[r]]: token embedding + soft-token splice as one gather */
+int pcy_f32_embed(pcy_ctx*, const float* table, const int32_t* ids, const float* soft, const int32_t* soft_map, float* out, int rows, int d);
+/* HF EsmEmbeddings with token_dropout over packed sequences (cu [nseq+1]): <mask> rows zero, x * 0.88 / (1 - mask ratio), pads zero */
+int pcy_f32_esm_embed(pcy_ctx*, const float* table, const int32_t* tokens, const int32_t* cu, int nseq, int max_len, float* out, int d, int mask_pads);
+int pcy_f32_silu_mul(pcy_ctx*, const float* gate, const float* up, float* out, size_t n);      /* out = silu(gate) * up */
+int pcy_f32_acc_rows(pcy_ctx*, const float* src, int ld, const int32_t* rows, float* dst, int nrows, int d);   /* dst[r] += src[rows[r]] */
+/* ProteinPooler over token ranges, arguments as pcy_pool (mode 0 mean, 1 mean of x[1:-1], 2 max) */
+int pcy_f32_pool(pcy_ctx*, const float* hidden, int d, const int32_t* seg, const int32_t* rng, int nprot, int mode, float* out);
+/* softmax((q . k) * scale + mask) . v over packed sequences (cu), grouped heads (Hkv | H), exact fp32 softmax; causal = 1: keys <= query;
+ * keep (may be NULL): one byte per packed token, 0 = the key is masked out.  q / k / v are column windows of row-major buffers. */
+int pcy_f32_attention(pcy_ctx*, const float* q, int ldq, int qcol0, const float* k, int ldk, int kcol0, const float* v, int ldv, int vcol0,
+                      float* o, int ldo, const int32_t* cu, const uint8_t* keep, int nseq, int max_len, int H, int Hkv, int dh, int causal,
+                      float scale);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
-ABI_VERSION = 6
+ABI_VERSION = 7
 # pcy_debug_dispatch_count kinds
 DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8, DISPATCH_ATTN_FAST, DISPATCH_BD_CHAIN, DISPATCH_GEMM_MID, DISPATCH_ESM_GRAPH = range(10)
 
@@ -90,6 +90,17 @@ SIGNATURES = {
     "pcy_retrieval_topk": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp]),
     "pcy_retrieval_scores_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, vp]),
     "pcy_retrieval_topk_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
+    # fp32 operator family (include/pcy.h: callers that never call .bfloat16())
+    "pcy_f32_linear": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
+    "pcy_f32_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, C.c_float]),
+    "pcy_f32_rmsnorm": (ci, [vp, vp, vp, vp, ci, ci, C.c_float]),
+    "pcy_f32_rope": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, C.c_float]),
+    "pcy_f32_embed": (ci, [vp, vp, vp, vp, vp, vp, ci, ci]),
+    "pcy_f32_esm_embed": (ci, [vp, vp, vp, vp, ci, ci, vp, ci, ci]),
+    "pcy_f32_silu_mul": (ci, [vp, vp, vp, vp, C.c_size_t]),
+    "pcy_f32_acc_rows": (ci, [vp, vp, ci, vp, vp, ci, ci]),
+    "pcy_f32_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
+    "pcy_f32_attention": (ci, [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, C.c_float]),
     "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),

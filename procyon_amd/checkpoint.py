@@ -164,16 +164,23 @@ def build_model(sd, config, tokenizer, device="cuda", max_new_tokens=256, esm_he
         plm = ESM_PLM(parts["esm"], infer_esm_config(parts["esm"], n_heads=esm_heads, rope_math=rope_math), pooling_method=config.protein_pooling_opt,
                       protein_pooling_correction_option=config.protein_pooling_correction_option,
                       max_protein_len=config.max_protein_len, device=dev)
-    mk = lambda layers: MlpEngine([(w.to(dev, BF16), None if b is None else b.to(dev, BF16)) for w, b in layers])
+    def mk(layers):
+        m = MlpEngine([(w.to(dev, BF16), None if b is None else b.to(dev, BF16)) for w, b in layers])
+        if any(w.dtype == torch.float32 for w, _ in layers):
+            m.src_f32 = list(layers)     # kept until .bfloat16(): the fp32 callers' arithmetic (engine_f32)
+        return m
     P = parts["projectors"]
     tok_proj = {n[len("token_"):]: mk(l) for n, l in P.items() if n.startswith("token_")}
     tabs = {k: v.to(dev, BF16) for k, v in parts["tables"].items()}
-    return UnifiedProCyon(config, text_encoder, tokenizer, protein_seq_encoder=plm, token_projectors=tok_proj,
+    tabs_f32 = {k: v for k, v in parts["tables"].items() if v.dtype == torch.float32}
+    model = UnifiedProCyon(config, text_encoder, tokenizer, protein_seq_encoder=plm, token_projectors=tok_proj,
                           aaseq_shared_projector=mk(P["aaseq_shared_projector"]) if "aaseq_shared_projector" in P else None,
                           aaseq_lm_projector=mk(P["aaseq_lm_projector"]) if "aaseq_lm_projector" in P else None,
                           protein_seq_embeddings=tabs.get("protein_seq_embeddings"), domain_embeddings=tabs.get("domain_embeddings"),
                           peptide_embeddings=tabs.get("peptide_embeddings"), protein_struct_embeddings=tabs.get("protein_struct_embeddings"),
                           drug_structure_embeddings=tabs.get("drug_structure_embeddings"))
+    model._tables_f32 = tabs_f32
+    return model
 
 
 # ---------------------------------------------------------------------------------------------------------------------

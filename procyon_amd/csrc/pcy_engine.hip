@@ -32,6 +32,14 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// for the other translation units of the library (pcy_f32.hip): the thread-local error text behind pcy_last_error
+void pcy_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
 struct pcy_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -526,6 +534,9 @@ __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict_
 // ====================================================================================== C ABI
 extern "C" {
 
+}  // extern "C"
+hipStream_t pcy_ctx_stream(pcy_ctx* c) { return c->stream; }
+extern "C" {
 int pcy_abi_version(void) { return PCY_ABI_VERSION; }
 unsigned long long pcy_debug_dispatch_count(int kind) { return (kind >= 0 && kind < PCY_DISPATCH_N) ? g_pcy_dispatch[kind] : 0; }
 const char* pcy_last_error(void) { return g_err; }

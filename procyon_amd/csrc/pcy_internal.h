@@ -108,6 +108,9 @@ struct PcyGemmArgs {
   int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the persistent ESM-GELU kernel skips the fast table epilogue
   int mid_cfg;          // > 0: this configuration of gemm_kernel_mid (pcy_gemm_mid.h); 0: the launcher's own choice
 };
+struct pcy_ctx;
+hipStream_t pcy_ctx_stream(pcy_ctx* c);               // the context's stream (pcy_engine.hip owns the struct)
+void pcy_set_error(const char* fmt, ...);             // sets the text pcy_last_error() returns
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 // builds the one-time device tables of the GEMM epilogues (the ESM GELU table) on `s` if this device has none yet -- callers that
 // CAPTURE a chain of launches call it first, so that the build is not recorded into the graph

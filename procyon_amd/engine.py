@@ -236,8 +236,24 @@ class MlpEngine:
             d.b[i] = 0 if b is None else b.data_ptr()
         self.desc = d
         self.in_features, self.out_features = d.dims[0], d.dims[n]
+        self.src_f32 = None      # fp32 (W, b) pairs of the same projector, set by the loader when the checkpoint is fp32
+        self._f32 = None
+
+    def f32(self):
+        """the same projector in fp32 arithmetic (procyon_amd.engine_f32), for a model that was never cast to bf16"""
+        if self._f32 is None:
+            if self.src_f32 is None:
+                raise RuntimeError("fp32 arithmetic was asked for, but this projector holds no fp32 weights")
+            from .engine_f32 import MlpEngineF32
+            self._f32 = MlpEngineF32(self.src_f32, self.ctx)
+        return self._f32
+
+    def drop_fp32(self):
+        self.src_f32 = self._f32 = None
 
     def __call__(self, x):
+        if x.dtype == torch.float32:
+            return self.f32()(x)
         shape = x.shape
         x = x.reshape(-1, shape[-1]).contiguous()
         _chk_bf16(x)

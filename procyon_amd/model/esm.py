@@ -31,6 +31,10 @@ class ESM_PLM:
         if long_protein_strategy not in ("split", "truncate"):
             raise NotImplementedError(f"long_protein_strategy={long_protein_strategy!r} (train_utils.py:1497-1596 knows 'split' and 'truncate')")
         self.long_protein_strategy = long_protein_strategy
+        # fp32 checkpoints keep their fp32 tensors until the caller asks for bf16 (see LlamaPostTokenization)
+        self._src_f32 = dict(state_dict) if any(v.dtype == torch.float32 for v in state_dict.values()) else None
+        self._engine_f32 = None
+        self._cfg = cfg
         self.engine = EsmEngine(state_dict, cfg, device)
         self.embedding_size = cfg.d
         self.repr_layer = cfg.n_layers
@@ -44,6 +48,27 @@ class ESM_PLM:
 
     def eval(self):
         return self
+
+    @property
+    def engine_f32(self):
+        if self._engine_f32 is None:
+            if self._src_f32 is None:
+                raise RuntimeError("fp32 arithmetic was asked for, but this protein encoder holds no fp32 weights (built from bf16 tensors, or "
+                                   ".bfloat16() was called before)")
+            from ..engine_f32 import EsmEngineF32
+            self._engine_f32 = EsmEngineF32(self._src_f32, self._cfg, self.engine.device)
+        return self._engine_f32
+
+    def drop_fp32(self):
+        self._src_f32 = self._engine_f32 = None
+
+    def forward_f32(self, tokens):
+        """`forward(tokens, aggregate=True)` in fp32 arithmetic (the model was never cast to bf16) -> (z [B,D] fp32, None)"""
+        if self.long_protein_strategy == "truncate":
+            from ..sequences import split_or_truncate_long_seq
+            tokens, _, _ = split_or_truncate_long_seq(tokens.cpu().long(), self.padding_idx, self.eos_idx, "truncate", self.max_protein_len)
+        return self.engine_f32.forward(tokens, pooling=self.pooling_method, correction=self.correction, mask_pads=not self.official,
+                                       max_protein_len=self.max_protein_len), None
 
     def forward(self, tokens, aggregate=True):
         if self.long_protein_strategy == "truncate":       # cut to max_protein_len residues, re-terminate (train_utils.py:1575-1588)

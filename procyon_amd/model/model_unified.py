@@ -109,6 +109,8 @@ class UnifiedProCyon:
         self.device = text_encoder.engine.device
         self.training = False
         self.dtype = torch.float32     # until the caller asks for bf16 (see `bfloat16` below)
+        self._tables_f32 = {}          # fp32 embedding tables of an fp32 checkpoint (checkpoint.build_model), kept until .bfloat16()
+        self._tables_f32_dev = {}
         self.use_llama_tokenizer = True
         self.train_qa_full_lm = False
         self.struct_dropout_prob = config.protein_struct_dropout
@@ -118,8 +120,11 @@ class UnifiedProCyon:
 
     # nn.Module protocol used by the callers (retrieval_utils.py:90-101, procyon.py:64-67).  The reference model is built in the
     # checkpoint's dtype (fp32) and every shipped entry point calls `.bfloat16()` before the first forward -- except
-    # examples/paper_analyses/protpep_qa_scores.py:55-58, which runs fp32.  The engine computes in bf16 only, so the model tracks
-    # the dtype its caller has asked for and REFUSES to run as anything but bf16 (never silently different arithmetic).
+    # examples/paper_analyses/protpep_qa_scores.py:55-58, scripts/qa_filter_captions.py:17-18 and scripts/caption_bulk.py:72-73, which
+    # run fp32.  The model tracks the dtype its caller has asked for and computes in it: bf16 on the bf16 engine; fp32 -- as long as the
+    # fp32 weights of the checkpoint are still held, i.e. `.bfloat16()` was never called -- on the fp32 operator family
+    # (procyon_amd/engine_f32.py) for `forward` (QA, retrieval) and `forward_sequences`; generation needs bf16 (`_require_bf16`).
+    # Never silently different arithmetic.
     def eval(self):
         self.training = False
         return self
@@ -131,7 +136,16 @@ class UnifiedProCyon:
 
     def bfloat16(self):
         self.dtype = BF16
+        # the reference's parameters ARE bf16 from here on: the fp32 copies go (they are 2x the bf16 engine's memory)
+        for m in [self.text_encoder, self.protein_seq_encoder, self.aaseq_shared_projector, self.aaseq_lm_projector] + list(self.token_projectors.values()):
+            if m is not None and hasattr(m, "drop_fp32"):
+                m.drop_fp32()
+        self._tables_f32, self._tables_f32_dev = {}, {}
         return self
+
+    @property
+    def _f32(self):
+        return self.dtype == torch.float32
 
     def float(self):
         self.dtype = torch.float32
@@ -160,9 +174,14 @@ class UnifiedProCyon:
     def _require_bf16(self, what):
         if self.dtype != BF16:
             raise RuntimeError(
-                f"UnifiedProCyon.{what}: the model is in {self.dtype} (as constructed / loaded) but the MI355X engine computes in "
-                "bfloat16 only -- call model.bfloat16() first, as the reference's entry points do (evaluate/framework/procyon.py:64-65, "
-                "inference/retrieval_utils.py:90-101).  An fp32 weight path (examples/paper_analyses/protpep_qa_scores.py:55-58) is not built.")
+                f"UnifiedProCyon.{what}: the model is in {self.dtype} (as constructed / loaded); KV-cached generation computes in bfloat16 "
+                "only on the MI355X engine -- call model.bfloat16() first, as the reference's entry points do "
+                "(evaluate/framework/procyon.py:64-65, inference/retrieval_utils.py:90-101).  fp32 arithmetic is available for `forward` "
+                "(QA scoring, retrieval) and `forward_sequences`.")
+
+    def _require_bf16_or_fp32(self, what):
+        if self.dtype not in (BF16, torch.float32):
+            raise RuntimeError(f"UnifiedProCyon.{what}: the engine computes in bfloat16 or float32, not {self.dtype}")
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
@@ -173,11 +192,22 @@ class UnifiedProCyon:
                "peptide": self.peptide_embeddings}[aaseq_type]
         if tab is None:
             raise ValueError(f"no embedding table for aaseq_type={aaseq_type}")
+        if self._f32:
+            return self._table_f32({"protein": "protein_seq_embeddings", "domain": "domain_embeddings", "peptide": "peptide_embeddings"}[aaseq_type])
         return tab
+
+    def _table_f32(self, name):
+        if name not in self._tables_f32_dev:
+            if name not in self._tables_f32:
+                raise RuntimeError(f"fp32 arithmetic was asked for, but the {name} table is held in bf16 only")
+            self._tables_f32_dev[name] = self._tables_f32[name].to(self.device, torch.float32)
+        return self._tables_f32_dev[name]
 
     def _encode_aaseq(self, seq, aaseq_type):
         if self.config.use_aaseq_embeddings:
             return self._embed_table(aaseq_type)[seq.to(self.device).long()]
+        if self._f32:
+            return self.protein_seq_encoder.forward_f32(seq)[0]
         z, _ = self.protein_seq_encoder(seq, aggregate=True)
         return z
 
@@ -195,7 +225,8 @@ class UnifiedProCyon:
             protein_soft_tokens = None
         if self.config.use_drug_embeddings and (inputs["data"]["drug"] is not None):
             full_index = list(chain.from_iterable(inputs["input"]["drug"]))
-            drug_z = self.drug_structure_embeddings[inputs["data"]["drug"].to(self.device).long()][full_index]
+            drug_tab = self._table_f32("drug_structure_embeddings") if self._f32 else self.drug_structure_embeddings
+            drug_z = drug_tab[inputs["data"]["drug"].to(self.device).long()][full_index]
             drug_soft_tokens = self.token_projectors["drug"](drug_z)
         else:
             drug_soft_tokens = None
@@ -213,9 +244,9 @@ class UnifiedProCyon:
             all_row_indices = torch.stack(all_row_indices, dim=0)
             ari_unique, ari_inverse = all_row_indices.unique(return_inverse=True)
             if aaseq_type == "protein":
-                struct_z = self.protein_struct_embeddings[ari_unique.to(self.device).long()]
+                struct_z = (self._table_f32("protein_struct_embeddings") if self._f32 else self.protein_struct_embeddings)[ari_unique.to(self.device).long()]
             else:
-                struct_z = torch.zeros(ari_unique.shape[0], self.protein_struct_embeddings.shape[1], dtype=BF16, device=self.device)
+                struct_z = torch.zeros(ari_unique.shape[0], self.protein_struct_embeddings.shape[1], dtype=self.dtype, device=self.device)
             token_z_expand = self.token_projectors["prot_structure"](struct_z)[ari_inverse.to(self.device)]
             for i, val in enumerate(include_mask):
                 protein_struct_tokens.append(token_z_expand[i, ...] if val else [])
@@ -297,7 +328,8 @@ class UnifiedProCyon:
             soft_map[m] = torch.arange(int(m.sum()), dtype=torch.int32) + base
             pieces.append(drug_soft_tokens)
         soft = torch.cat(pieces, 0).contiguous() if pieces else None
-        z = self.text_encoder.engine.embed_tokens(ids, soft, soft_map if pieces else None)
+        eng = self.text_encoder.engine_f32 if self._f32 else self.text_encoder.engine
+        z = eng.embed_tokens(ids, soft, soft_map if pieces else None)
         ret = ids == self.prot_retrieval_idx
         if self.config.roll_num != 0:
             ret = ret.roll(self.config.roll_num, 1)
@@ -312,7 +344,7 @@ class UnifiedProCyon:
         out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D]."""
         if return_mlm:
             raise NotImplementedError("return_mlm is a training path (model_unified.py:505-509)")
-        self._require_bf16("forward")
+        self._require_bf16_or_fp32("forward")
         input_embeds, input_ids, attn_masks, ret_idx, tok_emb, ret_emb = self._preprocessing(
             inputs, aaseq_type=aaseq_type, crop_off=crop_off, retrieval=retrieval, exclude_protein_structure=False)
         full_labels = None
@@ -379,7 +411,7 @@ class UnifiedProCyon:
 
     def forward_sequences(self, seq_input, get_soft_tokens=False, aaseq_type="protein"):
         """`forward_sequences` (model_unified.py:1029-1086)."""
-        self._require_bf16("forward_sequences")
+        self._require_bf16_or_fp32("forward_sequences")
         if isinstance(seq_input, dict):
             seq_input = seq_input["data"]
         z = self._encode_aaseq(seq_input, aaseq_type)

@@ -79,6 +79,10 @@ class LlamaPostTokenization:
     """
 
     def __init__(self, state_dict, cfg: LlamaConfig, device=None, max_new_tokens=256):
+        # fp32 checkpoints keep their fp32 tensors (references, wherever they live) until the caller asks for bf16 -- as the reference's
+        # module holds fp32 parameters until `.bfloat16()` -- so that a caller which never does gets fp32 arithmetic (engine_f32)
+        self._src_f32 = dict(state_dict) if any(v.dtype == torch.float32 for v in state_dict.values()) else None
+        self._engine_f32 = None
         self.engine = LlamaEngine(state_dict, cfg, device)
         self.cfg = cfg
         self.max_new_tokens = max_new_tokens
@@ -88,6 +92,20 @@ class LlamaPostTokenization:
     def eval(self):
         return self
 
+    @property
+    def engine_f32(self):
+        """the fp32 prefill engine, built on first use from the retained fp32 weights"""
+        if self._engine_f32 is None:
+            if self._src_f32 is None:
+                raise RuntimeError("fp32 arithmetic was asked for, but this text encoder holds no fp32 weights (built from bf16 tensors, or "
+                                   ".bfloat16() was called before): load the checkpoint again and do not call .bfloat16()")
+            from ..engine_f32 import LlamaEngineF32
+            self._engine_f32 = LlamaEngineF32(self._src_f32, self.cfg, self.engine.device)
+        return self._engine_f32
+
+    def drop_fp32(self):
+        self._src_f32 = self._engine_f32 = None
+
     def get_input_embeddings(self):
         return self.engine.embed
 
@@ -95,6 +113,8 @@ class LlamaPostTokenization:
                 use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None,
                 output_hidden_states=False, lazy_hidden=False):
         assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
+        if input_embeds is not None and input_embeds.dtype == torch.float32:
+            return self._forward_f32(input_embeds, attn_masks, past_key_values, use_cache, logit_positions, want_hidden, hidden_sum_positions)
         eng = self.engine
         if past_key_values is None:
             if input_embeds is None:
@@ -144,5 +164,22 @@ class LlamaPostTokenization:
         eng.decode_graph(cache, st, B)
         return SimpleNamespace(logits=st.logits.clone().view(B, 1, -1), past_key_values=_Past(cache, t + 1),
                                hidden_states=None, loss=None)
+
+    def _forward_f32(self, input_embeds, attn_masks, past_key_values, use_cache, logit_positions, want_hidden, hidden_sum_positions):
+        """fp32 embeddings in -> the fp32 prefill (the callers that never call `.bfloat16()`; one forward pass, no KV cache)"""
+        if past_key_values is not None or use_cache:
+            raise RuntimeError("the fp32 path is a prefill-only path (QA scoring / retrieval); cached decode computes in bf16 only -- "
+                               "call model.bfloat16() for generation")
+        eng = self.engine_f32
+        B, T, _ = input_embeds.shape
+        rows = "all" if logit_positions is None else (torch.arange(B) * T + logit_positions.cpu().long())
+        hsum = None
+        if hidden_sum_positions is not None:
+            logits, hidden, hsum = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True, sum_rows=hidden_sum_positions)
+        else:
+            logits, hidden = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True)
+        hs = _HiddenStates(self.cfg.n_layers + 1, hidden, lambda: (_ for _ in ()).throw(
+            RuntimeError("the fp32 path keeps the final hidden state only (hidden_states[-1])")))
+        return SimpleNamespace(logits=logits.view(B, -1, self.cfg.vocab), past_key_values=None, hidden_states=hs, hidden_state_sum_rows=hsum, loss=None)
 
     __call__ = forward

@@ -57,6 +57,20 @@ def llama_state_dict(vocab, d, n_layers, n_heads, n_kv_heads, ffn, dtype=torch.b
     return _materialise(todo, device, dtype, workers)
 
 
+def damp_residual_branches(sd, scale=0.25):
+    """Multiply every residual BRANCH's last projection (Llama: o_proj, down_proj; ESM: attention.output.dense, output.dense -- weights
+    and biases) by `scale` IN PLACE and return sd.  With N(0, 0.02^2) weights every branch is as large as the stream it is added to,
+    and a 32-layer stack amplifies a 2^-9 rounding into ~8 % of the logits (tests/test_gpu_fulldepth.py): any two bf16 arithmetics then
+    disagree on a fifth of the argmaxes.  Trained models keep their branches a fraction of the stream; scale 0.25 (a power of two: exact
+    in bf16, so the damped weights are the same bf16 values on every side) puts the synthetic model into that regime, where token
+    agreement between two implementations is a meaningful number."""
+    for k, v in sd.items():
+        if k.endswith(("self_attn.o_proj.weight", "mlp.down_proj.weight", "attention.output.dense.weight", "attention.output.dense.bias")) or \
+                (".output.dense." in k and ".attention." not in k):
+            v.mul_(scale)
+    return sd
+
+
 def esm_state_dict(d, n_layers, n_heads, ffn, vocab=33, dtype=torch.bfloat16, device="cpu", workers=0):
     todo = []
 

@@ -20,7 +20,10 @@ GEOMETRIES = {
 
 
 def build(geometry="full", device="cuda", pooling="mean", max_new_tokens=256, llama_layers=None, esm_layers=None,
-          rope_theta=10000.0, return_weights=False):
+          rope_theta=10000.0, return_weights=False, dtype=BF16, as_loaded=False):
+    """dtype=torch.float32 generates fp32 weights -- an "fp32 checkpoint": the sub-modules keep them beside their bf16 engines until
+    `.bfloat16()`, as a model loaded by the reference's `from_pretrained` holds fp32 parameters.  as_loaded=True returns the model
+    WITHOUT the `.eval().bfloat16()` every shipped caller adds (what protpep_qa_scores.py:55-58 / caption_bulk.py:72-73 run)."""
     g = {k: (dict(v) if isinstance(v, dict) else v) for k, v in GEOMETRIES[geometry].items()}
     if llama_layers is not None:
         g["llama"]["n_layers"] = llama_layers
@@ -32,20 +35,25 @@ def build(geometry="full", device="cuda", pooling="mean", max_new_tokens=256, ll
         g["llama"]["vocab"] = len(tok) - 1
     assert g["llama"]["vocab"] == len(tok) - 1  # model_unified.py:166: [EXT] is never embedded
     gen_dev = device if not return_weights else "cpu"
-    lsd = synth.llama_state_dict(**g["llama"], device=gen_dev)
-    esd = synth.esm_state_dict(**g["esm"], device=gen_dev)
+    lsd = synth.llama_state_dict(**g["llama"], device=gen_dev, dtype=dtype)
+    esd = synth.esm_state_dict(**g["esm"], device=gen_dev, dtype=dtype)
     D, d = g["esm"]["d"], g["llama"]["d"]
-    projs = {"aaseq": synth.mlp_layers(g["proj_layers"], D, d, g["proj_hidden"], 0, device=gen_dev),
-             "shared": synth.mlp_layers(g["proj_layers"], D, D, g["proj_hidden"], 20, device=gen_dev),
-             "lm": synth.mlp_layers(g["proj_layers"], d, D, g["proj_hidden"], 40, device=gen_dev)}
+    projs = {"aaseq": synth.mlp_layers(g["proj_layers"], D, d, g["proj_hidden"], 0, device=gen_dev, dtype=dtype),
+             "shared": synth.mlp_layers(g["proj_layers"], D, D, g["proj_hidden"], 20, device=gen_dev, dtype=dtype),
+             "lm": synth.mlp_layers(g["proj_layers"], d, D, g["proj_hidden"], 40, device=gen_dev, dtype=dtype)}
     dev = torch.device(device)
     text_encoder = LlamaPostTokenization(lsd, LlamaConfig(**g["llama"], rope_theta=rope_theta, max_pos=4096), dev, max_new_tokens)
     plm = ESM_PLM(esd, EsmConfig(**g["esm"]), pooling_method=pooling, device=dev)
-    mk = lambda layers: MlpEngine([(w.to(dev), None if b is None else b.to(dev)) for w, b in layers])
+    def mk(layers):
+        m = MlpEngine([(w.to(dev, BF16), None if b is None else b.to(dev, BF16)) for w, b in layers])
+        if dtype == torch.float32:
+            m.src_f32 = list(layers)
+        return m
     cfg = ProCyonConfig(protein_pooling_opt=pooling, use_aaseq_embeddings=False)
     model = UnifiedProCyon(cfg, text_encoder, tok, protein_seq_encoder=plm, token_projectors={"aaseq": mk(projs["aaseq"])},
                            aaseq_shared_projector=mk(projs["shared"]), aaseq_lm_projector=mk(projs["lm"]))
-    model.eval().bfloat16()      # what every shipped caller of the reference does after construction (procyon.py:64-65)
+    if not as_loaded:
+        model.eval().bfloat16()      # what every shipped caller of the reference does after construction (procyon.py:64-65)
     if return_weights:
         return model, dict(llama=lsd, esm=esd, projs=projs, geom=g)
     return model

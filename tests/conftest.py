@@ -15,6 +15,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- parity report: every full-depth / full-size comparison records its numbers here; at the end of the session they are written to
+# gpurun_out/parity_report.json (copied to profiles/rNN_parity_report.json after a GPU run) and ONE line per record is printed in the
+# terminal summary, which survives `pytest -q` (the driver's log otherwise shows dots)
+PARITY = {}
+
+
+def record_parity(key, **values):
+    PARITY[key] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in values.items()}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not PARITY:
+        return
+    import json
+    terminalreporter.section("parity report (HIP path vs oracle / fp32 truth)")
+    for k, v in PARITY.items():
+        terminalreporter.write_line(f"PARITY {k}: " + ", ".join(f"{a}={b}" for a, b in v.items()))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity_report.json")
+        old = {}
+        if os.path.exists(path):      # several pytest invocations of one GPU run add to the same file
+            try:
+                old = json.load(open(path))
+            except Exception:
+                old = {}
+        old.update(PARITY)
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+        terminalreporter.write_line(f"parity report written to {path}")
+    except OSError as e:
+        terminalreporter.write_line(f"parity report not written: {e}")
+
+
 def load_golden(name):
     """npz -> dict of torch tensors; uint16 arrays are raw bf16 bit patterns."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -12,12 +12,18 @@ reference's own bf16 path,
 
 on the prefill's last-row logits and on 64 teacher-forced cached decode steps (Llama; argmax agreement with the truth is
 asserted as a rate: agree(HIP, fp32) >= agree(oracle_bf16, fp32) - 2 of 65) and on the pooled / shared / soft-token
-embeddings (ESM + projectors).  err(HIP, oracle_bf16), argmax agreement and a near-tie histogram are printed.
+embeddings (ESM + projectors).
+
+Round 4: DAMPED fixtures (f3 / f4: residual branches x 0.25) were built to get a regime in which the bf16 oracle agrees with the truth on
+nearly every argmax; measured, they do not (57 / 65, see test_llama8b_damped_full_depth and tools/diag_bf16_floor.py), so token agreement
+is asserted where it CAN hold for two bf16 pipelines -- on every step whose top-2 margin clears 4 x the bf16 logit noise -- and as a rate
+against the oracle; every number of every test here goes into the parity report (conftest.record_parity -> gpurun_out/parity_report.json -> profiles/r04_parity_report.json)
+and one PARITY line per test survives `pytest -q`.
 """
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -26,45 +32,72 @@ ESM = dict(d=1280, n_layers=33, n_heads=20, ffn=5120)
 SLACK = 1.25
 
 
-@pytest.fixture(scope="module")
-def llama():
-    """Llama-3-8B geometry on the CPU-seeded weights of the fixture (the other full-size tests seed on the device)."""
+def _llama_engine(damped):
+    """Llama-3-8B geometry on the CPU-seeded weights of the fixtures (the other full-size tests seed on the device)."""
     from procyon_amd import synth
     from procyon_amd.engine import LlamaConfig, LlamaEngine
     sd = synth.llama_state_dict(**LLAMA, workers=16)
+    if damped:
+        synth.damp_residual_branches(sd, 0.25)
     return LlamaEngine(sd, LlamaConfig(**LLAMA, max_pos=4096), free_source=True)
 
 
-@pytest.mark.parametrize("T", [64, 512])
-def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
+@pytest.fixture(scope="module")
+def llama():
+    return _llama_engine(False)
+
+
+@pytest.fixture(scope="module")
+def llama_damped():
+    return _llama_engine(True)
+
+
+def _llama_steps(eng, g, T):
+    """prefill + teacher-forced cached decode steps on the fixture's tokens -> logits [65, V] fp32 (CPU), prefill hidden row"""
     from procyon_amd.engine import GenState
-    g = golden(f"f1_llama8b_T{T}")
-    ids, toks, cols = g["ids"].long(), g["tokens"].long(), g["cols"].long()
+    ids, toks = g["ids"].long(), g["tokens"].long()
     nstep = toks.numel()                          # prefill + 64 decode steps
-    cache = llama.new_cache(1, T + nstep + 1)
-    logits, hidden = llama.prefill(llama.embed_tokens(ids), None, cache, "last", want_hidden=True)
+    cache = eng.new_cache(1, T + nstep + 1)
+    logits, hidden = eng.prefill(eng.embed_tokens(ids), None, cache, "last", want_hidden=True)
     got = [logits[0].cpu()]
     st = GenState(1, LLAMA["vocab"], nstep + 1, "cuda")
     for s in range(1, nstep):                     # teacher-forced on the bf16 oracle's greedy tokens
         st.pos.fill_(T + s - 1)
         st.next_tok.copy_(toks[s - 1:s].to(torch.int32))
-        llama.decode(cache, st, 1)
+        eng.decode(cache, st, 1)
         got.append(st.logits[0].cpu())
-    got = torch.stack(got).float()                # [65, V]
+    return torch.stack(got).float(), hidden[0, -1].cpu().float()
+
+
+def _llama_stats(got, g):
+    """per-step errors and agreement counts of HIP logits [65, V] against the fixture's bf16 oracle and fp32 truth (column subset)"""
+    cols = g["cols"].long()
     truth, ref = g["logits_fp32"], g["logits_bf16"].float()
-    worst = 0.0
-    agree_hip_truth = agree_ref_truth = agree_hip_ref = 0
+    nstep = got.shape[0]
+    out = dict(nstep=nstep, e_hip_truth=[], e_ref_truth=[], e_hip_ref=[], agree_hip_truth=0, agree_ref_truth=0, agree_hip_ref=0, rows=[])
     for s in range(nstep):
-        e_hip = rel_err(got[s, cols], truth[s])
-        e_ref = rel_err(ref[s], truth[s])
-        e_hr = rel_err(got[s, cols], ref[s])
+        out["e_hip_truth"].append(rel_err(got[s, cols], truth[s]))
+        out["e_ref_truth"].append(rel_err(ref[s], truth[s]))
+        out["e_hip_ref"].append(rel_err(got[s, cols], ref[s]))
+        am, am_t, am_r = int(got[s].argmax()), int(g["top_ids_fp32"][s, 0]), int(g["top_ids_bf16"][s, 0])
+        out["agree_hip_truth"] += am == am_t
+        out["agree_ref_truth"] += am_r == am_t
+        out["agree_hip_ref"] += am == am_r
+        out["rows"].append((am, am_t, am_r, float(g["top_vals_fp32"][s, 0] - g["top_vals_fp32"][s, 1])))
+    return out
+
+
+@pytest.mark.parametrize("T", [64, 512])
+def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
+    g = golden(f"f1_llama8b_T{T}")
+    got, h_hip = _llama_steps(llama, g, T)
+    st = _llama_stats(got, g)
+    nstep = st["nstep"]
+    worst = 0.0
+    for s in range(nstep):
+        e_hip, e_ref, e_hr = st["e_hip_truth"][s], st["e_ref_truth"][s], st["e_hip_ref"][s]
         worst = max(worst, e_hip / e_ref)
-        am = int(got[s].argmax())
-        am_t, am_r = int(g["top_ids_fp32"][s, 0]), int(g["top_ids_bf16"][s, 0])
-        agree_hip_truth += am == am_t
-        agree_ref_truth += am_r == am_t
-        agree_hip_ref += am == am_r
-        margin = float(g["top_vals_fp32"][s, 0] - g["top_vals_fp32"][s, 1])
+        am, am_t, am_r, margin = st["rows"][s]
         if s < 4 or s % 16 == 0 or am != am_t:
             print(f"T={T} step {s}: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e} (all {LLAMA['vocab']} columns: "
                   f"{float(g['err_bf16_full'][s]):.3e})  err(HIP,oracle_bf16) {e_hr:.3e}  argmax HIP {am} / fp32 {am_t} / oracle {am_r}  "
@@ -74,30 +107,107 @@ def test_llama8b_full_depth_vs_fp32_truth(llama, golden, T):
     # often as the reference's own bf16 arithmetic does, within two steps (round-2 review: the per-step near-tie assertion could
     # not fail -- every fp32 top-2 margin of an untrained model lies inside the bf16 logits noise)
     print(f"T={T}: worst err(HIP,fp32)/err(oracle_bf16,fp32) = {worst:.3f}; argmax agreement over {nstep} steps: "
-          f"HIP vs fp32 {agree_hip_truth}/{nstep}, oracle_bf16 vs fp32 {agree_ref_truth}/{nstep}, HIP vs oracle_bf16 {agree_hip_ref}/{nstep}")
+          f"HIP vs fp32 {st['agree_hip_truth']}/{nstep}, oracle_bf16 vs fp32 {st['agree_ref_truth']}/{nstep}, HIP vs oracle_bf16 {st['agree_hip_ref']}/{nstep}")
+    mean = lambda v: sum(v) / len(v)
+    record_parity(f"fulldepth/llama8b_random_init_T{T}", steps=nstep, err_hip_fp32_mean=mean(st["e_hip_truth"]), err_oracle_fp32_mean=mean(st["e_ref_truth"]),
+                  err_hip_oracle_mean=mean(st["e_hip_ref"]), err_hip_oracle_max=max(st["e_hip_ref"]), worst_ratio_hip_over_oracle=worst,
+                  agree_hip_fp32=st["agree_hip_truth"], agree_oracle_fp32=st["agree_ref_truth"], agree_hip_oracle=st["agree_hip_ref"])
     assert nstep >= 65
-    assert agree_hip_truth >= agree_ref_truth - 2, (agree_hip_truth, agree_ref_truth)
+    assert st["agree_hip_truth"] >= st["agree_ref_truth"] - 2, (st["agree_hip_truth"], st["agree_ref_truth"])
     # final-normed hidden row of the prefill: all 4096 entries are in the fixture
-    h_hip = hidden[0, -1].cpu().float()
     e_hip, e_ref = rel_err(h_hip, g["hidden_fp32"][0]), rel_err(g["hidden_bf16"][0].float(), g["hidden_fp32"][0])
     print(f"T={T} prefill hidden row: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e}")
     assert e_hip <= SLACK * e_ref
 
 
-def test_esm650m_full_depth_vs_fp32_truth(golden):
+def _margin_conditioned(st, g):
+    """Steps whose fp32 top-2 margin exceeds 4 x the per-logit noise of the bf16 pipeline (rms over the fixture's columns of
+    oracle_bf16 - fp32 at that step): there two bf16 implementations MUST pick the same token (a flip needs a 2.8-sigma event on the
+    difference of two logit errors).  Returns (n_clear, n_clear_agree_hip_oracle, n_clear_agree_hip_fp32)."""
+    truth, ref = g["logits_fp32"], g["logits_bf16"].float()
+    clear = agree_o = agree_t = 0
+    for s_, (am, am_t, am_r, margin) in enumerate(st["rows"]):
+        noise = float((ref[s_] - truth[s_]).pow(2).mean().sqrt())
+        if margin >= 4.0 * noise:
+            clear += 1
+            agree_o += am == am_r
+            agree_t += am == am_t
+    return clear, agree_o, agree_t
+
+
+@pytest.mark.parametrize("T", [64, 512])
+def test_llama8b_argmax_agrees_wherever_the_margin_clears_the_bf16_noise(llama, golden, T):
+    """The falsifiable form of north_star's "bit-exact argmax ids" (/root/reference/procyon/model/model_unified.py:892-906).  Two
+    exact-class bf16 pipelines are as far from each other as from the fp32 truth (tools/diag_bf16_floor.py: the oracle against itself with
+    another accumulation order, 1.4e-2 vs 1.5e-2, at every weight scale), so on Gaussian logits a flat "63 of 65" cannot hold for ANY
+    second implementation -- the oracle itself agrees with the truth on 51-57 of 65.  Asserted instead: on EVERY step whose fp32 top-2
+    margin exceeds 4 x the bf16 logit noise, HIP argmax == oracle argmax == fp32 argmax; and over all steps the HIP path agrees with
+    the ORACLE at least as often as the oracle agrees with the truth, minus 2."""
+    g = golden(f"f1_llama8b_T{T}")
+    got, _ = _llama_steps(llama, g, T)
+    st = _llama_stats(got, g)
+    clear, ao, at = _margin_conditioned(st, g)
+    record_parity(f"fulldepth/llama8b_random_init_T{T}_margin_conditioned", steps=st["nstep"], clear_margin_steps=clear, clear_agree_hip_oracle=ao,
+                  clear_agree_hip_fp32=at, agree_hip_oracle=st["agree_hip_ref"], agree_oracle_fp32=st["agree_ref_truth"])
+    assert clear >= 8, clear
+    assert ao == clear and at == clear, (clear, ao, at)
+    assert st["agree_hip_ref"] >= st["agree_ref_truth"] - 2, (st["agree_hip_ref"], st["agree_ref_truth"])
+
+
+def test_llama8b_damped_full_depth(llama_damped, golden):
+    """The same comparison on the DAMPED model (residual branches x 0.25, fixture f3): round 3's review asked for a trained-like regime in
+    which the bf16 oracle agrees with fp32 on >= 63 / 65 steps.  Built and measured: damping does NOT produce that regime (the oracle
+    agrees on 57 / 65; err(oracle, fp32) 8.7e-2 as undamped -- the noise is per-layer materialisation, not amplification), so the
+    assertions are the margin-conditioned ones plus the truth-distance bar; every number goes into the parity report."""
+    T = 64
+    g = golden("f3_llama8b_damped_T64")
+    got, _ = _llama_steps(llama_damped, g, T)
+    st = _llama_stats(got, g)
+    nstep = st["nstep"]
+    mean = lambda v: sum(v) / len(v)
+    clear, ao, at = _margin_conditioned(st, g)
+    record_parity("fulldepth/llama8b_damped_T64", steps=nstep, err_hip_fp32_mean=mean(st["e_hip_truth"]), err_oracle_fp32_mean=mean(st["e_ref_truth"]),
+                  err_hip_oracle_mean=mean(st["e_hip_ref"]), err_hip_oracle_max=max(st["e_hip_ref"]),
+                  agree_hip_fp32=st["agree_hip_truth"], agree_oracle_fp32=st["agree_ref_truth"], agree_hip_oracle=st["agree_hip_ref"],
+                  clear_margin_steps=clear, clear_agree_hip_oracle=ao, clear_agree_hip_fp32=at)
+    for s in range(nstep):
+        assert st["e_hip_truth"][s] <= SLACK * st["e_ref_truth"][s], (s, st["e_hip_truth"][s], st["e_ref_truth"][s])
+    assert ao == clear and at == clear, (clear, ao, at)
+    assert st["agree_hip_truth"] >= st["agree_ref_truth"] - 2 and st["agree_hip_ref"] >= st["agree_ref_truth"] - 2
+
+
+def _esm_outputs(golden_name, damped, golden):
     from procyon_amd import synth
     from procyon_amd.engine import EsmConfig, EsmEngine, MlpEngine
-    g = golden("f2_esm650m_1024")
-    eng = EsmEngine(synth.esm_state_dict(**ESM, workers=8), EsmConfig(**ESM))
+    g = golden(golden_name)
+    sd = synth.esm_state_dict(**ESM, workers=8)
+    if damped:
+        synth.damp_residual_branches(sd, 0.25)
+    eng = EsmEngine(sd, EsmConfig(**ESM))
     mk = lambda layers: MlpEngine([(w.cuda(), b.cuda()) for w, b in layers])
     shared, token = mk(synth.mlp_layers(3, 1280, 1280, 2560, 20)), mk(synth.mlp_layers(3, 1280, 4096, 2560, 0))
     toks = g["tokens"].long()
     hid = eng.hidden_states(toks)[0]
     z = eng.forward(toks)
-    out = {"hidden_rows": hid[g["rows"].long().cuda()].cpu(), "pooled": z[0].cpu(), "shared": shared(z)[0].cpu(),
-           "soft_token": token(z)[0].cpu()}
+    return g, {"hidden_rows": hid[g["rows"].long().cuda()].cpu(), "pooled": z[0].cpu(), "shared": shared(z)[0].cpu(), "soft_token": token(z)[0].cpu()}
+
+
+@pytest.mark.parametrize("attn", ["fast", "exact"])
+@pytest.mark.parametrize("damped", [False, True])
+def test_esm650m_full_depth_vs_fp32_truth(golden, monkeypatch, attn, damped):
+    """33-layer ESM2-650M, one 1024-residue protein, both attention kernels (PCY_ESM_ATTN: the default single-pass kernel and the
+    exact two-pass one that reproduces the reference's rounding points), random-init and damped weights: no further from the fp32
+    truth than the bf16 oracle, and err(HIP, oracle_bf16) <= 2 x err(oracle_bf16, fp32) on every output."""
+    monkeypatch.setenv("PCY_ESM_ATTN", attn)
+    g, out = _esm_outputs("f4_esm650m_damped_1024" if damped else "f2_esm650m_1024", damped, golden)
+    rec = {}
     for k, v in out.items():
         e_hip, e_ref = rel_err(v.float(), g[k + "_fp32"]), rel_err(g[k + "_bf16"].float(), g[k + "_fp32"])
-        print(f"esm650m {k}: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e}  err(HIP,oracle_bf16) "
-              f"{rel_err(v.float(), g[k + '_bf16'].float()):.3e}")
-        assert e_hip <= SLACK * e_ref, k
+        e_hr = rel_err(v.float(), g[k + "_bf16"].float())
+        print(f"esm650m {'damped' if damped else 'random-init'} attention={attn} {k}: err(HIP,fp32) {e_hip:.3e}  err(oracle_bf16,fp32) {e_ref:.3e}  "
+              f"err(HIP,oracle_bf16) {e_hr:.3e}")
+        rec.update({f"{k}_err_hip_fp32": e_hip, f"{k}_err_oracle_fp32": e_ref, f"{k}_err_hip_oracle": e_hr})
+        assert e_hip <= SLACK * max(e_ref, 1e-3 if damped else 0.0), k
+        # two bf16 pipelines sit about as far from each other as each from the truth (tools/diag_bf16_floor.py): bounded by that
+        assert e_hr <= 2.0 * max(e_ref, 1e-3), (k, e_hr, e_ref)
+    record_parity(f"fulldepth/esm650m_{'damped' if damped else 'random_init'}_attention_{attn}", **rec)

@@ -3,7 +3,7 @@ finish these in seconds, so parity is checked through size-independent propertie
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -25,6 +25,18 @@ def esm():
     return EsmEngine(synth.esm_state_dict(**kw, device="cuda"), EsmConfig(**kw))
 
 
+@pytest.fixture(scope="module")
+def llama_damped():
+    """the same geometry with every residual branch damped to a quarter (synth.damp_residual_branches: the trained-like regime, where
+    a 2^-9 rounding is NOT amplified to several per cent of the logits by 32 undamped layers) -- the regime in which a bound on the
+    distance between two kernel families says something"""
+    from procyon_amd import synth
+    from procyon_amd.engine import LlamaConfig, LlamaEngine
+    kw = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
+    sd = synth.damp_residual_branches(synth.llama_state_dict(**kw, device="cuda"), 0.25)
+    return LlamaEngine(sd, LlamaConfig(**kw, max_pos=4096), free_source=True)
+
+
 def _emb(B, T, seed):
     g = torch.Generator(device="cuda").manual_seed(seed)
     return (torch.randn(B, T, 4096, generator=g, device="cuda") * 0.02).to(BF)
@@ -40,29 +52,39 @@ def test_llama_full_determinism_and_graph_equals_eager(llama):
     assert int(t1.min()) >= 0 and int(t1.max()) < 128263
 
 
-def test_llama_full_cache_consistency(llama):
-    """prefill(T) last-row logits == prefill(T-1) + one cached decode step of the T-th embedding's token path:
-    here checked as prefill(512) vs prefill(511) followed by decode of the token whose embedding is row 511."""
+@pytest.mark.parametrize("damped", [False, True])
+def test_llama_full_cache_consistency(llama, llama_damped, damped):
+    """prefill(T) last-row logits == prefill(T-1) + one cached decode step of the T-th token: prefill(512) vs prefill(511) followed by
+    the decode of token 511 -- two different kernel families (MFMA prefill vs streaming decode) through 32 bf16 layers, on the
+    random-init model and on the damped one (residual branches x 0.25).  Two bf16 pipelines with different accumulation orders sit
+    4-5e-2 apart on the logits after 32 layers whatever the weights' scale (tools/diag_bf16_floor.py; the parity report has 3.7e-2 for
+    both models), a wrong position / rope / cache slot gives O(1): the bar is 6e-2, the new key row of the last layer must agree to
+    2e-2, and the argmax must be equal wherever the top-2 margin exceeds 4 x the rms logit difference."""
     from procyon_amd.engine import GenState
+    eng = llama_damped if damped else llama
     ids = torch.randint(0, 128000, (1, 512), generator=torch.Generator().manual_seed(3))
-    emb = llama.embed_tokens(ids)
-    c1 = llama.new_cache(1, 520)
-    full, _ = llama.prefill(emb, None, c1, "last")
-    c2 = llama.new_cache(1, 520)
-    llama.prefill(emb[:, :511].contiguous(), None, c2, "last")
+    emb = eng.embed_tokens(ids)
+    c1 = eng.new_cache(1, 520)
+    full, _ = eng.prefill(emb, None, c1, "last")
+    c2 = eng.new_cache(1, 520)
+    eng.prefill(emb[:, :511].contiguous(), None, c2, "last")
     st = GenState(1, 128263, 2, "cuda")
     st.pos.fill_(511)
     st.next_tok.copy_(ids[:, 511].to(torch.int32))
-    llama.decode(c2, st, 1)
-    # two different kernel families (MFMA prefill vs streaming decode) through 32 bf16 layers: the per-layer noise floor
-    # (~2.5e-3, DESIGN.md) compounds to a few e-2; a wrong position / rope / cache slot would give O(1)
-    assert rel_err(st.logits.cpu(), full.cpu()) < 8e-2
-    assert int(st.logits.float().argmax()) == int(full.float().argmax()) or \
-        float(full.float().topk(2).values.diff().abs()) < 4 * float((st.logits.float() - full.float()).abs().max())
+    eng.decode(c2, st, 1)
+    e_logits = rel_err(st.logits.cpu(), full.cpu())
     k1, _ = c1.layer(31, 512)
     k2, _ = c2.layer(31, 512)
-    assert rel_err(k2.cpu(), k1.cpu()) < 8e-2
-    assert torch.equal(c1.layer(0, 511)[0], c2.layer(0, 511)[0]), "layer-0 keys of the shared prefix must be identical"
+    e_k = rel_err(k2[:, :, 511].cpu(), k1[:, :, 511].cpu())          # the one key row the two runs computed with different kernels
+    same = int(st.logits.float().argmax()) == int(full.float().argmax())
+    margin = float(full.float().topk(2).values.diff().abs())
+    noise = float((st.logits.float() - full.float()).pow(2).mean().sqrt())
+    record_parity(f"fullsize/cache_consistency/{'damped' if damped else 'random_init'}", err_logits_decode_vs_prefill=e_logits,
+                  err_last_layer_new_key_row=e_k, argmax_equal=same, top2_margin=margin, rms_logit_diff=noise)
+    assert e_logits < 6e-2, e_logits
+    assert e_k < 2e-2, e_k
+    assert same or margin < 4 * noise, (margin, noise)
+    assert torch.equal(c1.layer(0, 511)[0][:, :, :511], c2.layer(0, 511)[0][:, :, :511]), "layer-0 keys of the shared prefix must be identical"
 
 
 def test_llama_full_batch_invariance(llama):
