@@ -292,8 +292,19 @@ def main():
         idx = list(range(b0, min(b0 + rb, (i // per + 1) * per, nprot)))
         ref_row = model.forward_sequences(tok_fn(idx))["shared"][i - b0]
         assert torch.equal(ref_row, allz[i]), f"gathered embedding of protein {i} differs from the single-rank result"
+    # the encoder of one retrieval batch alone, HIP events on the engine's stream (the leg above is wall clock: host packing, pooling,
+    # projector, the gather; on a busy host it loses up to 15 % to the launch rate)
+    btoks = tok_fn(list(range(rb)))
+    for _ in range(2):
+        esm_eng.forward(btoks)
+    ctx.timer_start()
+    for _ in range(4):
+        esm_eng.forward(btoks)
+    enc_b_ms = ctx.timer_stop() / 4
     retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": rb, "timing": "best of 2 passes",
                  "mfma_frac_of_2500TF": round(nprot / rt * (2 * 648806400 * (plen + 2) + 168960 * (plen + 2) ** 2) / 2.5e15, 4) if a.geometry == "full" else None,
+                 "encoder_ms_per_batch": round(enc_b_ms, 3), "encoder_proteins_per_s": round(rb / enc_b_ms * 1e3, 1),
+                 "encoder_mfma_frac_of_2500TF": round(rb / enc_b_ms * 1e3 * (2 * 648806400 * (plen + 2) + 168960 * (plen + 2) ** 2) / 2.5e15, 4) if a.geometry == "full" else None,
                  "attention": "single-pass (PCY_ESM_ATTN=fast, default)" if rt_exact is not None else "exact two-pass (PCY_ESM_ATTN=exact)",
                  "proteins_per_s_exact_attention": round(nprot / rt_exact, 2) if rt_exact is not None else None,
                  "collective": "one RCCL all-gather through pcy_allgather" if dist else "none (single rank)", "gather_checked_rows": 3}

@@ -12,7 +12,7 @@ EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
 ABI_VERSION = 7
 # pcy_debug_dispatch_count kinds
-DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8, DISPATCH_ATTN_FAST, DISPATCH_BD_CHAIN, DISPATCH_GEMM_MID, DISPATCH_ESM_GRAPH = range(10)
+DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8, DISPATCH_ATTN_FAST, _DISPATCH_UNUSED_7, DISPATCH_GEMM_MID, DISPATCH_ESM_GRAPH = range(10)
 
 vp = C.c_void_p
 i32 = C.c_int32

@@ -60,7 +60,6 @@ struct pcy_ctx {
   unsigned* xwg_err = nullptr;
   // fused attention + o projection launches of the layered decode step: [0] = step epoch, [64 + 64*l ...] = flags of layer l
   unsigned* ao_sync = nullptr;
-  unsigned* tile_ctr = nullptr;       // 16 zeroed words: dynamic tile queue of the persistent GEMM (PcyGemmArgs.tile_ctr)
   // tagged hand-over vectors of the MLP chain launches: [layer][ffn + d] words, owned by one model geometry at a time
   uint32_t* mc_tags = nullptr;
   const void* mc_tags_model = nullptr;
@@ -138,10 +137,8 @@ int take_sticky_error(pcy_ctx* c) {
   return fail(4, "decode kernel: a cross-workgroup dependency wait timed out (code %u): its workgroups were not all resident -- is "
                  "another kernel running on this device? -- results since the last successful pcy_ctx_sync are invalid", code);
 }
-thread_local unsigned* g_cur_tile_ctr = nullptr;   // the calling context's tile-queue words (PcyGemmArgs.tile_ctr), set per ABI call
 #define PCY_STICKY(c)                                 \
   do {                                                \
-    g_cur_tile_ctr = (c)->tile_ctr;                   \
     if (int r_ = take_sticky_error(c)) return r_;     \
   } while (0)
 
@@ -169,7 +166,6 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
   a.splitk_ws = splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
   a.next_rms_w = next_w; a.next_xn = next_xn; a.fused_next = fused; a.rms_eps = rms_eps; a.rms_cast = rms_cast;
-  a.tile_ctr = g_cur_tile_ctr;
   pcy_launch_gemm(s, a);
 }
 
@@ -199,12 +195,11 @@ bool decode_step_enabled() {
   const char* e = getenv("PCY_DECODE_STEP");
   return !e || atoi(e) != 0;
 }
-// batched decode: everything of a layer behind the attention as one launch (pcy_bdec_chain.h), PCY_BD_CHAIN=1.  OFF by default:
-// bit-identical, but 133 us per layer against 110 us launch by launch at batch 32 -- a grid barrier under a saturated memory
-// system costs ~10 us (in-kernel stamps), more than the kernel boundary it replaces.
-bool bd_chain_enabled() { const char* e = getenv("PCY_BD_CHAIN"); return e && atoi(e) == 1; }
+// (round 3 had everything of a batched-decode layer behind the attention as one launch with grid barriers: bit-identical, 133 us per
+// layer against 110 us launch by launch at batch 32 -- a grid barrier under a saturated memory system costs ~10 us, more than the kernel
+// boundary it replaces; removed in round 4, numbers in DESIGN.md)
 bool qkv_finish_launch() { const char* e = getenv("PCY_QKV_FINISH"); return e && atoi(e) == 1; }   // read per call: tests compare both
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) | (bd_chain_enabled() ? 256 : 0); }
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
@@ -332,8 +327,6 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     step_done = pcy_launch_decode_step(s, t, bp, mc, sa, c->n_cu, c->ao_sync);
   }
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
-  int chain_qkv = 0;  // batched path: K splits of THIS layer's qkv projection left in sk_ws by the previous layer's chain launch
-  bool try_chain = batched && B <= 32 && bd_chain_enabled() && !qkv_finish_launch() && c->ao_sync && c->xwg_err && sk_ws && !try_ao;
   for (int l = 0; l < (step_done ? 0 : m->n_layers); ++l) {
     const pcy_llama_layer& L = m->layers[l];
     PcyGemvArgs g{};
@@ -375,39 +368,14 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       try_layer = false;   // geometry not covered: the same for every layer
     }
     int qkv_splits = 0;   // batched: the attention adds up the K-split partial sums of ITS rows (no finish launch); PCY_QKV_FINISH=1: separate launch
-    if (chain_qkv > 1) qkv_splits = chain_qkv;
-    else {
-      if (batched && sk_ws && !try_ao && !qkv_finish_launch()) g.defer_finish = &qkv_splits;
-      pcy_launch_gemv(s, g);
-    }
-    chain_qkv = 0;
+    if (batched && sk_ws && !try_ao && !qkv_finish_launch()) g.defer_finish = &qkv_splits;
+    pcy_launch_gemv(s, g);
     if (qkv_splits > 1) { t.qkv_partials = sk_ws; t.qkv_splits = qkv_splits; }
-    if (try_chain && qkv_splits > 1) {   // attention, then the rest of the layer (and the next layer's qkv projection) as one launch
-      PcyBdChainArgs ch{};
-      const bool last = l + 1 == m->n_layers;
-      ch.B = B; ch.d = d; ch.Ko = H * dh; ch.F = F; ch.Nq = last ? 0 : qkvw;
-      ch.ao = ao; ch.x = x; ch.xn = xn; ch.act = act;
-      ch.wo = (const bf16_t*)L.wo; ch.ln2 = (const bf16_t*)L.ln2; ch.wgu = (const bf16_t*)L.wgu; ch.wdown = (const bf16_t*)L.wdown;
-      ch.next_norm = (const bf16_t*)(last ? m->final_norm : m->layers[l + 1].ln1);
-      ch.next_wqkv = last ? nullptr : (const bf16_t*)m->layers[l + 1].wqkv;
-      ch.ws = sk_ws; ch.ws_bytes = sk_bytes; ch.rms_eps = m->rms_eps; ch.rms_cast = m->rms_cast;
-      ch.ctr = c->ao_sync + 8; ch.err = c->xwg_err;
-      if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode_b.py): in-kernel time stamps, [layer][workgroup][16]
-        if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
-        ch.trace = g_mc_trace + (size_t)l * 256 * 16;
-      }
-      pcy_launch_attn_decode(s, t);
-      if (pcy_launch_bd_chain(s, ch, c->n_cu, &chain_qkv)) { xn_ready = 1; continue; }
-      try_chain = false;   // geometry not covered: the same for every layer; the attention has run, go on with the o projection
-      pcy_launch_gemv(s, o);
-      goto after_o;
-    }
     if (!(try_ao && pcy_launch_attn_o(s, t, o, c->n_cu, c->ao_sync, c->ao_sync + 64 + l * AO_FLAGS, AO_FLAGS, c->xwg_err,
                                        c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS))) {
       pcy_launch_attn_decode(s, t);
       pcy_launch_gemv(s, o);
     }
-  after_o:
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
     u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
@@ -553,8 +521,6 @@ int pcy_ctx_create(int device_id, void* stream, pcy_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tile_ctr), 64));
-  HIP_TRY(hipMemset(c->tile_ctr, 0, 64));
   *out = c;
   return 0;
 }
@@ -566,7 +532,6 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->ws) hipFree(c->ws);
   if (c->xwg_err) hipHostFree(c->xwg_err);
   if (c->ao_sync) hipFree(c->ao_sync);
-  if (c->tile_ctr) hipFree(c->tile_ctr);
   if (c->mc_tags) hipFree(c->mc_tags);
   if (c->dev_layers) hipFree(c->dev_layers);
   if (c->op_tags) hipFree(c->op_tags);
@@ -598,7 +563,6 @@ int pcy_gemm(pcy_ctx* c, const void* A, int lda, const void* W, const void* bias
   PcyGemmArgs a{};
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = (const bf16_t*)bias; a.resid = (const bf16_t*)resid;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.epi = epi;
-  a.tile_ctr = c->tile_ctr;
   pcy_launch_gemm(c->stream, a);
   return check_launch("pcy_gemm");
 }

@@ -136,19 +136,6 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
   }
 }
 
-// one 1-KiB piece (instruction i of this wave) of stage_tile
-template <int BK, int ROWS, int NW>
-__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ g, int ld, int row0, int nrows_valid, int k0,
-                                            char* lds_tile, int wave, int lane, int i) {
-  constexpr int CPR = BK / 8, RPI = 64 / CPR, NINST = ROWS / RPI;
-  const int inst = wave * (NINST / NW) + i;
-  const int r = inst * RPI + lane / CPR;
-  const int c = (lane % CPR) ^ swz<BK>(r);
-  int gr = row0 + r;
-  gr = gr < nrows_valid ? gr : nrows_valid - 1;
-  __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)gr * ld + k0 + c * 8), (lds_ptr_t)(lds_tile + inst * 1024), 16, 0, 0);
-}
-
 template <int BK, int SW = 0>
 __device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BK * 2) + ((chunk ^ swz<BK, SW>(row)) << 4));
@@ -175,33 +162,13 @@ __device__ __forceinline__ void tile_origin(const PcyGemmArgs& a, int tile, int&
 // All global reads of the epilogue (bias: 16 values per lane, residual: 16 x 8 B per lane) are issued up front as
 // independent vector loads -- element-wise loads inside the rounding chain serialised ~64 L2 round trips per tile
 // (20 us of the 37 us a K=1280 tile took).
-// LDS_OUT: the finished bf16 quads go to the wave's private LDS tile instead of global memory (rows = the wave's 64 tokens, 256
-// bytes each, 16-byte chunk c of row r at c ^ (r & 15)); gemm_wide_flush then stores whole rows (see gemm_epilogue_wide).
-__device__ __forceinline__ void lds_put4(char* wave_lds, int row, int col, uint2 w) {
-  *reinterpret_cast<uint2*>(wave_lds + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) = w;
-}
-template <int COLS>   // 128 features per wave row (64 for the SwiGLU output)
-__device__ __forceinline__ void gemm_wide_flush(const PcyGemmArgs& a, const char* wave_lds, int mw, int nw, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  constexpr int CPR = COLS / 8, RPI = 64 / CPR;       // 16-byte chunks per row, rows per wave-instruction
-  const int c = lane % CPR, n = nw + c * 8;
-#pragma unroll 4
-  for (int it = 0; it < 64 / RPI; ++it) {
-    const int row = it * RPI + lane / CPR, m = mw + row;
-    const uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * 256 + ((c ^ (row & 15)) << 4));
-    if (m < a.M && n < (COLS == 64 ? a.N / 2 : a.N)) *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = v;
-  }
-}
-template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true, bool LDS_OUT = false>
+template <int EPI, int WTN = 4, int WTM = 4, bool ROPE_OK = true>
 __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)[WTN][WTM], int m0, int n0, int wm, int wn, int fr, int fq,
-                                              const uint16_t* gelu_lut = nullptr, char* wave_lds = nullptr) {
+                                              const uint16_t* gelu_lut = nullptr) {
   m0 += wm * WTM * 16 - wm * 64;   // the code below adds wm * 64 / wn * 64 (the 4 x 4 layout)
   n0 += wn * WTN * 16 - wn * 64;
-  const int mw_ = m0 + wm * 64, nw_ = n0 + wn * 64;   // first token / feature of this wave's tile
   auto emit = [&](int m, int n, uint2 w) __attribute__((always_inline)) {
-    if (LDS_OUT) lds_put4(wave_lds, m - mw_, n - nw_, w);
-    else *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = w;
+    *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + n) = w;
   };
   const bool vec_ok = (a.ldc % 4 == 0) && (a.N % 4 == 0) && (a.resid == nullptr || a.ldr % 4 == 0);
   if (EPI == EPI_SWIGLU) {
@@ -220,8 +187,7 @@ __device__ __forceinline__ void gemm_epilogue(const PcyGemmArgs& a, f32x4 (&acc)
           const float g = rbf(acc[i][j][r]), u = rbf(acc[i + 1][j][r]);
           o[r] = rbf(silu_f(g)) * u;
         }
-        if (LDS_OUT) lds_put4(wave_lds, m - mw_, f - (nw_ >> 1), make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3])));
-        else *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
+        *reinterpret_cast<uint2*>(a.C + (size_t)m * a.ldc + f) = make_uint2(pack_bf(o[0], o[1]), pack_bf(o[2], o[3]));
       }
     }
     return;
@@ -395,7 +361,7 @@ __device__ __forceinline__ void gemm_epilogue_perm(const PcyGemmArgs& a, f32x4 (
                       (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
   // (a wave tile that lies entirely behind the rotated columns -- the V third of a qkv projection -- takes the plain path below: no
   // position / table loads; rot = false gives the same bits)
-  if constexpr (EPI == EPI_STORE) if (a.rope_cos != nullptr && (nw < a.rope_ncols || a.rope_noskip)) {
+  if constexpr (EPI == EPI_STORE) if (a.rope_cos != nullptr && nw < a.rope_ncols) {
     // fused rotary (head_dim 64; callers guarantee N % 64 == 0 and 16-byte aligned rows): a head = 4 tiles, the lane holds
     // e = fq*8 + [0, 8) in tiles (4hg, 4hg+1) and the partners e + 32 in tiles (4hg+2, 4hg+3).  Loads first: bias, positions,
     // then per token four 16-byte pieces of its cos / sin rows (shared by every head).
@@ -695,12 +661,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
     const int cur = kt & 1;
     const char* Acur = smem + cur * 2 * TILE_B;
     const char* Wcur = Acur + TILE_B;
-#ifndef PCY_G128_VARIANT
-#define PCY_G128_VARIANT 0
-#endif
-    // (PCY_G128_VARIANT 1 = the split + priority schedule of gemm_kernel_big: no gain here, two workgroups per CU already overlap:
-    // ESM wo 638 vs 641, Llama qkv T512 482 vs 530 TFLOP/s)
-    if ((!PCY_G128_VARIANT || BK != 64) && kt + 1 < nk) {
+    // (the split + priority schedule of gemm_kernel_big buys nothing here -- two workgroups per CU already overlap: ESM wo 638 vs 641,
+    // Llama qkv T512 482 vs 530 TFLOP/s -- and was removed)
+    if (kt + 1 < nk) {
       char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
       stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
       stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
@@ -712,18 +675,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(PcyGemmArgs a) {
       for (int j = 0; j < 4; ++j) xf[j] = lds_frag<BK>(Acur, wm * 64 + j * 16 + fr, kb * 4 + fq);
 #pragma unroll
       for (int i = 0; i < 4; ++i) wf[i] = lds_frag<BK>(Wcur, wn * 64 + i * 16 + fr, kb * 4 + fq);
-      if (PCY_G128_VARIANT && BK == 64 && kt + 1 < nk) {   // as in gemm_kernel_big: half of the next stage behind each kb's reads
-        char* Anext = smem + (cur ^ 1) * 2 * TILE_B;
-        if (kb == 0) stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.A, a.lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-        else stage_tile<BK, 128, 4, 0, PCY_STG_SMALL>(a.W, a.K, n0, a.N, (kt + 1) * BK, Anext + TILE_B, wave, lane);
-      }
-      if (PCY_G128_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      if (PCY_G128_VARIANT) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
@@ -896,78 +852,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(PcyGemmArgs a, int s
 // 4 + fq) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) -- A and B use the same k -> slot map, which is all
 // a dot product needs.  Twice the k per MFMA issue slot at the MX rate = 2x the bf16 flops for the same LDS / global bytes.
 // The per-token / per-output-row dequantisation scales are applied to the fp32 accumulators in front of the epilogue.
-// Epilogue of the 256 x 256 kernel through LDS (plain / residual epilogues): the accumulator layout gives a lane 4 consecutive
-// features of one token, so a direct store instruction writes 16 row segments of 32 bytes -- a quarter of a 128-byte line each,
-// 1024 partial-line writes per wave tile.  Here the wave first parks its bf16 tile [64 tokens][128 features] in its OWN 16 KiB of
-// the (now idle) stage buffers -- 16-byte chunk c of row r at position c ^ (r & 15): conflict-free 8-byte writes and 16-byte
-// reads, no barrier, the tile is wave-private -- and then moves whole rows: 16 lanes x 16 bytes = 256 contiguous bytes per
-// token row, for the residual read as well as for the store.  Same values, same rounding order (bias, round, + residual,
-// round) as gemm_epilogue.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_wide(const PcyGemmArgs& a, f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane,
-                                                   char* wave_lds) {
-  const int fr = lane & 15, fq = lane >> 4;
-  const int nw = n0 + wn * 128, mw = m0 + wm * 64;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = nw + i * 16 + fq * 4;
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-      const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + (n + 3 < a.N ? n : 0));
-      b[0] = lo_bf(bb.x); b[1] = hi_bf(bb.x); b[2] = lo_bf(bb.y); b[3] = hi_bf(bb.y);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = j * 16 + fr;
-      const int chunk = 2 * i + (fq >> 1);
-      const uint2 w = make_uint2(pack_bf(acc[i][j][0] + b[0], acc[i][j][1] + b[1]), pack_bf(acc[i][j][2] + b[2], acc[i][j][3] + b[3]));
-      *reinterpret_cast<uint2*>(wave_lds + row * 256 + ((chunk ^ (row & 15)) << 4) + (fq & 1) * 8) = w;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  const int c = lane & 15;
-  const int n = nw + c * 8;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 4 + (lane >> 4);
-    const int m = mw + row;
-    uint4 v = *reinterpret_cast<const uint4*>(wave_lds + row * 256 + ((c ^ (row & 15)) << 4));
-    if (m >= a.M || n >= a.N) continue;
-    if (EPI == EPI_RESID) {
-      const uint4 r = *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.ldr + n);
-      v.x = pack_bf(lo_bf(v.x) + lo_bf(r.x), hi_bf(v.x) + hi_bf(r.x));
-      v.y = pack_bf(lo_bf(v.y) + lo_bf(r.y), hi_bf(v.y) + hi_bf(r.y));
-      v.z = pack_bf(lo_bf(v.z) + lo_bf(r.z), hi_bf(v.z) + hi_bf(r.z));
-      v.w = pack_bf(lo_bf(v.w) + lo_bf(r.w), hi_bf(v.w) + hi_bf(r.w));
-    }
-    *reinterpret_cast<uint4*>(a.C + (size_t)m * a.ldc + n) = v;
-  }
-}
-
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
   return (i32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
-// SPLITK: grid = tiles x a.splits, workgroup (tile, split) accumulates k in [split * K / splits, +K / splits) and stores its fp32
-// partial tile to a.splitk_ws[split] (finished by gemm_splitk_epilogue / the finish + norm kernel, as for gemm_splitk_kernel: same
-// k order per element, same bits); EPI is then ignored.
-template <int EPI, bool F8 = false, bool WIDE = false, bool SPLITK = false, bool NOPERM = false, int STG = 0>
+// STG: 1 = lock-step k-loop over `buffer_load ... lds` staging (the fp8 kernels), 2 = the software-pipelined k-loop (bf16).
+// NOPERM: W rows in their natural order + the 8-byte epilogue (SwiGLU, fp8 by default); otherwise wperm_row order + 16-byte epilogue.
+template <int EPI, bool F8 = false, bool NOPERM = false, int STG = 2>
 __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
   constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
-  // W rows in wperm_row order + the 16-byte epilogue (the LDS-epilogue experiment, the K-split partial store and -- for now --
-  // the SwiGLU epilogue keep the natural order)
-  constexpr bool PERM = !WIDE && !SPLITK && !NOPERM;   // NOPERM: the natural row order (PCY_GEMM_PERM=0, A/B measurements)
+  constexpr bool PERM = !NOPERM;
   constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
+  static_assert(STG == 1 || (STG == 2 && !F8), "bf16: pipelined loop; fp8: lock-step loop");
   extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
   char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = STG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = SPLITK ? gridDim.x / a.splits : gridDim.x, bid = SPLITK ? blockIdx.x % nwg : blockIdx.x;
-  const int split = SPLITK ? blockIdx.x / nwg : 0;
+  const int nwg = gridDim.x, bid = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   int m0, n0;
@@ -980,8 +884,8 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
     for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
-  const int nk = F8 ? a.K / 128 : (SPLITK ? a.K / a.splits / BK : a.K / BK);
-  const int kbeg = SPLITK ? split * (a.K / a.splits) : 0;
+  const int nk = F8 ? a.K / 128 : a.K / BK;
+  constexpr int kbeg = 0;
   const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
   stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg, smem, wave, lane);
   stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg, smem + TILE_A, wave, lane);
@@ -1033,15 +937,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       __syncthreads();   // (lgkmcnt(0): this wave's reads of stage kt are complete; vmcnt(0): its pieces of stage kt+1 have landed)
       // (the eight pieces in front of the sub-step; spreading them over the MFMA rows with sched_group_barrier(0x020) made hipcc
       // cluster them -- each needs its own M0 -- and undo the MFMA : read interleave below)
-#ifndef PCY_PIPE_SPLIT_DMA
-#define PCY_PIPE_SPLIT_DMA 1   // 0: all eight pieces of stage kt+2 right behind the barrier (the first form)
-#endif
-      if ((!PCY_PIPE_SPLIT_DMA) && kt + 2 < nk) {
-        stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
-        stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
-      }
-      // sub-step 1: MFMAs on (xb, wf); prefetch sub-step 0 of stage kt+1 into (xa, wf)
-      if (PCY_PIPE_SPLIT_DMA && kt + 2 < nk) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
+      // sub-step 1: MFMAs on (xb, wf); prefetch sub-step 0 of stage kt+1 into (xa, wf).  The DMA of stage kt+2 goes out in two halves: A
+      // here, W behind the fourth MFMA row (all eight pieces right behind the barrier: +2.7 % instead of +7 % on the Llama prefill)
+      if (kt + 2 < nk) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 2) * BK, const_cast<char*>(Acur), wave, lane);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTM; ++i) {
@@ -1052,11 +950,9 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < WTM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-      if (PCY_PIPE_SPLIT_DMA) {   // the W half of stage kt+2 behind the first four rows (the A half went out in front of them)
-        __builtin_amdgcn_s_setprio(0);
-        if (kt + 2 < nk) stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
-        __builtin_amdgcn_s_setprio(1);
-      }
+      __builtin_amdgcn_s_setprio(0);   // the W half of stage kt+2 behind the first four rows (the A half went out in front of them)
+      if (kt + 2 < nk) stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 2) * BK, const_cast<char*>(Wcur), wave, lane);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = WTM; i < WTN; ++i) {
 #pragma unroll
@@ -1068,100 +964,33 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       __builtin_amdgcn_s_setprio(0);
     }
   } else {
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const char* Acur = smem + cur * (TILE_A + TILE_W);
-    const char* Wcur = Acur + TILE_A;
-// PCY_BIG_VARIANT (bits): 1 = the next stage's DMA is issued in two halves, A behind the first 32-k step's fragment reads and
-// W behind the second's, instead of all eight pieces at the top of the k-step; 2 = s_setprio(1) around each block of 32 MFMAs.
-// Measured at 4096^3 / ESM qkv / ESM fc2: neither 1195 / 783 / 925 TFLOP/s, split only 1161 / 766 / 890, priority only 1198 /
-// 783 / 932, BOTH 1258 / 822-842 / 976-997 (shipped); one piece after every 8 MFMAs (bit 4) 1164 / 780 / 890; the whole stage behind the
-// first sub-step 1192-1212 / 783-822 / 930-940; two pieces before and two in the middle of each sub-step: equal to the shipped one.
-#ifndef PCY_BIG_VARIANT
-#define PCY_BIG_VARIANT 3
-#endif
-#ifndef PCY_F8_VARIANT
-#define PCY_F8_VARIANT 0
-#endif
-    if (((F8 && !PCY_F8_VARIANT) || (!F8 && !(PCY_BIG_VARIANT & 1))) && kt + 1 < nk) {
-      char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
-    }
-    if constexpr (F8) {
+    // fp8: lock-step loop, the whole next stage requested at the top of the k-step (the split + priority schedule of the bf16 loop
+    // measured no better here: 1609-1615 vs 1619-1620 TFLOP/s)
+    static_assert(F8, "the lock-step loop is the fp8 form");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* Acur = smem + cur * (TILE_A + TILE_W);
+      const char* Wcur = Acur + TILE_A;
+      if (kt + 1 < nk) {
+        char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
+        stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
+        stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
+      }
       i32x8 xf[WTM];
 #pragma unroll
       for (int j = 0; j < WTM; ++j)
         xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
-      // PCY_F8_VARIANT 1: the A stage behind the x fragment reads, the W stage after half of the MFMAs, priority raised
-      // (measured no better than the plain order on the fp8 prefill: 1609-1615 vs 1619-1620 TFLOP/s; off)
-      if (PCY_F8_VARIANT && kt + 1 < nk)
-        stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W), wave, lane);
-      if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < WTN; ++i) {
-        const i32x8 wf = cat_frag(lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), fq), lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), 4 + fq));
+        const int wr = wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr);
+        const i32x8 wf = cat_frag(lds_frag<BK, SWW>(Wcur, wr, fq), lds_frag<BK, SWW>(Wcur, wr, 4 + fq));
 #pragma unroll
         for (int j = 0; j < WTM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        if (PCY_F8_VARIANT && i == WTN / 2 - 1 && kt + 1 < nk) {
-          __builtin_amdgcn_s_setprio(0);
-          stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, smem + (cur ^ 1) * (TILE_A + TILE_W) + TILE_A, wave, lane);
-          __builtin_amdgcn_s_setprio(1);
-        }
       }
-      if (PCY_F8_VARIANT) __builtin_amdgcn_s_setprio(0);
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < BK / 32; ++kb) {
-        bf16x8 xf[WTM], wf[WTN];
-#pragma unroll
-        for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
-        if ((PCY_BIG_VARIANT & 1) && !(PCY_BIG_VARIANT & 4) && kt + 1 < nk) {   // one operand's stage behind each kb's fragment reads
-          char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-          if (kb == 0) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane);
-        }
-        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) {
-#pragma unroll
-          for (int j = 0; j < WTM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-          if ((PCY_BIG_VARIANT & 4) && (i & 1) && kt + 1 < nk) {   // one DMA piece after every 8 MFMAs
-            char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-            if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
-            if (kb == 0) stage_piece<BK, TBM, NW>(a.A, lda, m0, a.M, kbeg + (kt + 1) * BK, Anext, wave, lane, i >> 1);
-            else stage_piece<BK, TBN, NW>(a.W, ldw, n0, a.N, kbeg + (kt + 1) * BK, Anext + TILE_A, wave, lane, i >> 1);
-            if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
-          }
-        }
-        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
-      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
-  }   // (lock-step loop)
-  if constexpr (SPLITK) {   // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
-    float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) {
-      const int m = m0 + wm * WTM * 16 + j * 16 + fr;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int i = 0; i < WTN; ++i) {
-        const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
-        if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * a.N + n) = acc[i][j];
-        else
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) ws[(size_t)m * a.N + n + r] = acc[i][j][r];
-      }
-    }
-    return;
   }
   if constexpr (F8) {
     // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
@@ -1190,21 +1019,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
       if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<4, WTM>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, sx);
       else if constexpr (PERM) gemm_epilogue_perm<EPI, 4, WTM, 1>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, nullptr, sx);
       else gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
-    }
-    return;
-  }
-  if constexpr (WIDE) {
-    // whole-row stores through the (now idle: every wave has passed the barrier that closed the last k-step) stage buffers, 16 KiB
-    // per wave; the ESM GELU table sits behind them (the launcher allocates 12 KiB more)
-    char* wave_lds = smem + wave * 16384;
-    if constexpr (EPI == EPI_RESID) {
-      gemm_epilogue_wide<EPI>(a, acc, m0, n0, wm, wn, lane, wave_lds);
-    } else {
-      const uint16_t* lut = nullptr;
-      if constexpr (EPI == EPI_GELU_ESM) { gelu_lut_to_lds<512>(smem + 2 * (TILE_A + TILE_W)); lut = reinterpret_cast<const uint16_t*>(smem + 2 * (TILE_A + TILE_W)); }
-      gemm_epilogue<EPI, WTN, WTM, true, true>(a, acc, m0, n0, wm, wn, fr, fq, lut, wave_lds);
-      if constexpr (EPI == EPI_SWIGLU) gemm_wide_flush<64>(a, wave_lds, m0 + wm * 64, (n0 + wn * 128) >> 1, lane);
-      else gemm_wide_flush<128>(a, wave_lds, m0 + wm * 64, n0 + wn * 128, lane);
     }
     return;
   }
@@ -1231,181 +1045,6 @@ __global__ __launch_bounds__(512) void gemm_kernel_big(PcyGemmArgs a) {
   else gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
 }
 
-// Persistent variant of gemm_kernel_big for the ESM fc1 GEMM (EPI_GELU_ESM, K = 1280: 20 k-steps per tile, so the first-stage
-// round trip and the table-lookup epilogue are a large share of a tile).  The other epilogues keep gemm_kernel_big: inside a
-// tile loop their register demand passes 256 VGPRs (measured: spills, fp8 prefill -12 %).
-// DQ = true: the tiles of an XCD's contiguous run are handed out by a per-XCD atomic counter instead of a fixed stride, and the
-// workgroups take their FIRST tile after a delay of 0..7 eighths of a tile time.  One workgroup per CU and tiles of equal length
-// keep every CU in lock-step otherwise: all 256 epilogues (33.5 MB of stores) hit HBM in the same ~8 us while every matrix pipe
-// idles, once per tile round.  Out of phase, a CU's epilogue shares the memory system with 7/8 of the chip in its mainloop; the
-// queue makes the late starters take fewer tiles, so the stagger does not come back as a tail.  a.tile_ctr: 9 zeroed words
-// (8 XCD heads + an exit counter; the last workgroup to leave zeroes them again).
-template <int EPI, bool F8 = false, bool DQ = false, bool NOPERM = false, int STG = 0>
-__global__ __launch_bounds__(512) void gemm_kernel_big_persist(PcyGemmArgs a) {
-  constexpr int BK = 64, TBM = 256, TBN = 256, WTM = 4, WTN = 8, NW = 8;
-  constexpr int TILE_A = TBM * BK * 2, TILE_W = TBN * BK * 2;   // 32 KiB each
-  constexpr bool PERM = !NOPERM;   // as in gemm_kernel_big
-  constexpr int SWW = PERM ? (EPI == EPI_SWIGLU ? 2 : 1) : 0;
-  extern __shared__ __attribute__((aligned(1024))) char smem_dyn[];
-  char* smem = smem_dyn;
-  const int lane = threadIdx.x & 63, wave = STG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  // workgroup b computes tiles b, b + gridDim.x, ... (gridDim.x = min(tiles, CUs), a multiple of 8 or the whole grid, so b % 8
-  // -- the XCD -- is the same for all of them and each XCD still walks one contiguous run of the rasterised tile order).  The
-  // first k-stage of the NEXT tile is requested before the epilogue of the current one: its L2 / HBM round trip runs under
-  // the table lookups and stores (fc1 548 -> 526 us at M = 32832).
-  constexpr bool PERSIST = true;
-  const int ntiles = ((a.M + TBM - 1) / TBM) * ((a.N + TBN - 1) / TBN);
-  const int xq = ntiles >> 3, xr = ntiles & 7;
-  auto tile_of = [&](int vb) { const int xcd = vb & 7; return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (vb >> 3); };
-  __shared__ int next_slot;
-  const int my_xcd = blockIdx.x & 7;
-  const int run_start = my_xcd < xr ? my_xcd * (xq + 1) : xr * (xq + 1) + (my_xcd - xr) * xq;
-  const int run_len = xq + (my_xcd < xr ? 1 : 0);
-  int cur_j = 0;
-  if (DQ) {
-    const int nk0 = F8 ? a.K / 128 : a.K / BK;
-    const int phase = ((blockIdx.x >> 3) * 5) & 7;                       // neighbours in dispatch order get distant phases
-    for (int i = 0; i < phase * nk0; ++i) __builtin_amdgcn_s_sleep(7);    // ~ phase/8 of a tile: a k-step is ~3.4 k cycles, s_sleep(7) = 448
-    if (threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);
-    __syncthreads();
-    cur_j = next_slot;
-    __syncthreads();
-    if (cur_j >= run_len) {
-      if (threadIdx.x == 0 && atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x - 1)
-        for (int i = 0; i < 9; ++i) a.tile_ctr[i] = 0;
-      return;
-    }
-  }
-  int m0, n0;
-  tile_origin<TBM, TBN>(a, DQ ? run_start + cur_j : tile_of(blockIdx.x), m0, n0);
-  // leading dimensions and k offsets in 2-byte units (an e4m3 row of K bytes = K/2 units; one stage = 128 bytes of k)
-  const int nk = F8 ? a.K / 128 : a.K / BK;
-  const int lda = F8 ? a.lda / 2 : a.lda, ldw = F8 ? a.K / 2 : a.K;
-  stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, 0, smem, wave, lane);
-  stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, 0, smem + TILE_A, wave, lane);
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int vb = blockIdx.x; DQ ? true : (PERSIST ? vb < ntiles : vb == (int)blockIdx.x); vb += gridDim.x) {
-  if (DQ && threadIdx.x == 0) next_slot = (int)atomicAdd(a.tile_ctr + my_xcd, 1u);   // the NEXT tile: the answer is read after the mainloop's barriers
-  f32x4 acc[WTN][WTM];
-#pragma unroll
-  for (int i = 0; i < WTN; ++i)
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // stage 0 of this tile has landed; every wave has left the previous tile's epilogue
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const char* Acur = smem + cur * (TILE_A + TILE_W);
-    const char* Wcur = Acur + TILE_A;
-    if ((F8 || !(PCY_BIG_VARIANT & 1)) && kt + 1 < nk) {
-      char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-      stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-      stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
-    }
-    if constexpr (F8) {
-      i32x8 xf[WTM];
-#pragma unroll
-      for (int j = 0; j < WTM; ++j)
-        xf[j] = cat_frag(lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, fq), lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, 4 + fq));
-#pragma unroll
-      for (int i = 0; i < WTN; ++i) {
-        const i32x8 wf = cat_frag(lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), fq), lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), 4 + fq));
-#pragma unroll
-        for (int j = 0; j < WTM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < BK / 32; ++kb) {
-        bf16x8 xf[WTM], wf[WTN];
-#pragma unroll
-        for (int j = 0; j < WTM; ++j) xf[j] = lds_frag<BK>(Acur, wm * WTM * 16 + j * 16 + fr, kb * 4 + fq);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i) wf[i] = lds_frag<BK, SWW>(Wcur, wn * WTN * 16 + (PERM ? wperm<EPI>(i, fr) : i * 16 + fr), kb * 4 + fq);
-        if ((PCY_BIG_VARIANT & 1) && kt + 1 < nk) {
-          char* Anext = smem + (cur ^ 1) * (TILE_A + TILE_W);
-          if (kb == 0) stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, m0, a.M, (kt + 1) * BK, Anext, wave, lane);
-          else stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, n0, a.N, (kt + 1) * BK, Anext + TILE_A, wave, lane);
-        }
-        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < WTN; ++i)
-#pragma unroll
-          for (int j = 0; j < WTM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        if (PCY_BIG_VARIANT & 2) __builtin_amdgcn_s_setprio(0);
-      }
-    }
-    __syncthreads();
-  }
-  // next tile: origin + its first k-stage into buffer 0 (all waves passed the barrier that ended the last k-step, so no
-  // wave still reads LDS; the ESM GELU table goes to buffer 1)
-  const int nvb = vb + gridDim.x;
-  int nm0 = 0, nn0 = 0;
-  const int nj = DQ ? next_slot : 0;                 // (written before the k-loop, whose barriers order it)
-  const bool have_next = DQ ? nj < run_len : (PERSIST && nvb < ntiles);
-  if (have_next) {
-    tile_origin<TBM, TBN>(a, DQ ? run_start + nj : tile_of(nvb), nm0, nn0);
-    stage_tile<BK, TBM, NW, 0, STG>(a.A, lda, nm0, a.M, 0, smem, wave, lane);
-    stage_tile<BK, TBN, NW, SWW, STG>(a.W, ldw, nn0, a.N, 0, smem + TILE_A, wave, lane);
-  }
-  if constexpr (F8) {
-    // dequantise: lane holds D[n = fq*4 + r][m = fr] of tile (i, j); (acc * sa[m]) * sw[n], in this order (oracle/fp8_ref.py)
-    float sx[WTM];
-#pragma unroll
-    for (int j = 0; j < WTM; ++j) {
-      const int m = m0 + wm * WTM * 16 + j * 16 + fr;
-      sx[j] = a.sa[m < a.M ? m : a.M - 1];
-    }
-    if constexpr (!PERM) {
-#pragma unroll
-    for (int i = 0; i < WTN; ++i) {
-      const int n = n0 + wn * WTN * 16 + i * 16 + fq * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sw = a.sw[n + r < a.N ? n + r : a.N - 1];
-#pragma unroll
-        for (int j = 0; j < WTM; ++j) acc[i][j][r] = (acc[i][j][r] * sx[j]) * sw;
-      }
-    }
-    }
-    // the epilogue in two halves of 64 features: its up-front residual loads (64 VGPRs for the whole 64 x 128 wave tile)
-    // plus the scale registers would spill
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if constexpr (PERM && EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<4, WTM>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, sx);
-      else if constexpr (PERM) gemm_epilogue_perm<EPI, 4, WTM, 1>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0 + wm * 64, n0 + wn * 128 + h * 64, fr, fq, nullptr, sx);
-      else gemm_epilogue<EPI, 4, WTM, false>(a, reinterpret_cast<f32x4(&)[4][WTM]>(acc[h * 4]), m0, n0 + wn * 64 + h * 64, wm, wn, fr, fq);
-    }
-  } else if constexpr (EPI == EPI_GELU_ESM) {
-    if constexpr (PERM) {
-      // sparse table image: positive half over the dead stage buffer 1, negative half 64 KiB further (the launcher allocates 8 KiB
-      // behind the two stage buffers); the fast form where the store can be whole 16-byte pieces, redone with the select form by
-      // the (rare) waves that met a value outside the table
-      char* lut_pos = smem + TILE_A + TILE_W;
-      gelu_lut_to_lds_sparse<512>(lut_pos);
-      const bool vec16 = (a.ldc % 8 == 0) && (a.N % 8 == 0) && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
-                         (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && !a.gelu_select;
-      bool done = false;
-      if (vec16) done = gemm_epilogue_perm_gelu_fast<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, lut_pos);
-      if (!done)
-        gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq, reinterpret_cast<const uint16_t*>(lut_pos), nullptr, GELU_SPARSE_NEG);
-    } else {
-      gelu_lut_to_lds<512>(smem + TILE_A + TILE_W);
-      gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem + TILE_A + TILE_W));
-    }
-  } else {
-    if constexpr (!PERM) gemm_epilogue<EPI, WTN, WTM>(a, acc, m0, n0, wm, wn, fr, fq);
-    else if constexpr (EPI == EPI_SWIGLU) gemm_epilogue_perm_swiglu<WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
-    else gemm_epilogue_perm<EPI, WTN, WTM>(a, acc, m0 + wm * 64, n0 + wn * 128, fr, fq);
-  }
-  m0 = nm0; n0 = nn0;
-  if (DQ && !have_next) break;
-  }   // tile loop
-  if (DQ && threadIdx.x == 0 && atomicAdd(a.tile_ctr + 8, 1u) == gridDim.x - 1)
-    for (int i = 0; i < 9; ++i) a.tile_ctr[i] = 0;
-}
-
 }  // namespace
 // which kernel a launch went to (test instrumentation behind pcy_debug_dispatch_count: parity tests assert that they reach the
 // kernel they claim to test)
@@ -1428,21 +1067,11 @@ inline bool gemm_noperm(int epi, bool f8) {
   const int bit = epi == EPI_STORE ? 1 : epi == EPI_RESID ? 2 : epi == EPI_GELU_ESM ? 4 : epi == EPI_SWIGLU ? 8 : 0;
   return !(mask & bit) || (f8 && !(mask & 16));
 }
-// LDS-DMA pieces of the bf16 256 x 256 kernels as buffer loads with a scalar k offset (stage_tile, STG = 1); PCY_GEMM_STG=0 (read per
-// call) = the global_load_lds form.  Interleaved A/B: ESM2-650M batch 41.2 -> 40.6 ms, Llama-3-8B prefill 64 x 450 tokens 1048 -> 1055
-// TFLOP/s, one 512-token prompt unchanged; 16-40 VGPRs fewer.
-inline bool gemm_stg() { const char* e = getenv("PCY_GEMM_STG"); return !(e && atoi(e) == 0); }
-// The software-pipelined k-loop of gemm_kernel_big (STG = 2; STORE / RESID / SwiGLU epilogues), the default.  Interleaved A/B against the
-// lock-step loop over the same buffer-load staging (STG = 1): Llama-3-8B prefill 64 x 450 tokens 1068 -> 1143 TFLOP/s, one 512-token
-// prompt 10.40 -> 9.97 ms, ESM2-650M batch 40.3 -> 39.55 ms (its first form, all eight DMA pieces in front of the second sub-step, gave
-// +2.7 % on the Llama prefill and nothing at K = 1280; with the A half in front and the W half behind the fourth MFMA row it pays at every
-// K).  PCY_GEMM_STG=1 / =0 switch it off.
-inline bool gemm_pipe(int K) {
-  const char* e = getenv("PCY_GEMM_STG");
-  if (e) return atoi(e) == 2;
-  (void)K;
-  return true;
-}
+// (History of the 256 x 256 k-loop, all interleaved A/Bs, now the only forms left: LDS-DMA pieces as `buffer_load ... lds` with a scalar k
+// offset instead of global_load_lds -- ESM2-650M batch 41.2 -> 40.6 ms, 16-40 VGPRs fewer; the software-pipelined loop with the stage
+// DMA in two halves -- Llama-3-8B prefill 64 x 450 tokens 1068 -> 1143 TFLOP/s, ESM batch 40.3 -> 39.55 ms.  The lock-step bf16 loops,
+// the persistent tile loop for the ESM-GELU GEMM (39.60 vs 39.36 ms per batch), the per-XCD tile queue, the epilogue through LDS and
+// the 256 x 256 K-split form were measured slower or equal and REMOVED in round 4; see DESIGN.md for their numbers.)
 template <int EPI>
 void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   constexpr int smem = 2 * (256 + 256) * 64 * 2;
@@ -1451,52 +1080,33 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   const int tn = (a.N + 255) / 256;
   long gnb = (5L << 19) / ((long)256 * a.K);
   if (gnb < 2) gnb = 2;
-  { const char* ge = getenv("PCY_GEMM_GN"); if (ge && atoi(ge) > 0) gnb = atoi(ge); }
   b.gn = (int)(gnb > tn ? tn : gnb);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    configured = true;
-  }
   ++g_pcy_dispatch[PCY_DISPATCH_GEMM_FP8];
   if (gemm_noperm(EPI, true)) {
     static bool configured_n = false;
     if (!configured_n) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       configured_n = true;
     }
-    if (gemm_stg()) {
-      static bool configured_ns = false;
-      if (!configured_ns) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        configured_ns = true;
-      }
-      hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, false, true, 1>), dim3(tiles_big), dim3(512), smem, s, b);
-      return;
-    }
-    hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, false, true>), dim3(tiles_big), dim3(512), smem, s, b);
+    hipLaunchKernelGGL((gemm_kernel_big<EPI, true, true, 1>), dim3(tiles_big), dim3(512), smem, s, b);
     return;
   }
-  hipLaunchKernelGGL((gemm_kernel_big<EPI, true>), dim3(tiles_big), dim3(512), smem, s, b);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, 1>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
-template <int EPI, bool NOPERM, int STG>
+template <int EPI, bool NOPERM>
 void launch_big_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, int smem) {
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, false, false, NOPERM, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, NOPERM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_kernel_big<EPI, false, false, false, NOPERM, STG>), grid, dim3(512), smem, s, b);
-}
-template <int EPI, bool NOPERM, int STG>
-void launch_big_persist_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, int smem) {
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big_persist<EPI, false, false, NOPERM, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    configured = true;
-  }
-  hipLaunchKernelGGL((gemm_kernel_big_persist<EPI, false, false, NOPERM, STG>), grid, dim3(512), smem, s, b);
+  hipLaunchKernelGGL((gemm_kernel_big<EPI, false, NOPERM, 2>), grid, dim3(512), smem, s, b);
 }
 
 #include "pcy_gemm_mid.h"
@@ -1508,7 +1118,7 @@ template <int EPI>
 void launch(hipStream_t s, const PcyGemmArgs& a) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if constexpr (EPI != EPI_GELU_ERF) {
-    if (a.mid_cfg > 0 && launch_mid<EPI, false>(s, a, a.mid_cfg)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
+    if (a.mid_cfg > 0 && launch_mid<EPI>(s, a, a.mid_cfg)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
   }
   constexpr int big_min_m = 2048;
   // 256x256 tiles pay off where the mainloop dominates (measured, M = 32832: qkv 734 -> 804, fc2 827 -> 911 TFLOP/s);
@@ -1541,73 +1151,18 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
       if (tn <= 6) want = tn;
       if (gnb < want) gnb = want;
     }
-    { const char* ge = getenv("PCY_GEMM_GN"); if (ge && atoi(ge) > 0) gnb = atoi(ge); }   // (A/B: column tiles per rasterisation group)
     b.gn = (int)(gnb > tn ? tn : gnb);
-    {
-      static bool configured = false;
-      if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        configured = true;
-      }
-      // epilogue through LDS (whole-row stores; PCY_GEMM_WIDE_EPI=1, same bits as the direct stores).  OFF by default: measured
-      // alone the plain-store shapes with many tile rounds gain (M = 25650: N = 3840 271 -> 241 us, N = 5120 324 -> 298 us, residual
-      // shapes 107 -> 98 / 303 -> 301 us), but inside the encoder / the Llama prefill the interleaved A/B is a wash (ESM2-650M
-      // batch 25: 46.0 vs 46.3 ms; pair scoring 1047 vs 1048 TFLOP/s): the fc1 GEMM loses its persistent tile loop (the table and
-      // the wave tiles do not fit beside a prefetched stage) and the rotary epilogue spills three registers.  The store pattern
-      // is not what a tile round waits for.
-      const char* we = getenv("PCY_GEMM_WIDE_EPI");
-      const int Nout = EPI == EPI_SWIGLU ? a.N / 2 : a.N;
-      b.wide_epi = (we && atoi(we) != 0) && (Nout % 8 == 0) && (a.ldc % 8 == 0) && (a.resid == nullptr || a.ldr % 8 == 0) &&
-                   ((reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.resid)) & 15) == 0 &&
-                   (a.bias == nullptr || (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0) && (a.N % 4 == 0) && EPI != EPI_GELU_ERF &&
-                   EPI != EPI_SWIGLU;   // (the SwiGLU variant of the LDS path does not reproduce the direct stores yet: excluded)
-      if (b.wide_epi) {
-        constexpr int smem_w = smem + (EPI == EPI_GELU_ESM ? GELU_LUT_N * 2 : 0);
-        static bool configured_w = false;
-        if (!configured_w) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
-          configured_w = true;
-        }
-        ++g_pcy_dispatch[EPI == EPI_GELU_ESM ? PCY_DISPATCH_GEMM_BIG_PERSIST : PCY_DISPATCH_GEMM_BIG];
-        hipLaunchKernelGGL((gemm_kernel_big<EPI, false, true>), dim3(tiles_big), dim3(512), smem_w, s, b);
-        return;
-      }
-      // row order (PCY_GEMM_PERM mask) x staging / loop form (PCY_GEMM_STG): every combination is its own instantiation
-      const bool noperm = gemm_noperm(EPI, false);
-      if constexpr (EPI == EPI_GELU_ESM) {
-        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];
-        const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (A/B, tests)
-        b.gelu_select = gs && atoi(gs) == 1;
-        // One tile per workgroup on the pipelined k-loop (default) or the tile loop of gemm_kernel_big_persist (PCY_GELU_PERSIST=1, read per
-        // call): with the fast table epilogue in both, interleaved 39.36 vs 39.60 ms per ESM2-650M batch -- what the tile loop gains
-        // by requesting the next tile's first stage under the epilogue, the pipelined loop gains inside the tile.  (The dispatch counter
-        // keeps one slot for both: "the ESM-GELU 256 x 256 kernel".)
-        const char* gpe = getenv("PCY_GELU_PERSIST");
-        if (!(gpe && atoi(gpe) == 1) && !noperm && gemm_pipe(a.K)) {
-          launch_big_variant<EPI, false, 2>(s, b, dim3(tiles_big), smem);
-          return;
-        }
-        const dim3 gp(tiles_big > 256 ? 256 : tiles_big);
-        if (noperm) launch_big_persist_variant<EPI, true, 0>(s, b, gp, smem);
-        else if (gemm_stg()) launch_big_persist_variant<EPI, false, 1>(s, b, gp, smem + GELU_LUT_HALF * 2);   // (+ the negative half of the sparse table image)
-        else launch_big_persist_variant<EPI, false, 0>(s, b, gp, smem + GELU_LUT_HALF * 2);
-      } else {
-        // (the fc1 kernel's tile loop for the STORE / RESID epilogues, measured once more with the 16-byte epilogue: RESID fits 256
-        // VGPRs and is neutral -- 43.42 vs 43.41 ms per ESM2-650M batch -- the rotary STORE form spills 29 registers: 44.4 ms)
-        ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
-        const int stg = gemm_pipe(a.K) ? 2 : (gemm_stg() ? 1 : 0);
-        const dim3 g(tiles_big);
-        if (noperm) {
-          if (stg == 2) launch_big_variant<EPI, true, 2>(s, b, g, smem);
-          else if (stg == 1) launch_big_variant<EPI, true, 1>(s, b, g, smem);
-          else launch_big_variant<EPI, true, 0>(s, b, g, smem);
-        } else {
-          if (stg == 2) launch_big_variant<EPI, false, 2>(s, b, g, smem);
-          else if (stg == 1) launch_big_variant<EPI, false, 1>(s, b, g, smem);
-          else launch_big_variant<EPI, false, 0>(s, b, g, smem);
-        }
-      }
+    // row order (PCY_GEMM_PERM mask: 16-byte epilogue over permuted W rows, or the natural order) -- both are shipped and compared by tests
+    const bool noperm = gemm_noperm(EPI, false);
+    if constexpr (EPI == EPI_GELU_ESM) {
+      ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];   // (the slot keeps its name: "the ESM-GELU 256 x 256 kernel")
+      const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (tests)
+      b.gelu_select = gs && atoi(gs) == 1;
+    } else {
+      ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
     }
+    if (noperm) launch_big_variant<EPI, true>(s, b, dim3(tiles_big), smem);
+    else launch_big_variant<EPI, false>(s, b, dim3(tiles_big), smem);
     return;
   }
   // Mid-M (128 <= M < 2048 and the 256 x 256 tiling under-fills the chip: one 1024-residue protein, one 512-token prompt): the GEMM is
@@ -1627,7 +1182,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
         const double cost = (double)((t + 255) / 256) * cand[i][1] * cand[i][2] * 10.0 / cand[i][3];
         if (!best || cost < best_cost) { best = cand[i][0]; best_cost = cost; }
       }
-      if (best && launch_mid<EPI, false>(s, a, best)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
+      if (best && launch_mid<EPI>(s, a, best)) { ++g_pcy_dispatch[PCY_DISPATCH_GEMM_MID]; return; }
     }
   }
   // fewer than 192 tiles of 128 x 128 (of 512 slots): 64 x 64 tiles -- four times the workgroups, same arithmetic per element
@@ -1663,7 +1218,6 @@ void pcy_gemm_prepare(hipStream_t s) {
 void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
   if (a0.M <= 0 || a0.N <= 0) return;
   PcyGemmArgs a = a0;
-  { const char* e = getenv("PCY_ROPE_VSKIP"); a.rope_noskip = e && atoi(e) == 0; }   // (A/B: 0 = table loads for the V tiles too)
   if (a.mid_cfg == 0) {   // tools / tests: force a gemm_kernel_mid configuration -- "5" for every GEMM, or per shape "3840x1280=6,1280x5120=5" (N x K)
     const char* e = getenv("PCY_GEMM_MID");
     if (e && !strchr(e, 'x')) a.mid_cfg = atoi(e);
@@ -1689,62 +1243,22 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
     return;
   }
   // split-K: few tiles, long K, plain / residual epilogue, a workspace supplied by the caller
-  // (tools: PCY_GEMM_MID_SK="4096x14336=5:4" = gemm_kernel_mid configuration 5 with 4 K ranges for that N x K)
-  int sk_cfg = 0, sk_splits = 0;
-  if (const char* e = getenv("PCY_GEMM_MID_SK")) {
-    char key[48];
-    snprintf(key, sizeof(key), "%dx%d=", a.N, a.K);
-    const char* hit = strstr(e, key);
-    if (hit && (hit == e || hit[-1] == ',')) {
-      sk_cfg = atoi(hit + strlen(key));
-      const char* c = strchr(hit, ':');
-      sk_splits = c ? atoi(c + 1) : 0;
-    }
-  }
   if (a.mid_cfg <= 0 && a.splitk_ws && (a.epi == EPI_STORE || a.epi == EPI_RESID) && a.rope_cos == nullptr && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (a.resid == nullptr || a.ldr % 4 == 0)) {
     const int tiles = ((a.M + BM - 1) / BM) * tiles_n;
     // the split count depends on (N, K) only -- sized for four row tiles (one 512-token prompt) -- so that a row's result
     // does not change with the number of rows in the batch (tests: batch invariance); callers pass the workspace only
-    // for M <= 1024
-    // PCY_SPLITK_BIG=1 (OFF by default): a split rule sized for the 256 x 256 tiles of one 512-token prompt -- two row tiles x
-    // N / 256 column tiles, split until <= 256 workgroups (Llama-3-8B: qkv 4, o 8, down 8 instead of 2, 4, 4) -- and the 256 x 256
-    // mainloop above 256 rows (below, the 128 x 128 kernel with the SAME split count: same bits for every M).  Measured at T = 512:
-    // the projections themselves 44.8 / 29.8 / 80.3 -> 42 / 30.5 / 67.3 us, but twice the partial sums make the finish launches
-    // 6.5 + 2 x 10.7 -> 9.8 + 2 x 21.1 us: prefill 10.66 -> 11.01 ms.
-    static const bool big_rule = [] { const char* e = getenv("PCY_SPLITK_BIG"); return e && atoi(e) == 1; }();
-    const int tiles_ref = big_rule ? 2 * ((a.N + 255) / 256) : 4 * tiles_n;
+    // for M <= 1024.  (Tried and removed: a rule sized for 256 x 256 tiles with twice the splits -- the projections 44.8 / 29.8 / 80.3
+    // -> 42 / 30.5 / 67.3 us, but twice the partial sums make the finish launches 6.5 + 2 x 10.7 -> 9.8 + 2 x 21.1 us: prefill 10.66 ->
+    // 11.01 ms; gemm_kernel_mid tiles for the partial GEMMs: 10.19 -> 10.33 / 11.2 ms.)
+    const int tiles_ref = 4 * tiles_n;
     int splits = 1;
-    if (big_rule) while (splits < 8 && tiles_ref * splits * 2 <= 256 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
-    else while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    while (splits < 8 && tiles_ref * splits * 2 <= 512 && a.K % (splits * 2 * 64) == 0 && a.K / (splits * 2) >= 512) splits *= 2;
     // (a 2-way split buys less than its finish launch costs: Llama-3-8B qkv at one 512-token prompt 41.3 + 6.4 us split vs 41.9 us as one
     // gemm_kernel_mid launch -- and the rule stays a function of (N, K) only)
-    if (splits == 2 && !big_rule) splits = 1;
-    if (sk_cfg > 0 && sk_splits > 0 && a.K % (sk_splits * 64) == 0) splits = sk_splits;
+    if (splits == 2) splits = 1;
     if (splits > 1 && (size_t)splits * a.M * a.N * 4 <= a.splitk_ws_bytes) {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_SPLITK];
-      bool mid_done = false;
-      if (sk_cfg > 0) {
-        PcyGemmArgs b = a;
-        b.splits = splits;
-        mid_done = launch_mid<EPI_STORE, true>(s, b, sk_cfg);
-      }
-      if (mid_done) {
-      } else if (big_rule && a.M > 256) {
-        constexpr int smem = 2 * (256 + 256) * 64 * 2;
-        static bool configured = false;
-        if (!configured) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI_STORE, false, false, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          configured = true;
-        }
-        PcyGemmArgs b = a;
-        const int tn = (a.N + 255) / 256;
-        long gnb = (5L << 19) / ((long)256 * (a.K / splits) * 2);
-        if (gnb < 2) gnb = 2;
-        b.gn = (int)(gnb > tn ? tn : gnb);
-        b.splits = splits;
-        hipLaunchKernelGGL((gemm_kernel_big<EPI_STORE, false, false, true, false, 2>), dim3(((a.M + 255) / 256) * tn * splits), dim3(512), smem, s, b);
-      } else
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
       // residual epilogue + the RMSNorm that follows in ONE finish launch (one workgroup per row) where the caller asks for it

@@ -20,7 +20,7 @@
 //     register sets, the counted wait one stage earlier -- bit-identical and 8-25 % SLOWER at every shape (o 11.9 -> 13.6 us, fc2 33.9 ->
 //     40.4, fc1 28.0 -> 30.9, Llama qkv 41.0 -> 43.7): two waves per SIMD already cover each other's LDS latency, the earlier wait costs a
 //     stage of prefetch depth)
-//   * SPLITK: grid = tiles x a.splits, fp32 partial tiles to a.splitk_ws (finished by gemm_splitk_epilogue / the finish + norm kernel).
+//   * (tried, dropped: a K-split form writing fp32 partial tiles for the Llama projections at M = 512 -- prefill 10.19 -> 10.33 / 11.2 ms)
 #pragma once
 
 template <int N>
@@ -38,7 +38,7 @@ __device__ __forceinline__ void mid_wait_left(int left) {
 
 // (the body is a __device__ function: buffer-resource builtins written directly inside a __global__ template make the HOST pass drop the
 // kernel's stub without a diagnostic -- undefined symbol at load time)
-template <int EPI, int TM, int TN, int WM, int WN, int S, bool SPLITK>
+template <int EPI, int TM, int TN, int WM, int WN, int S>
 __device__ __forceinline__ void gemm_mid_body(const PcyGemmArgs& a) {
   constexpr int BK = 64, NW = WM * WN, NT = NW * 64;
   constexpr int FM = TM / WM / 16, FN = TN / WN / 16;            // MFMA tiles per wave: FM token tiles x FN feature tiles
@@ -50,14 +50,13 @@ __device__ __forceinline__ void gemm_mid_body(const PcyGemmArgs& a) {
   char* smem = smem_dyn;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int nwg = SPLITK ? gridDim.x / a.splits : gridDim.x, bid = SPLITK ? blockIdx.x % nwg : blockIdx.x;
-  const int split = SPLITK ? blockIdx.x / nwg : 0;
+  const int nwg = gridDim.x, bid = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
   int m0, n0;
   tile_origin<TM, TN>(a, tile, m0, n0);
-  const int nk = SPLITK ? a.K / a.splits / BK : a.K / BK;
-  const int kbeg = SPLITK ? split * (a.K / a.splits) : 0;
+  const int nk = a.K / BK;
+  constexpr int kbeg = 0;
 
   // this wave's pieces of a stage: piece p = wave + i * NW; p < PA: rows 8p .. 8p+7 of the A tile, else of the W tile.  Byte offset of the
   // lane inside its operand (row clamped at the matrix edge, 16-byte chunk XOR-swizzled by the row -- the read side applies the same
@@ -139,24 +138,6 @@ __device__ __forceinline__ void gemm_mid_body(const PcyGemmArgs& a) {
     }
   }
 
-  if constexpr (SPLITK) {   // fp32 partial tile: lane holds D[n = fq*4 + r][m = fr] of each 16x16 tile -> one 16-byte store per tile
-    float* ws = a.splitk_ws + (size_t)split * a.M * a.N;
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0 + wm * FM * 16 + j * 16 + fr;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = n0 + wn * FN * 16 + i * 16 + fq * 4;
-        if (n + 3 < a.N) *reinterpret_cast<f32x4*>(ws + (size_t)m * a.N + n) = acc[i][j];
-        else
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) ws[(size_t)m * a.N + n + r] = acc[i][j][r];
-      }
-    }
-    return;
-  }
   if constexpr (EPI == EPI_GELU_ESM) {
     gelu_lut_to_lds<NT>(smem);   // (every stage buffer is dead: the tail waited for vmcnt(0) and every wave passed the last barrier + its reads)
     gemm_epilogue<EPI, FN, FM, false>(a, acc, m0, n0, wm, wn, fr, fq, reinterpret_cast<const uint16_t*>(smem));
@@ -164,8 +145,8 @@ __device__ __forceinline__ void gemm_mid_body(const PcyGemmArgs& a) {
   }
   gemm_epilogue<EPI, FN, FM, (FN % 4 == 0)>(a, acc, m0, n0, wm, wn, fr, fq);
 }
-template <int EPI, int TM, int TN, int WM, int WN, int S, bool SPLITK>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) { gemm_mid_body<EPI, TM, TN, WM, WN, S, SPLITK>(a); }
+template <int EPI, int TM, int TN, int WM, int WN, int S>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) { gemm_mid_body<EPI, TM, TN, WM, WN, S>(a); }
 
 // configurations (id -> TM, TN, WM, WN, S); LDS = S x (TM + TN) x 128 B <= 160 KiB
 #define PCY_MID_CONFIGS(X)                                                                                        \
@@ -182,13 +163,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) {
   X(11, 128, 128, 2, 2, 3) /* as 1, 96 KiB */                                                                      \
   X(12, 128, 128, 2, 2, 5) /* as 1, 160 KiB */
 
-template <int EPI, int TM, int TN, int WM, int WN, int S, bool SPLITK>
+template <int EPI, int TM, int TN, int WM, int WN, int S>
 void launch_mid_cfg(hipStream_t s, const PcyGemmArgs& a0) {
   constexpr int smem = S * (TM + TN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_mid<EPI, TM, TN, WM, WN, S, SPLITK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_mid<EPI, TM, TN, WM, WN, S>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     configured = true;
   }
@@ -201,19 +182,18 @@ void launch_mid_cfg(hipStream_t s, const PcyGemmArgs& a0) {
   while (gn * gn < per_xcd && gn < tn) ++gn;
   if (gn > tn) gn = tn;
   a.gn = gn < 1 ? 1 : gn;
-  const int splits = SPLITK ? a.splits : 1;
-  hipLaunchKernelGGL((gemm_kernel_mid<EPI, TM, TN, WM, WN, S, SPLITK>), dim3(tm * tn * splits), dim3(WM * WN * 64), smem, s, a);
+  hipLaunchKernelGGL((gemm_kernel_mid<EPI, TM, TN, WM, WN, S>), dim3(tm * tn), dim3(WM * WN * 64), smem, s, a);
 }
 
 // cfg = one of PCY_MID_CONFIGS; false if the id is unknown or the epilogue does not fit the shape (rotary needs FN % 4 == 0)
-template <int EPI, bool SPLITK>
+template <int EPI>
 bool launch_mid(hipStream_t s, const PcyGemmArgs& a, int cfg) {
   switch (cfg) {
 #define X(ID, TM_, TN_, WM_, WN_, S_)                                                                   \
     case ID:                                                                                            \
       if (a.rope_cos != nullptr && ((TN_ / WN_ / 16) % 4 != 0)) return false;                           \
       if (EPI == EPI_SWIGLU && ((TN_ / WN_ / 16) % 2 != 0)) return false;                                \
-      launch_mid_cfg<EPI, TM_, TN_, WM_, WN_, S_, SPLITK>(s, a);                                        \
+      launch_mid_cfg<EPI, TM_, TN_, WM_, WN_, S_>(s, a);                                 \
       return true;
     PCY_MID_CONFIGS(X)
 #undef X

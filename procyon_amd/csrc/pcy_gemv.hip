@@ -1014,9 +1014,6 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
 }
 
 
-}  // namespace
-#include "pcy_bdec_chain.h"
-namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Batch-1 decode: gate/up + SwiGLU -> down + residual as ONE launch (PcyMlpChainArgs; pcy_decode_mlp).  The body, shared with the

@@ -26,27 +26,6 @@ struct PcyGemvArgs {
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
-// Batched decode (5..32 rows): everything of a decoder layer after the attention as ONE launch (pcy_bdec_chain.h) --
-//   x += ao . Wo^T ; xn = RMSNorm(x) ln2 ; act = SwiGLU(xn . Wgu^T) ; x += act . Wdown^T ; xn = RMSNorm(x) next_norm ;
-//   [partial sums of xn . next_Wqkv^T -> ws, added up by the next layer's attention launch (PcyDecAttnArgs::qkv_partials)]
-// 256 workgroups (one per CU, all resident), the stages separated by grid barriers on a device counter; the first weight copies
-// of the next stage are issued BEFORE the barrier, so the weight stream does not ramp down and up again at a stage boundary.
-// Same K splits, split order and finish arithmetic as the launch-per-stage path: bit-identical.
-struct PcyBdChainArgs {
-  int B, d, Ko, F, Nq;        // batch rows, model width, K of the o projection (H * dh), ffn width, next qkv width (0: last layer)
-  const bf16_t* ao;           // [B, Ko] attention output
-  bf16_t* x;                  // [B, d] residual stream (in / out)
-  bf16_t* xn;                 // [B, d] normalised stream (out: input of the next projection)
-  bf16_t* act;                // [B, F]
-  const bf16_t *wo, *ln2, *wgu, *wdown, *next_norm, *next_wqkv;
-  float* ws; size_t ws_bytes; // K-split partial sums, >= max(4 B d, 2 B Nq) floats
-  float rms_eps; int rms_cast;
-  unsigned* ctr;              // grid-barrier counter: a multiple of the grid size between launches
-  unsigned* err;              // watchdog word (pcy_wait_give_up)
-  unsigned long long* trace;  // measurement aid: [grid][16] time stamps (nullptr: none)
-};
-// false (nothing launched): geometry not covered or the grid would not be resident at once
-bool pcy_launch_bd_chain(hipStream_t s, const PcyBdChainArgs& a, int n_cu, int* qkv_splits);
 // Launches whose workgroups wait for each other INSIDE the launch need every workgroup resident at once: true when the occupancy
 // query says `grid` workgroups of `block` threads with `smem` bytes of dynamic LDS fit on `n_cu` compute units at the same time
 // (the check a cooperative launch would make, without its +15-19 us per launch; MI355X_MICROARCH.md, coop-launch row).
@@ -100,12 +79,7 @@ struct PcyGemmArgs {
   // optional (split-K path with the residual epilogue only): the finish kernel also writes next_xn = RMSNorm(C) * next_rms_w and
   // sets *fused_next = 1; otherwise *fused_next stays 0 and the caller launches the norm itself.  Same bits as the two launches.
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next; float rms_eps; int rms_cast;
-  // optional: 9 zeroed device words for the dynamic tile queue of the persistent 256 x 256 kernel (see gemm_kernel_big_persist, DQ)
-  unsigned* tile_ctr;
-  int wide_epi;         // set by the launcher: the 256 x 256 kernel's plain / residual epilogue goes through LDS (whole-row stores)
-  int splits;           // set by the launcher (split-K forms): number of K ranges, partial sums in splitk_ws [splits][M][N]
-  int rope_noskip;      // set by the launcher (PCY_ROPE_VSKIP=0): the fused-rotary epilogue loads its tables for un-rotated wave tiles too
-  int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the persistent ESM-GELU kernel skips the fast table epilogue
+  int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the ESM-GELU kernel skips the fast table epilogue
   int mid_cfg;          // > 0: this configuration of gemm_kernel_mid (pcy_gemm_mid.h); 0: the launcher's own choice
 };
 struct pcy_ctx;
@@ -117,7 +91,7 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a);
 void pcy_gemm_prepare(hipStream_t s);
 // launch counters per kernel family (pcy_debug_dispatch_count)
 enum { PCY_DISPATCH_GEMM_128 = 0, PCY_DISPATCH_GEMM_64 = 1, PCY_DISPATCH_GEMM_BIG = 2, PCY_DISPATCH_GEMM_BIG_PERSIST = 3,
-       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_BD_CHAIN = 7, PCY_DISPATCH_GEMM_MID = 8, PCY_DISPATCH_ESM_GRAPH = 9, PCY_DISPATCH_N = 10 };
+       PCY_DISPATCH_GEMM_SPLITK = 4, PCY_DISPATCH_GEMM_FP8 = 5, PCY_DISPATCH_ATTN_FAST = 6, PCY_DISPATCH_UNUSED_7 = 7, PCY_DISPATCH_GEMM_MID = 8, PCY_DISPATCH_ESM_GRAPH = 9, PCY_DISPATCH_N = 10 };
 extern unsigned long long g_pcy_dispatch[PCY_DISPATCH_N];
 
 // per-row symmetric e4m3 quantisation: scale[r] = smallest power of two with amax|x[r,:]| / scale <= 448 (1 for an all-zero row), q = e4m3_rne(x / scale)

@@ -1,5 +1,9 @@
 """Bulk captioning over the MI355X engine: the command line of the reference's scripts/caption_bulk.py (same arguments, same output
-files), batched across proteins (`--batch_size`).  See procyon_amd/pipelines.py."""
+files), batched across proteins (`--batch_size`).  See procyon_amd/pipelines.py.
+
+One permanent difference from the reference script: it generates with the model as loaded (fp32, /root/reference/scripts/caption_bulk.py:72-73);
+KV-cached generation computes in bf16 only on the MI355X engine, so this script casts the model first, as the evaluation framework and the
+retrieval service do (the fp32 operator family covers `forward` -- QA scoring, retrieval -- and `forward_sequences`, not decode)."""
 import argparse
 
 import pandas as pd

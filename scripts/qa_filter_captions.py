@@ -1,5 +1,9 @@
 """QA filtering of generated captions over the MI355X engine: the command line of the reference's scripts/qa_filter_captions.py,
-batched across (protein, caption) pairs (`--batch_size`).  See procyon_amd/pipelines.py."""
+batched across (protein, caption) pairs (`--batch_size`).  See procyon_amd/pipelines.py.
+
+Arithmetic: the reference script runs the model as loaded -- fp32 (/root/reference/scripts/qa_filter_captions.py:17-18, no
+`.bfloat16()`) -- and so does this one by default (the fp32 operator family, procyon_amd/engine_f32.py); `--bf16` casts the model first,
+as the evaluation framework does, for ~10x the rate."""
 import argparse
 
 import torch
@@ -12,7 +16,8 @@ def main(args):
     device = torch.device("cuda")
     data_args, _, _ = UnifiedProCyon.get_checkpoint_configs(resume_from_checkpoint=args.ckpt)
     model, _ = UnifiedProCyon.from_pretrained(checkpoint_dir=args.ckpt)
-    model.bfloat16()
+    if args.bf16:
+        model.bfloat16()
     model.to(device)
     model.eval()
     captions = load_caption_table(args.caption_fpath, args.caption_dir)
@@ -32,6 +37,7 @@ if __name__ == "__main__":
     p.add_argument("--prompt_dataset", default="uniprot")
     p.add_argument("--prompt_relation", default="all")
     p.add_argument("--batch_size", default=16, type=int, help="pairs per engine call (the reference script: 1)")
+    p.add_argument("--bf16", action="store_true", help="cast the model to bfloat16 first (the reference script scores in fp32)")
     a = p.parse_args()
     assert (a.caption_fpath is not None) or (a.caption_dir is not None)
     main(a)

@@ -425,45 +425,6 @@ def test_batched_decode_qkv_finish_in_attention_bit_identical(monkeypatch):
                 assert torch.equal(x, y), (B, use_graph)
 
 
-def test_batched_decode_chain_launch_bit_identical(monkeypatch):
-    """Batched decode, 5..32 rows: o projection + norm + MLP + norm + the next layer's qkv projection as ONE launch with grid barriers
-    (bdec_chain_kernel, default) against the launch-per-stage step (PCY_BD_CHAIN=0).  Same K splits, split order and finish
-    arithmetic: logits, tokens and appended K/V rows are bit-identical, eager and under graph replay, over 3 layers (first / middle
-    / last layer forms of the launch)."""
-    from procyon_amd import synth
-    from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
-    kw = dict(vocab=4096, d=4096, n_layers=3, n_heads=32, n_kv_heads=8, ffn=14336)
-    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=256))
-    T, N = 40, 6
-    for B in (5, 20, 32):
-        torch.manual_seed(B)
-        emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
-
-        def run(chain, use_graph):
-            monkeypatch.setenv("PCY_BD_CHAIN", "1" if chain else "0")
-            cache = eng.new_cache(B, T + N + 2)
-            st = GenState(B, kw["vocab"], N + 2, "cuda")
-            logits, _ = eng.prefill(emb, None, cache, "last")
-            st.logits.copy_(logits); st.pos.fill_(T)
-            eng.pick(cache, st, B, advance_pos=False)
-            out = []
-            for _ in range(N):
-                eng.greedy_steps(cache, st, B, 1, use_graph=use_graph)
-                out.append(st.logits.clone())
-            eng.ctx.sync()
-            return (torch.stack(out).cpu(), st.tokens_out[:, :N + 1].cpu(), cache.k[:, :B, :, T:T + N].cpu(), cache.v[:, :B, :, T:T + N].cpu())
-
-        from procyon_amd import _lib as L
-        n0 = L.load().pcy_debug_dispatch_count(L.DISPATCH_BD_CHAIN)
-        ref = run(False, False)
-        assert L.load().pcy_debug_dispatch_count(L.DISPATCH_BD_CHAIN) == n0
-        for use_graph in (False, True):
-            got = run(True, use_graph)
-            for x, y in zip(got, ref):
-                assert torch.equal(x, y), (B, use_graph)
-        assert L.load().pcy_debug_dispatch_count(L.DISPATCH_BD_CHAIN) >= n0 + 3 * N + 3     # eager: 3 layers x N steps; capture: 3
-
-
 def test_llama2_7b_geometry_layer():
     """BASELINE configs[0] geometry (ProCyon-Split text side: Llama-2-7B, multi-head attention H = Hkv = 32, F = 11008, odd
     vocabulary 32007) at full width, one layer: prefill + 3 cached decode steps against the oracle.  Exercises G = 1 in both

@@ -537,29 +537,6 @@ def test_fastapi_service_round_trip_on_a_synthetic_checkpoint(instruct_env, monk
         assert allr.status_code == 200 and len(allr.json()["results"]) == 20000
 
 
-@pytest.mark.parametrize("epi", [0, 1, 3])
-def test_gemm_epilogue_through_lds_bit_identical(ctx, monkeypatch, epi):
-    """PCY_GEMM_WIDE_EPI=1: the 256 x 256 kernel parks its finished tile in LDS and stores whole rows (plain, residual, ESM GELU
-    epilogues; ragged M and N edges) -- the same values as the direct per-lane stores, bit for bit."""
-    from procyon_amd import _lib as L
-    from procyon_amd.engine import interleave_gate_up
-    M, N, K = 2048 + 300, 1280 + 256 + 8, 1280
-    A, b = rnd(M, K, seed=1).cuda(), rnd(N, seed=3).cuda()
-    if epi == 4:
-        W = interleave_gate_up(rnd(N, K, seed=2, std=0.05), rnd(N, K, seed=4, std=0.05)).cuda()
-        b = None
-    else:
-        W = rnd(N, K, seed=2, std=0.05).cuda()
-    r = rnd(M, N, seed=5).cuda() if epi == 1 else None
-    outs = []
-    for wide in ("0", "1"):
-        monkeypatch.setenv("PCY_GEMM_WIDE_EPI", wide)
-        n0 = _dispatch(L.DISPATCH_GEMM_BIG) + _dispatch(L.DISPATCH_GEMM_BIG_PERSIST)
-        outs.append(ctx.gemm(A, W, b, r, epi).cpu())
-        assert _dispatch(L.DISPATCH_GEMM_BIG) + _dispatch(L.DISPATCH_GEMM_BIG_PERSIST) == n0 + 1     # the 256 x 256 kernels
-    assert torch.equal(outs[0], outs[1])
-
-
 # ---------------------------------------------------------------------------------------------- round 3, later: row order of the 256 x 256 GEMM, V path of the attention
 @pytest.mark.parametrize("epi", [0, 1, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(2048 + 300, 1280 + 256 + 8, 1280), (2304, 2560, 2560)])

@@ -351,3 +351,32 @@ def test_retrieval_plugin_tells_query_datasets_apart_like_isinstance():
     assert f(AASeqTextUnifiedDataset()) is False and f(Both()) is False
     with pytest.raises(ValueError, match="unexpected dataset type"):
         f(object())
+
+
+def test_protein_retrieval_cli_without_inference(tmp_path):
+    """`scripts/protein_retrieval_disease_pheno.py` (/root/reference/scripts/protein_retrieval_disease_pheno.py:52-85): the file-driven
+    command line, in its no-inference mode (`--inference_bool` is a store_false flag: the CLI check that loads no model) -- reads
+    $CHECKPOINT_PATH/protein_target_embeddings.pkl and both description files, logs "DONE WITH ALL WORK"; a missing file or an
+    unset CHECKPOINT_PATH is an error."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    torch.save((torch.randn(5, 8), list(range(5))), ck / "protein_target_embeddings.pkl")
+    (tmp_path / "task.txt").write_text("Retrieve proteins\nfor the disease.")
+    (tmp_path / "dis.txt").write_text("A disease description.")
+    script = os.path.join(root, "scripts", "protein_retrieval_disease_pheno.py")
+    env = dict(os.environ, CHECKPOINT_PATH=str(ck), PYTHONPATH=root, DATA_DIR=str(tmp_path))
+    cmd = [sys.executable, script, "--task_desc_infile", str(tmp_path / "task.txt"), "--disease_desc_infile", str(tmp_path / "dis.txt"),
+           "--inference_bool", "--instruction_source_dataset", "disgenet"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "DONE WITH ALL WORK" in (r.stderr + r.stdout)
+    r = subprocess.run(cmd[:4] + ["--inference_bool"], env=env, capture_output=True, text=True, timeout=300)     # no disease description
+    assert r.returncode != 0 and "disease_desc" in r.stderr
+    env.pop("CHECKPOINT_PATH")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "CHECKPOINT_PATH" in r.stderr

@@ -1,5 +1,5 @@
 """Interleaved A/B of an environment switch that the engine reads per call, on the ESM2-650M encoder (batch 25 x 1024 residues):
-    VAR=PCY_GEMM_WIDE_EPI VALS=0,1 python tools/ab_esm_env.py"""
+    VAR=PCY_GEMM_PERM VALS=0,7 python tools/ab_esm_env.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
