@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--retrieval-proteins", type=int, default=125, help="proteins per rank in the retrieval leg")
+    ap.add_argument("--retrieval-proteins", type=int, default=250, help="proteins per rank in the retrieval leg (10 engine batches: the first batch's host packing is the only one the GPU waits for)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] block (batch-32 generation, pair scoring)")
     return ap.parse_args()
 
