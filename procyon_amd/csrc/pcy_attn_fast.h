@@ -109,9 +109,14 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
 // (first form: [64 keys][64 dh] rows with the 64-byte halves swapped on bit 1 of the key -- conflict-free by the bank formula, but the
 // kernel ran 17 us per layer slower than over the transposed copy)
 typedef __attribute__((ext_vector_type(4))) short fa_s16x4;
-template <int ABL, bool VROW = false>
+// NG = query groups of 32 per wave.  2 (default): a wave alternates two groups, 256 queries per workgroup.  1: one group per wave, 128
+// queries per workgroup, the two 32-key sub-blocks of a tile alternate instead -- for inputs with so few (sequence, head, chunk)
+// workgroups that most CUs would idle (ONE 1024-residue protein: 100 workgroups of NG = 2, 180 of NG = 1, each half as long).  The
+// arithmetic of a query group -- its key blocks in order, its rescale decisions (the __any is over the group's own 64 lanes) -- is the
+// same in both forms: bit-identical results, so which form ran does not show in an embedding.
+template <int ABL, bool VROW = false, int NG = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_fast64_kernel(PcyAttnArgs a, int nchunk) {
-  constexpr int DH = 64, KT = 64, QW = 64, QB = 4 * QW, NBUF = 3;
+  constexpr int DH = 64, KT = 64, QW = 32 * NG, QB = 4 * QW, NBUF = 3;
   constexpr int TILE = KT * DH * 2;                     // 8 KiB: K tile, then Vt tile
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   // Q fragments (B operand of S^T): lane holds Q[query col][16 ks + 8 half .. +8]
   bf16x8 qf[2][4];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     int qrow = qr0 + g * 32 + col;
     qrow = qrow < len ? qrow : len - 1;
     const bf16_t* qp = a.q + (size_t)(t0 + qrow) * a.ldq + a.qcol0 + h * DH + half * 8;
@@ -269,6 +274,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   if (ntiles > 1) stage(1, smem + 2 * TILE);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (NG == 1) {
+    // one group per wave: the tile's two 32-key sub-blocks alternate through (s0, s1) --
+    //   QK(u.b) -> s1 | softmax(s0 = u.a), PV(u.a) | [barrier, DMA of tile u+2] QK((u+1).a) -> s0 | softmax(s1 = u.b), PV(u.b)
+    if (active && nfull > 0) { FA_LOAD_K(smem, 0); FA_QK(s0, 0); }
+    for (int u = 0; u < nfull; ++u) {
+      const char* buf = smem + (u % NBUF) * 2 * TILE;
+      if (active) {
+        FA_LOAD_K(buf, 1);
+        FA_QK(s1, 0);                                      // (u.b)
+        FA_SM_PV(buf, u, 0, s0, m0, l0, o0, false);
+      }
+      if (u + 1 < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see the two-group loop below)
+        __syncthreads();
+        if (u + 2 < ntiles) stage(u + 2, smem + ((u + 2) % NBUF) * 2 * TILE);
+        if (active && u + 1 < nfull) { FA_LOAD_K(smem + ((u + 1) % NBUF) * 2 * TILE, 0); FA_QK(s0, 0); }   // ((u+1).a)
+      }
+      if (active) FA_SM_PV(buf, u, 1, s1, m0, l0, o0, false);
+    }
+    if (active && nfull < ntiles) {                        // the ragged last tile: masked, not pipelined
+      const char* buf = smem + (nfull % NBUF) * 2 * TILE;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (nfull * KT + 32 * sub >= len) break;
+        FA_LOAD_K(buf, sub);
+        FA_QK(s0, 0);
+        FA_SM_PV(buf, nfull, sub, s0, m0, l0, o0, true);
+      }
+    }
+  } else {
   if (active && nfull > 0) { FA_LOAD_K(smem, 0); FA_QK(s0, 0); }
   for (int u = 0; u < nfull; ++u) {
     const char* buf = smem + (u % NBUF) * 2 * TILE;
@@ -304,13 +339,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       FA_SM_PV(buf, nfull, sub, s1, m1, l1, o1, true);
     }
   }
+  }
 #undef FA_LOAD_K
 #undef FA_QK
 #undef FA_SM_PV
   if (!active) return;
   // O^T: lane (query col, half) holds dh = 32 t + 8 i + 4 half + r  ->  four consecutive features per (t, i)
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int qq = qr0 + g * 32 + col;
     const float lg = g ? l1 : l0;
     const float lt = lg + __shfl_xor(lg, 32, 64);
@@ -339,6 +375,13 @@ inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_
   const dim3 grid(nchunk * a.H * a.nseq);
   if (a.v != nullptr) {   // V token-major as the projection wrote it (no transposed copy)
     if ((a.ldv | a.vcol0) % 8) return false;
+    // few workgroups (one or two proteins): one query group per wave, twice the workgroups of half the length (bit-identical; ESM2-650M,
+    // one 1024-residue protein: 29.2 -> 21.2 us per layer, encoder 4.77 -> 4.53 ms)
+    if ((long)nchunk * a.H * a.nseq <= 224) {
+      const int nchunk1 = (a.max_len + 127) / 128;
+      hipLaunchKernelGGL((attn_fast64_kernel<0, true, 1>), dim3(nchunk1 * a.H * a.nseq), dim3(256), 0, s, a, nchunk1);
+      return true;
+    }
     hipLaunchKernelGGL((attn_fast64_kernel<0, true>), grid, dim3(256), 0, s, a, nchunk);
     return true;
   }
