@@ -243,7 +243,7 @@ def main():
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     try:
-        pname = "r03_pmc_decode_step.json" if all_layers else "r02_pmc_decode_layer.json"
+        pname = "r04_pmc_decode_step.json" if all_layers else "r02_pmc_decode_layer.json"
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
         if a.geometry == "full" and one_launch:
             traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "decode_step_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
