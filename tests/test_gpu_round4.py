@@ -124,3 +124,30 @@ def test_esm_encode_replays_a_captured_launch_chain_with_the_same_bits(ctx, monk
     assert cnt() - n0 >= 4, cnt() - n0            # a1 x2 (2nd, 4th, 6th of that shape: >= 3 replays incl. the capturing call) + b1 (2nd, 3rd)
     for k, o in outs:
         assert torch.equal(o, ref[k]), k
+
+
+# ---------------------------------------------------------------------------------------------- the N > 1 path of bench.py on one GPU
+def test_bench_under_a_process_group_splits_rows_and_gathers():
+    """`bench.py` with PCY_BENCH_FORCE_DIST=1 (world 1, backend nccl = RCCL): the WHOLE distributed path of the driver's N > 1 runs --
+    process-group set-up, the sharded retrieval leg with its RCCL all-gather, and the `configs` block with the 32 generation rows / 256
+    pairs split across the ranks (contiguous chunks in rank order, /root/reference/procyon/data/samplers.py:154-196) and ONE gather of the
+    token ids / probabilities through `pcy_allgather` -- so that the first real 8-GPU run cannot fail on plumbing."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, PCY_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--retrieval-proteins", "50"],
+                         capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "RCCL" in d["retrieval"]["collective"]
+    c = d["configs"]
+    for k in ("config3_4a_batch32_mixed_residues_T512", "config3_4b_batch32_ragged_prompts"):
+        assert c[k]["rows"] == 32 and c[k]["ranks"] == 1 and c[k]["rows_per_rank"] == 32 and "all-gather" in c[k]["collective"] and c[k]["tokens_per_s"] > 0
+    assert c["config4_pair_scoring_256"]["pairs"] == 256 and c["config4_pair_scoring_256"]["ranks"] == 1
+    assert "batched_decode_roofline" not in d and "config4_fp8_accuracy_damped_model" not in c      # single-GPU-only blocks
