@@ -224,10 +224,11 @@ def main():
                   decode_step_algorithmic_GB=(step_bytes + kv_bytes) / 1e9,
                   decode_step_GBps=(step_bytes + kv_bytes) / 1e9 / (dec_ms / 1e3))
 
+    off = set(os.environ.get("PCY_DISABLE", "").split(","))   # procyon_amd/csrc/pcy_switch.h
     # ---- roofline of the dominant kernel: the decode LAYER launch (qkv + attention + o + gate/up + down of one layer, one per layer per token)
     one_launch = (cfg.d == 4096 and cfg.ffn == 14336 and cfg.n_heads * cfg.head_dim == 4096 and
-                  all(os.environ.get(k, "1") != "0" for k in ("PCY_DECODE_LAYER", "PCY_ATTN_O")))
-    all_layers = one_launch and os.environ.get("PCY_DECODE_STEP", "1") != "0"   # decode_step_kernel: the 32 layers in ONE launch
+                  not (off & {"decode_layer", "attn_o"}))
+    all_layers = one_launch and "decode_step" not in off   # decode_step_kernel: the 32 layers in ONE launch
     t_mid = int(st.pos.item())                     # cache length of the measured launches (the timed decode ended here)
     reps = 8
     eng.decode_layers(cache, st, 1, 2)

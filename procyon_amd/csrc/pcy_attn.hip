@@ -1071,8 +1071,8 @@ bool pcy_attn_fast_eligible(int dh, int causal, bool has_keep, float scale, int 
   if (!(dh == 64 && !causal && !has_keep && scale == 1.0f && H == Hkv)) return false;
   return ((ldq | ldk | qcol0 | kcol0) % 8) == 0 && ldo % 4 == 0;
 }
-// ... and for reading V token-major where the projection wrote it (PCY_FA_VROW=0: from the transposed copy)
-bool pcy_attn_fast_vrow(int ldv, int vcol0) { const char* e = getenv("PCY_FA_VROW"); return !(e && atoi(e) == 0) && ((ldv | vcol0) % 8) == 0; }
+// ... and for reading V token-major where the projection wrote it (PCY_DISABLE=fa_vrow: from the transposed copy)
+bool pcy_attn_fast_vrow(int ldv, int vcol0) { return !pcy_off("fa_vrow") && ((ldv | vcol0) % 8) == 0; }
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a) {
   if (a.nseq <= 0) return;
   if (a.vt_pad64 && pcy_attn_fast_eligible(a.dh, a.causal, a.keep != nullptr, a.scale, a.H, a.Hkv, a.ldq, a.qcol0, a.ldk, a.kcol0, a.ldo) &&

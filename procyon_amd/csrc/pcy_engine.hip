@@ -172,33 +172,21 @@ void linear(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, const bf16
 // ------------------------------------------------------------------ decode step (enqueue only)
 struct DecodeWs { bf16_t *x, *qkv, *ao, *act; };
 
-// PCY_ATTN_O=0 switches the fused attention + o-projection launch of the layered decode step off (default on; batch 1,
-// head_dim 128, d = 4096): 3.35 -> 3.28 ms/token.  Read on every call like PCY_DECODE_FUSED.
-bool attn_o_enabled() {
-  const char* e = getenv("PCY_ATTN_O");
-  return !e || atoi(e) != 0;
-}
-// PCY_MLP_CHAIN=0: pcy_decode_mlp runs the two GEMV launches instead of mlp_chain_kernel.  PCY_DECODE_LAYER=0: the batch-1 decode
-// step runs launch by launch (qkv GEMV, attention + o, gate/up, down) instead of one decode_layer_kernel per layer.  Both are
+// PCY_DISABLE=attn_o switches the fused attention + o-projection launch of the layered decode step off (default on; batch 1,
+// head_dim 128, d = 4096): 3.35 -> 3.28 ms/token.  PCY_DISABLE=attn_o: the two launches (pcy_switch.h).
+bool attn_o_enabled() { return !pcy_off("attn_o"); }
+// PCY_DISABLE=mlp_chain: pcy_decode_mlp runs the two GEMV launches instead of mlp_chain_kernel.  PCY_DISABLE=decode_layer: the batch-1
+// decode step runs launch by launch (qkv GEMV, attention + o, gate/up, down) instead of one decode_layer_kernel per layer.  Both are
 // read on every call: tests compare the paths in one process (bit-identical).
 unsigned long long* g_mc_trace = nullptr;
-bool mlp_chain_enabled() {
-  const char* e = getenv("PCY_MLP_CHAIN");
-  return !e || atoi(e) != 0;
-}
-bool decode_layer_enabled() {
-  const char* e = getenv("PCY_DECODE_LAYER");
-  return !e || atoi(e) != 0;
-}
-// PCY_DECODE_STEP=0: one launch per decoder layer instead of one for all layers (decode_step_kernel); bit-identical
-bool decode_step_enabled() {
-  const char* e = getenv("PCY_DECODE_STEP");
-  return !e || atoi(e) != 0;
-}
+bool mlp_chain_enabled() { return !pcy_off("mlp_chain"); }
+bool decode_layer_enabled() { return !pcy_off("decode_layer"); }
+// PCY_DISABLE=decode_step: one launch per decoder layer instead of one for all layers (decode_step_kernel); bit-identical
+bool decode_step_enabled() { return !pcy_off("decode_step"); }
 // (round 3 had everything of a batched-decode layer behind the attention as one launch with grid barriers: bit-identical, 133 us per
 // layer against 110 us launch by launch at batch 32 -- a grid barrier under a saturated memory system costs ~10 us, more than the kernel
 // boundary it replaces; removed in round 4, numbers in DESIGN.md)
-bool qkv_finish_launch() { const char* e = getenv("PCY_QKV_FINISH"); return e && atoi(e) == 1; }   // read per call: tests compare both
+bool qkv_finish_launch() { return pcy_off("attn_qkv_finish"); }   // the qkv K-split finish as its own launch instead of inside the attention's
 int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
@@ -343,7 +331,6 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
-    { static const int dbg = [] { const char* e = getenv("PCY_DBG_ATTN"); return e ? atoi(e) : 0; }(); t.dbg = dbg; }   // timing experiments: early exits
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
@@ -367,7 +354,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       if (pcy_launch_decode_layer(s, t, bp, mc, c->n_cu, c->ao_sync, c->ao_sync + 64 + (AO_MAX_LAYERS + l) * AO_FLAGS)) continue;
       try_layer = false;   // geometry not covered: the same for every layer
     }
-    int qkv_splits = 0;   // batched: the attention adds up the K-split partial sums of ITS rows (no finish launch); PCY_QKV_FINISH=1: separate launch
+    int qkv_splits = 0;   // batched: the attention adds up the K-split partial sums of ITS rows (no finish launch); PCY_DISABLE=attn_qkv_finish: separate launch
     if (batched && sk_ws && !try_ao && !qkv_finish_launch()) g.defer_finish = &qkv_splits;
     pcy_launch_gemv(s, g);
     if (qkv_splits > 1) { t.qkv_partials = sk_ws; t.qkv_splits = qkv_splits; }
@@ -660,7 +647,7 @@ int pcy_attention(pcy_ctx* c, const void* q, int ldq, int qcol0, const void* k, 
   }
   if (int r = c->reserve(align_up((size_t)Hkv * dh * vt_total * 2, 256) + align_up((size_t)(nseq + 1) * 4, 256) + 4096)) return r;
   bf16_t* vt = reinterpret_cast<bf16_t*>(c->ws);
-  // the single-pass kernel reads V token-major where it is (PCY_FA_VROW=0: from a transposed copy, as the other kernels do)
+  // the single-pass kernel reads V token-major where it is (PCY_DISABLE=fa_vrow: from a transposed copy, as the other kernels do)
   const bool vrow = fast && pcy_attn_fast_vrow(ldv, vcol0);
   if (fast && !vrow) {
     vt_cu64 = reinterpret_cast<int32_t*>(c->ws + align_up((size_t)Hkv * dh * vt_total * 2, 256));
@@ -686,7 +673,6 @@ int pcy_attn_decode(pcy_ctx* c, void* qkv, int ld, void* kcache, void* vcache, v
   t.qkv = (bf16_t*)qkv; t.ld = ld; t.kcache = (bf16_t*)kcache; t.vcache = (bf16_t*)vcache; t.o = (bf16_t*)o; t.ldo = ldo;
   t.pos_dev = pos; t.cos_t = (const bf16_t*)cos_t; t.sin_t = (const bf16_t*)sin_t; t.keep = keep; t.ld_keep = Tmax;
   t.scratch = nullptr; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = Tmax; t.scale = 1.0f / sqrtf((float)dh);
-  { const char* e = getenv("PCY_DBG_ATTN"); t.dbg = e ? atoi(e) : 0; }
   pcy_launch_attn_decode(c->stream, t);
   return check_launch("pcy_attn_decode");
 }
@@ -844,11 +830,9 @@ int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, voi
 
 static int esm_encode_enqueue(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                               const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out);
-// tokens at or below which pcy_esm_encode replays a captured launch chain (PCY_ESM_GRAPH=0: always launch by launch; read per call)
+// tokens at or below which pcy_esm_encode replays a captured launch chain (PCY_DISABLE=esm_graph: always launch by launch; read per call)
 static int esm_graph_max_tokens() {
-  const char* e = getenv("PCY_ESM_GRAPH");
-  if (e && atoi(e) == 0) return 0;
-  return (e && atoi(e) > 1) ? atoi(e) : 4200;
+  return pcy_off("esm_graph") ? 0 : 4200;
 }
 int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                    const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {
@@ -863,8 +847,8 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
                       ((uint64_t)(uint32_t)ntok << 32) | (uint32_t)nseq, ((uint64_t)(uint32_t)max_len << 32) | (uint32_t)vt_total,
                       ((uint64_t)(uint32_t)m->d << 32) | (uint32_t)m->ffn, ((uint64_t)(uint32_t)m->n_layers << 32) | (uint32_t)m->n_heads,
                       (uint64_t)mask_pads | ((uint64_t)m->rope_mode << 8), 0 /* workspace base, below */,
-                      envh("PCY_ESM_ATTN") ^ (envh("PCY_FA_VROW") << 1), envh("PCY_GEMM_MID") ^ (envh("PCY_GEMM_PERM") << 1) ^ (envh("PCY_GEMM_STG") << 2),
-                      envh("PCY_GELU_SELECT") ^ (envh("PCY_ROPE_VSKIP") << 1) ^ (envh("PCY_DEBUG_POISON_WS") << 2)};
+                      envh("PCY_ESM_ATTN") ^ (envh("PCY_DISABLE") << 1), envh("PCY_GEMM_MID") ^ (envh("PCY_GEMM_PERM") << 1),
+                      envh("PCY_DEBUG_POISON_WS")};
   // the workspace is sized (and possibly re-allocated: every slot is dropped then) before the key is final
   {
     const int d = m->d, F = m->ffn;
@@ -1027,11 +1011,10 @@ int llama_prefill_impl(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* 
   // fp8 weight path: every projection = per-token e4m3 quantisation of its bf16 input + the fp8 MFMA GEMM
   unsigned char* a8 = m->layers_fp8 ? cv.take<unsigned char>((size_t)M * (F > H * dh ? F : H * dh)) : nullptr;
   float* sa8 = m->layers_fp8 ? cv.take<float>((size_t)M) : nullptr;
-  // ln != nullptr: A is the raw hidden state, RMSNorm(A) * ln is what gets quantised (one fused pass; PCY_FP8_FUSED_NORM=0 = two launches)
+  // ln != nullptr: A is the raw hidden state, RMSNorm(A) * ln is what gets quantised (one fused pass; PCY_DISABLE=fp8_fused_norm = two launches)
   auto linear8 = [&](const bf16_t* A, int K, const void* W8, const float* sw, const bf16_t* resid, bf16_t* Cout, int ldc, int N, int epi,
                      const bf16_t* ln = nullptr) {
-    const char* fe = getenv("PCY_FP8_FUSED_NORM");
-    if (ln && !(fe && atoi(fe) == 0) && pcy_launch_rmsnorm_quant_fp8(s, A, ln, M, K, m->rms_eps, m->rms_cast, a8, sa8)) {
+    if (ln && !pcy_off("fp8_fused_norm") && pcy_launch_rmsnorm_quant_fp8(s, A, ln, M, K, m->rms_eps, m->rms_cast, a8, sa8)) {
     } else {
       if (ln) { pcy_launch_rmsnorm(s, A, ln, xn, M, K, m->rms_eps, m->rms_cast); A = xn; }
       pcy_launch_quant_rows_fp8(s, A, K, M, K, a8, sa8);
@@ -1060,8 +1043,7 @@ int llama_prefill_impl(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* 
       xn_ready = 0;
       linear(s, xn, d, (const bf16_t*)L.wqkv, nullptr, nullptr, 0, qkv, qkvw, M, qkvw, d, EPI_STORE, sk_ws, sk_bytes);
     }
-    const char* pq = getenv("PCY_PREFILL_POST_QKV");   // =0: the three launches (read per call: the test compares both)
-    if ((pq && atoi(pq) == 0) ||
+    if (pcy_off("prefill_post_qkv") ||   // (the three launches: the test compares both)
         !pcy_launch_prefill_post_qkv(s, qkv, qkvw, H, Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin,
                                      (bf16_t*)kv->k + l * layer_stride, (bf16_t*)kv->v + l * layer_stride, B, T, kv->Tmax, cu, vt_cu, vt, vt_total)) {
       pcy_launch_rope(s, qkv, qkvw, 0, H + Hkv, dh, pos, (const bf16_t*)m->rope_cos, (const bf16_t*)m->rope_sin, M, 0, 0.f);

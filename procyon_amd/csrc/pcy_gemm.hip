@@ -1156,8 +1156,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
     const bool noperm = gemm_noperm(EPI, false);
     if constexpr (EPI == EPI_GELU_ESM) {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG_PERSIST];   // (the slot keeps its name: "the ESM-GELU 256 x 256 kernel")
-      const char* gs = getenv("PCY_GELU_SELECT");   // 1 (read per call): every wave takes the select form of the table epilogue (tests)
-      b.gelu_select = gs && atoi(gs) == 1;
+      b.gelu_select = pcy_off("gelu_fast");   // every wave takes the select form of the table epilogue (tests)
     } else {
       ++g_pcy_dispatch[PCY_DISPATCH_GEMM_BIG];
     }
@@ -1262,9 +1261,8 @@ void pcy_launch_gemm(hipStream_t s, const PcyGemmArgs& a0) {
       hipLaunchKernelGGL(gemm_splitk_kernel, dim3(tiles * splits), dim3(GEMM_THREADS), 0, s, a, splits, a.K / splits);
       const int eb = (int)(((size_t)a.M * (a.N / 4) + 255) / 256);
       // residual epilogue + the RMSNorm that follows in ONE finish launch (one workgroup per row) where the caller asks for it
-      const char* fn_env = getenv("PCY_FINISH_NORM");   // read per call: tests compare both paths in one process
       if (a.epi == EPI_RESID && a.next_rms_w && a.next_xn && a.fused_next && a.bias == nullptr && a.ldc == a.N && a.ldr == a.N &&
-          !(fn_env && atoi(fn_env) == 0) &&
+          !pcy_off("finish_norm") &&
           pcy_launch_splitk_finish_norm(s, a.splitk_ws, splits, a.M, a.N, a.resid, a.C, a.next_rms_w, a.next_xn, a.rms_eps, a.rms_cast)) {
         *a.fused_next = 1;
         return;

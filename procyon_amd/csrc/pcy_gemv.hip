@@ -958,11 +958,8 @@ void launch_mfma3_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
 // Ring depth S (super-steps of 128 k kept in flight per wave = S - 1): the SwiGLU kernel streams two row tiles per wave (S = 3: 96 KB
 // of rings, one workgroup per CU).  The single-row-tile kernels (qkv, o, down, lm_head) ran S = 6 (96 KB, one workgroup per CU);
 // S = 3 halves the rings so that TWO workgroups share a CU (48 + 33 KB each) -- same bytes in flight per CU, twice the
-// workgroups to split K over.  PCY_GEMV_S1 = 3 | 6 selects (measured: see DESIGN.md round 3).
-inline int gemv_ring_depth_rt1() {
-  static const int v = [] { const char* e = getenv("PCY_GEMV_S1"); const int x = e ? atoi(e) : 6; return x == 3 ? 3 : 6; }();
-  return v;
-}
+// workgroups to split K over: measured no better, S = 6 stays.
+inline int gemv_ring_depth_rt1() { return 6; }
 template <int EPI, int BT>
 void launch_mfma3(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
@@ -980,15 +977,14 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     // K split until ~3/4 of the CUs have a workgroup (measured batch-32 decode step with the fill target at 128 / 192 / 256 / 512
     // workgroups: 4.46 / 4.21 / 4.28 / 4.56 ms); only with a plain / residual epilogue and a workspace
     int ksplit = 1;
-    static const int kfill = [] { const char* e = getenv("PCY_GEMV_KFILL"); const int x = e ? atoi(e) : 192; return x > 0 ? x : 192; }();
+    constexpr int kfill = 192;
     if ((EPI == EPI_STORE || EPI == EPI_RESID) && a.splitk_ws && a.N % 4 == 0 && (a.ldy & 3) == 0)
       while (ksplit < 8 && bx * ksplit < kfill && a.K % (ksplit * 2 * 512) == 0 &&
              (size_t)(ksplit * 2) * a.B * a.N * 4 <= a.splitk_ws_bytes) ksplit *= 2;
-    // PCY_GEMV_LDS=0: weights through registers (gemv_mfma2_kernel) instead of LDS-DMA (gemv_mfma3_kernel); read per call, same bits
-    const char* lds_env = getenv("PCY_GEMV_LDS");
-    const bool lds = !(lds_env && atoi(lds_env) == 0) && a.K % (ksplit * 256) == 0;
-    // PCY_GEMV_LDS=3: the previous schedule (gemv_mfma3_kernel: x one chunk ahead); read per call, same bits
-    const bool v4 = lds && !(lds_env && atoi(lds_env) == 3) && a.K % (ksplit * 128) == 0;
+    // PCY_DISABLE=gemv_lds: weights through registers (gemv_mfma2_kernel) instead of LDS-DMA; read per call, same bits
+    const bool lds = !pcy_off("gemv_lds") && a.K % (ksplit * 256) == 0;
+    // PCY_DISABLE=gemv_mfma4: the previous schedule (gemv_mfma3_kernel: x one chunk ahead); read per call, same bits
+    const bool v4 = lds && !pcy_off("gemv_mfma4") && a.K % (ksplit * 128) == 0;
     if (v4 && (a.B <= 16 ? launch_mfma4<EPI, 1>(s, a, bx, ksplit) : launch_mfma4<EPI, 2>(s, a, bx, ksplit))) {
     } else if (lds) {
       if (a.B <= 16) launch_mfma3<EPI, 1>(s, a, bx, ksplit);
@@ -999,9 +995,8 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     if (ksplit > 1 && EPI == EPI_STORE && a.defer_finish && !a.bias) { *a.defer_finish = ksplit; return; }
     if (ksplit > 1) {
       const int eb = (int)(((size_t)a.B * (a.N / 4) + 255) / 256);
-      const char* fn_env = getenv("PCY_FINISH_NORM");   // read per call: tests compare both paths in one process
       if (EPI == EPI_RESID && a.next_rms_w && a.next_xn && a.fused_next && a.N % 8 == 0 && a.N <= 8192 && a.ldy == a.N &&
-          !(fn_env && atoi(fn_env) == 0)) {
+          !pcy_off("finish_norm")) {
         hipLaunchKernelGGL(gemv_splitk_finish_norm_kernel, dim3(a.B), dim3(256), 0, s, a, ksplit);
         *a.fused_next = 1;
         return;

@@ -1,6 +1,7 @@
 // Internal launcher prototypes shared by the engine translation units.
 #pragma once
 #include "pcy_common.h"
+#include "pcy_switch.h"
 
 struct PcyGemvArgs {
   const bf16_t* W;      // [N,K] row-major (nn.Linear layout); EPI_SWIGLU: [2N,K], 16-row gate/up interleave
@@ -79,7 +80,7 @@ struct PcyGemmArgs {
   // optional (split-K path with the residual epilogue only): the finish kernel also writes next_xn = RMSNorm(C) * next_rms_w and
   // sets *fused_next = 1; otherwise *fused_next stays 0 and the caller launches the norm itself.  Same bits as the two launches.
   const bf16_t* next_rms_w; bf16_t* next_xn; int* fused_next; float rms_eps; int rms_cast;
-  int gelu_select;      // set by the launcher (PCY_GELU_SELECT=1): the ESM-GELU kernel skips the fast table epilogue
+  int gelu_select;      // set by the launcher (PCY_DISABLE=gelu_fast): the ESM-GELU kernel skips the fast table epilogue
   int mid_cfg;          // > 0: this configuration of gemm_kernel_mid (pcy_gemm_mid.h); 0: the launcher's own choice
 };
 struct pcy_ctx;
@@ -138,7 +139,7 @@ struct PcyAttnArgs {
   // transposed copy is made at all (vt_pad64 still says "the caller may take the single-pass kernel")
   const bf16_t* v; int ldv; int vcol0;
 };
-// PCY_FA_VROW=0 (read per call): the single-pass attention reads a transposed copy of V (the first form) instead of V itself
+// PCY_DISABLE=fa_vrow (read per call): the single-pass attention reads a transposed copy of V (the first form) instead of V itself
 bool pcy_attn_fast_vrow(int ldv, int vcol0);
 void pcy_launch_attn(hipStream_t s, const PcyAttnArgs& a);
 // the single-pass kernel (pcy_attn_fast.h) covers this call unless PCY_ESM_ATTN=exact asks for the reference's rounding points

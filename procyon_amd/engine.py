@@ -732,7 +732,7 @@ class EsmEngine:
                               1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
                               self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
 
-    GRAPH_MAX_TOKENS = 4200     # = the engine's own bound (pcy_esm_encode, PCY_ESM_GRAPH)
+    GRAPH_MAX_TOKENS = 4200     # = the engine's own bound (pcy_esm_encode; PCY_DISABLE=esm_graph switches the replay off)
 
     def preferred_batch(self, tokens_per_protein, lo=16, hi=40, n_cu=256):
         """Proteins per engine call for retrieval-style bulk encoding ("batch size chosen by the engine", BASELINE configs[2]).

@@ -49,6 +49,16 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         terminalreporter.write_line(f"parity report not written: {e}")
 
 
+def pcy_disable(monkeypatch, *names):
+    """PCY_DISABLE=<names> for the rest of the test (procyon_amd/csrc/pcy_switch.h: each name switches a fused path OFF in favour of its
+    launch-per-stage twin; read per call); no names = everything at its default."""
+    names = [n for n in names if n]
+    if names:
+        monkeypatch.setenv("PCY_DISABLE", ",".join(names))
+    else:
+        monkeypatch.delenv("PCY_DISABLE", raising=False)
+
+
 def load_golden(name):
     """npz -> dict of torch tensors; uint16 arrays are raw bf16 bit patterns."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_bf16_close, rel_err
+from conftest import assert_bf16_close, pcy_disable, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -158,7 +158,7 @@ def test_pair_scoring_fp8_agrees_with_bf16():
 
 
 def test_fp8_prefill_fused_norm_quant_bit_identical(monkeypatch):
-    """RMSNorm + per-token quantisation in one pass (default) vs the two launches (PCY_FP8_FUSED_NORM=0): same statistic order,
+    """RMSNorm + per-token quantisation in one pass (default) vs the two launches (PCY_DISABLE=fp8_fused_norm): same statistic order,
     same rounding points, same scale rule -> bit-identical logits, hidden states and K/V at full width (d = 4096, one group of
     2048 elements per thread pass) and at the small geometry."""
     for kw, B, T in ((dict(vocab=512, d=4096, n_layers=1, n_heads=32, n_kv_heads=8, ffn=14336), 2, 40),
@@ -168,7 +168,7 @@ def test_fp8_prefill_fused_norm_quant_bit_identical(monkeypatch):
         emb = (torch.randn(B, T, kw["d"]) * 0.02).to(BF).cuda()
         outs = []
         for fused in ("1", "0"):
-            monkeypatch.setenv("PCY_FP8_FUSED_NORM", fused)
+            pcy_disable(monkeypatch, "" if fused == "1" else "fp8_fused_norm")
             cache = eng.new_cache(B, T)
             logits, hidden = eng.prefill(emb, None, cache, "last", want_hidden=True)
             outs.append((logits.cpu(), hidden.cpu(), cache.k.cpu().clone(), cache.v.cpu().clone()))

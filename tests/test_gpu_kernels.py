@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_bf16_close, rel_err
+from conftest import assert_bf16_close, pcy_disable, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -118,9 +118,9 @@ def test_decode_mlp_one_launch_vs_oracle(ctx, monkeypatch, d, ffn):
         xn = rms_norm(x, w, 1e-5, "hf5")
         act = F.silu(F.linear(xn, g)) * F.linear(xn, u)
         ref = x + F.linear(act, dn)
-        monkeypatch.setenv("PCY_MLP_CHAIN", "1")
+        pcy_disable(monkeypatch)
         out = ctx.decode_mlp(x.cuda(), wc, wgu, wd).cpu()
-        monkeypatch.setenv("PCY_MLP_CHAIN", "0")
+        pcy_disable(monkeypatch, "mlp_chain")
         two = ctx.decode_mlp(x.cuda(), wc, wgu, wd).cpu()
         ctx.sync()
         assert torch.equal(out, two), i
@@ -314,10 +314,10 @@ def test_gemv_mfma_swiglu_and_decode_layer(ctx, B):
 
 @pytest.mark.parametrize("B", [5, 16, 20, 32, 45])
 def test_gemv_mfma_lds_dma_variant_bit_identical(ctx, monkeypatch, B):
-    """gemv_mfma4_kernel (default) / gemv_mfma3_kernel (PCY_GEMV_LDS=3): the batched decode GEMV with the weights through per-wave
+    """gemv_mfma4_kernel (default) / gemv_mfma3_kernel (PCY_DISABLE=gemv_mfma4): the batched decode GEMV with the weights through per-wave
     LDS-DMA rings (4 rows x 256 contiguous bytes per copy instruction) instead of register loads (16 rows x 64 bytes); the default
     stages x like the weights, in a ring of the same depth.  Same MFMA operands in the same order: all bit-identical to
-    gemv_mfma2_kernel (PCY_GEMV_LDS=0) for every epilogue, incl. ragged N and the SwiGLU row pairing."""
+    gemv_mfma2_kernel (PCY_DISABLE=gemv_lds) for every epilogue, incl. ragged N and the SwiGLU row pairing."""
     from procyon_amd.engine import interleave_gate_up
     x4, x14 = rnd(B, 4096, seed=1), rnd(B, 14336, seed=2)
     cases = [(rnd(4096, 4096, seed=3, std=0.03), x4, 1), (rnd(6144, 4096, seed=4, std=0.03), x4, 0), (rnd(1000, 4096, seed=5, std=0.03), x4, 2),
@@ -327,8 +327,8 @@ def test_gemv_mfma_lds_dma_variant_bit_identical(ctx, monkeypatch, B):
         r = rnd(B, N, seed=9).cuda() if epi == 1 else None
         b = rnd(N, seed=10, std=0.1).cuda() if epi in (1, 2) else None
         outs = []
-        for lds in ("1", "3", "0"):
-            monkeypatch.setenv("PCY_GEMV_LDS", lds)
+        for off in ("", "gemv_mfma4", "gemv_lds"):
+            pcy_disable(monkeypatch, off)
             outs.append(ctx.gemv(W.cuda(), x.cuda(), b, r, epi).cpu())
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (tuple(W.shape), epi)
 

@@ -12,7 +12,7 @@ oracle's own top-2 margin lies inside the measured logits error (reported as `ne
 import pytest
 import torch
 
-from conftest import alt_accumulation, assert_no_further_from_truth, assert_bf16_close, parity_bar, rel_err
+from conftest import alt_accumulation, assert_no_further_from_truth, assert_bf16_close, parity_bar, pcy_disable, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -224,9 +224,9 @@ def test_kv_reorder():
 
 @pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (600, 10, 2), (1100, 6, 2)])   # 600 / 1100: key split + score exchange on
 def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
-    """PCY_ATTN_O (default on): decode attention and o projection in one launch -- Wo rows wait in registers while the
+    """attn_o_kernel (the step below the per-layer launch): decode attention and o projection in one launch -- Wo rows wait in registers while the
     attention workgroups run, hand-over by per-workgroup flags.  Same per-lane accumulation order, reduction tree and
-    rounding points as the two-launch path, so logits, tokens and the appended K/V must be BIT-identical to PCY_ATTN_O=0,
+    rounding points as the two-launch path, so logits, tokens and the appended K/V must be BIT-identical to PCY_DISABLE=attn_o,
     eager and under hipGraph replay, over enough steps that a stale flag or a missed hand-over would show; no watchdog."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
@@ -238,7 +238,7 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
     monkeypatch.setenv("PCY_AO_XMIN", "384")   # key split + score exchange between the slice workgroups from 384 keys on (default 1024)
 
     def run(ao, use_graph):
-        monkeypatch.setenv("PCY_ATTN_O", "1" if ao else "0")
+        pcy_disable(monkeypatch, "decode_layer", "" if ao else "attn_o")     # (the per-layer / all-layer launches have their own test below)
         cache = eng.new_cache(1, T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
@@ -260,8 +260,8 @@ def test_decode_attn_o_fused_launch_bit_identical(monkeypatch, T, N, n_layers):
 
 @pytest.mark.parametrize("T,N,n_layers,cap", [(300, 24, 3, 0), (40, 12, 2, 0), (1100, 6, 2, 0), (765, 8, 2, 4096)])
 def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
-    """The batch-1 decode step runs ALL decoder layers in one launch (decode_step_kernel; PCY_DECODE_STEP=0: one launch per layer,
-    decode_layer_kernel; PCY_DECODE_LAYER=0: launch by launch), the residual stream crossing the layer boundaries as tagged words: qkv
+    """The batch-1 decode step runs ALL decoder layers in one launch (decode_step_kernel; PCY_DISABLE=decode_step: one launch per layer,
+    decode_layer_kernel; PCY_DISABLE=decode_layer: launch by launch), the residual stream crossing the layer boundaries as tagged words: qkv
     projection, attention (cache rows requested before the new token's q / k / v arrive), o projection, gate/up + SwiGLU and down,
     the vectors between the stages as {tag : bf16} words inside the launch.  Same per-row arithmetic and the same order of the
     RMSNorm statistics as the stand-alone launches: logits, tokens, log-probabilities and the appended K/V must be BIT-identical
@@ -277,9 +277,7 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
     def run(layer, attn_o, use_graph, step=False):
-        monkeypatch.setenv("PCY_DECODE_LAYER", "1" if layer else "0")
-        monkeypatch.setenv("PCY_DECODE_STEP", "1" if step else "0")
-        monkeypatch.setenv("PCY_ATTN_O", "1" if attn_o else "0")
+        pcy_disable(monkeypatch, "" if layer else "decode_layer", "" if step else "decode_step", "" if attn_o else "attn_o")
         cache = eng.new_cache(1, cap or T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
@@ -336,8 +334,8 @@ def test_decode_layers_only_entry_runs_the_layer_launches():
 
 def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
     """Single-prompt prefill (M <= 1024: the o and down projections run K-split): the finish launch of the residual epilogue also
-    writes the RMSNorm of its result (PCY_FINISH_NORM=0: residual finish + rmsnorm as two launches), and rope, K/V cache scatter
-    and V transpose run as one launch (PCY_PREFILL_POST_QKV=0: three).  Same element assignment, accumulation order and block
+    writes the RMSNorm of its result (PCY_DISABLE=finish_norm: residual finish + rmsnorm as two launches), and rope, K/V cache scatter
+    and V transpose run as one launch (PCY_DISABLE=prefill_post_qkv: three).  Same element assignment, accumulation order and block
     reduction: last-row logits, final hidden state and the K/V cache must be bit-identical."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, LlamaConfig, LlamaEngine
@@ -349,8 +347,7 @@ def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
         emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
         res = []
         for fused in ("1", "0"):
-            monkeypatch.setenv("PCY_FINISH_NORM", fused)
-            monkeypatch.setenv("PCY_PREFILL_POST_QKV", fused)   # rope + K/V scatter + V transpose as one launch / three
+            pcy_disable(monkeypatch, *(() if fused == "1" else ("finish_norm", "prefill_post_qkv")))   # the latter: rope + K/V scatter + V transpose as one launch / three
             cache = eng.new_cache(1, T + 4)
             logits, hidden = eng.prefill(emb, None, cache, "last", want_hidden=True)
             Context.get().sync()
@@ -361,8 +358,8 @@ def test_prefill_splitk_finish_norm_fusion_bit_identical(monkeypatch):
 
 def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
     """Batched decode (B > 4, skinny-MFMA GEMVs with K split): the finish kernel of the o / down projections also writes the
-    RMSNorm that follows (PCY_FINISH_NORM, default on).  Same element assignment and reduction order as the two separate
-    launches, so logits, tokens and K/V must be bit-identical to PCY_FINISH_NORM=0, eager and under graph replay."""
+    RMSNorm that follows (default; PCY_DISABLE=finish_norm: two launches).  Same element assignment and reduction order as the two separate
+    launches, so logits, tokens and K/V must be bit-identical to the two-launch form, eager and under graph replay."""
     from procyon_amd import synth
     from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
     kw = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
@@ -373,7 +370,7 @@ def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
         emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
 
         def run(fused, use_graph):
-            monkeypatch.setenv("PCY_FINISH_NORM", "1" if fused else "0")
+            pcy_disable(monkeypatch, "" if fused else "finish_norm")
             cache = eng.new_cache(B, T + N + 2)
             st = GenState(B, kw["vocab"], N + 2, "cuda")
             logits, _ = eng.prefill(emb, None, cache, "last")
@@ -394,7 +391,7 @@ def test_batched_decode_finish_norm_fusion_bit_identical(monkeypatch):
 
 def test_batched_decode_qkv_finish_in_attention_bit_identical(monkeypatch):
     """Batched decode: the K-split partial sums of the qkv projection are added up by the attention workgroup that needs them
-    (attn_dec_splitk_kernel, default) instead of by a finish launch (PCY_QKV_FINISH=1).  Same split order, same rounding: logits,
+    (attn_dec_splitk_kernel, default) instead of by a finish launch (PCY_DISABLE=attn_qkv_finish).  Same split order, same rounding: logits,
     tokens and the appended K/V rows are bit-identical, eager and under graph replay; batches of 5..32 rows incl. a ragged keep mask."""
     from procyon_amd import synth
     from procyon_amd.engine import GenState, LlamaConfig, LlamaEngine
@@ -406,7 +403,7 @@ def test_batched_decode_qkv_finish_in_attention_bit_identical(monkeypatch):
         emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
 
         def run(separate, use_graph):
-            monkeypatch.setenv("PCY_QKV_FINISH", "1" if separate else "0")
+            pcy_disable(monkeypatch, "attn_qkv_finish" if separate else "")
             cache = eng.new_cache(B, T + N + 2)
             st = GenState(B, kw["vocab"], N + 2, "cuda")
             logits, _ = eng.prefill(emb, None, cache, "last")

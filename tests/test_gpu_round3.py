@@ -11,7 +11,7 @@ import socket
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import pcy_disable, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -598,7 +598,7 @@ def test_esm_layer_row_order_and_v_path_bit_identical(monkeypatch):
     for mask in ("0", "7", "31"):
         for vrow in ("0", "1"):
             monkeypatch.setenv("PCY_GEMM_PERM", mask)
-            monkeypatch.setenv("PCY_FA_VROW", vrow)
+            pcy_disable(monkeypatch, "" if vrow == "1" else "fa_vrow")
             outs[(mask, vrow)] = eng.hidden_states(toks).cpu()
     keep = toks != 1
     ref = outs[("0", "0")]
@@ -617,7 +617,7 @@ def test_attention_single_pass_v_token_major_bit_identical(ctx, monkeypatch, len
     monkeypatch.setenv("PCY_ESM_ATTN", "fast")
     outs = []
     for vrow in ("0", "1"):
-        monkeypatch.setenv("PCY_FA_VROW", vrow)
+        pcy_disable(monkeypatch, "" if vrow == "1" else "fa_vrow")
         outs.append(ctx.attention(q, k, v, lens, H, H, dh, False, 1.0).cpu())
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
@@ -633,7 +633,7 @@ def test_gemm_esm_gelu_fast_table_epilogue_every_in_range_value(ctx, monkeypatch
     """The persistent 256 x 256 ESM-GELU kernel looks a wave tile up WITHOUT per-element range tests when every value of the tile lies
     inside the table (2^-25 <= |x| < 2^7; pattern << 1 is the gather address of a sparse table image) and redoes the tile with the
     select form otherwise (test_gemm_esm_gelu_epilogue_every_bf16_value feeds every pattern: always the select form).  Here every one of
-    the 2 x 4096 in-range patterns, only those, through the kernel -- all waves take the fast form (PCY_GELU_SELECT=1: none does) --
+    the 2 x 4096 in-range patterns, only those, through the kernel -- all waves take the fast form (PCY_DISABLE=gelu_fast: none does) --
     against the reference's op-by-op bf16 chain, bit for bit; a second matrix with ONE out-of-range value per 64 x 128 wave tile."""
     import math
     from procyon_amd import _lib as L
@@ -644,7 +644,7 @@ def test_gemm_esm_gelu_fast_table_epilogue_every_in_range_value(ctx, monkeypatch
     M = 2048
     A = torch.zeros(M, 64, dtype=BF)
     A[torch.arange(M), torch.arange(M) % 64] = 1.0
-    monkeypatch.setenv("PCY_GELU_SELECT", select)
+    pcy_disable(monkeypatch, "gelu_fast" if select == "1" else "")
     n0 = _dispatch(L.DISPATCH_GEMM_BIG_PERSIST)
     out = ctx.gemm(A.cuda(), W.cuda(), torch.zeros(2048, dtype=BF).cuda(), None, 3).cpu()
     assert _dispatch(L.DISPATCH_GEMM_BIG_PERSIST) == n0 + 1

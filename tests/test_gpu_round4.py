@@ -6,7 +6,7 @@
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import pcy_disable, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -107,7 +107,7 @@ def test_every_mid_m_configuration_is_bit_identical(ctx, monkeypatch, cfg):
 def test_esm_encode_replays_a_captured_launch_chain_with_the_same_bits(ctx, monkeypatch):
     """`pcy_esm_encode` of a short input (one protein; /root/reference/procyon/model/esm.py:517-538 at batch 1) runs launch by launch the
     first time a shape is seen, captures its launch chain the second time and replays it from then on (asserted through the dispatch
-    counter).  Same kernels, same arguments: the bits must equal the launch-by-launch run (PCY_ESM_GRAPH=0), also when two shapes
+    counter).  Same kernels, same arguments: the bits must equal the launch-by-launch run (PCY_DISABLE=esm_graph), also when two shapes
     alternate and when the tokens change under an unchanged shape."""
     from procyon_amd import _lib as L
     from procyon_amd import synth
@@ -116,9 +116,9 @@ def test_esm_encode_replays_a_captured_launch_chain_with_the_same_bits(ctx, monk
     eng = EsmEngine(synth.esm_state_dict(**kw), EsmConfig(**kw))
     cnt = lambda: int(ctx.lib.pcy_debug_dispatch_count(L.DISPATCH_ESM_GRAPH))
     a1, a2, b1 = synth.protein_tokens([300], seed=1), synth.protein_tokens([300], seed=2), synth.protein_tokens([77, 130], seed=3)
-    monkeypatch.setenv("PCY_ESM_GRAPH", "0")
+    pcy_disable(monkeypatch, "esm_graph")
     ref = {k: eng.forward(t).clone() for k, t in (("a1", a1), ("a2", a2), ("b1", b1))}
-    monkeypatch.delenv("PCY_ESM_GRAPH")
+    pcy_disable(monkeypatch)
     n0 = cnt()
     outs = [(k, eng.forward(t).clone()) for k, t in (("a1", a1), ("a1", a1), ("b1", b1), ("a2", a2), ("b1", b1), ("a1", a1), ("b1", b1))]
     assert cnt() - n0 >= 4, cnt() - n0            # a1 x2 (2nd, 4th, 6th of that shape: >= 3 replays incl. the capturing call) + b1 (2nd, 3rd)

@@ -1,4 +1,4 @@
-"""Decode-only tokens/s for Llama-3-8B geometry, used for A/B of decode-path changes (PCY_DECODE_LAYER=0/1, PCY_ATTN_O=0/1, GRAPH=0/1; PCY_MC_TRACE=1 GRAPH=0: in-kernel stamps):
+"""Decode-only tokens/s for Llama-3-8B geometry, used for A/B of decode-path changes (PCY_DISABLE=decode_layer/1, PCY_DISABLE=attn_o/1, GRAPH=0/1; PCY_MC_TRACE=1 GRAPH=0: in-kernel stamps):
 GPU time per token (HIP events) and host time to enqueue a step."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

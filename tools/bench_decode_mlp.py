@@ -1,6 +1,6 @@
 """The decode MLP chain launch (pcy_decode_mlp: gate/up + SwiGLU + down + residual of one token, Llama-3-8B shapes), rotating
 over distinct weight copies so neither the 256 MiB Infinity Cache nor L2 can serve them.  Used for the rocprofv3 --pmc passes
-behind profiles/r02_pmc_mlp_chain.json and for A/B timing (PCY_MLP_CHAIN=0: the two GEMV launches)."""
+behind profiles/r02_pmc_mlp_chain.json and for A/B timing (PCY_DISABLE=mlp_chain: the two GEMV launches)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,4 +24,4 @@ for _ in range(reps):
         ctx.decode_mlp(x, ln, wgu[i], wdn[i])
 ms = ctx.timer_stop() / (reps * ncopy)
 nbytes = 3 * F * d * 2
-print(f"decode mlp (chain={os.environ.get('PCY_MLP_CHAIN', '1')}) {nbytes/1e6:8.1f} MB  {ms*1e3:7.2f} us per call  {nbytes/1e9/(ms/1e3):7.1f} GB/s", flush=True)
+print(f"decode mlp (chain={'mlp_chain' not in os.environ.get('PCY_DISABLE', '')}) {nbytes/1e6:8.1f} MB  {ms*1e3:7.2f} us per call  {nbytes/1e9/(ms/1e3):7.1f} GB/s", flush=True)

@@ -1,5 +1,5 @@
 """The four ESM2-650M GEMM shapes at batch 32 (M = 32832): shipped epilogue vs plain store (what the epilogue costs),
-and the 128x128 kernel (PCY_GEMM_BIG_M=999999 in a second run) vs the 256x256 one."""
+and the mid-M kernel (PCY_GEMM_MID) vs the 256x256 one."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -11,6 +11,5 @@ model.generate(make(), max_len=8, method="greedy"); torch.cuda.synchronize()
 for n in (8, 512):
     t0 = time.perf_counter(); model.generate(make(), max_len=n, method="greedy"); torch.cuda.synchronize()
     print(f"generate max_len={n}: {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
-os.environ["PCY_SYNC_PHASES"] = "1"
 pr = cProfile.Profile(); pr.enable(); model.generate(make(), max_len=8, method="greedy"); torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
