@@ -770,7 +770,7 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
 template <int DH, int G>
 __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_attn,
                                                   unsigned xepoch, int vthr_qkv, size_t stage_off, int vthr_gu, char* smem,
-                                                  const uint32_t* x_in_lines, uint32_t* x_out_lines, unsigned long long* tr_base) {
+                                                  const uint32_t* x_in_lines, uint32_t* x_out_lines, unsigned long long* tr_base, int pf_off) {
   const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
   unsigned long long* tr = tr_base ? tr_base + (size_t)blockIdx.x * 16 : nullptr;
@@ -893,6 +893,11 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
   }
   // gate/up rows of the MLP while the attention runs: 16 KB per wave beside the Wo rows (both batches: 256 VGPRs and spills)
   if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false);
+  // ... and the THIRD batch (k-iterations 4, 5) into LDS, which is idle here (pf_off: behind everything this workgroup keeps in LDS; 16 KB
+  // per wave): the registers are full, and without it the weight stream stood still for the last ~5 us of the attention (in-kernel stamps:
+  // 73 MB requested at 14 us have landed by 26, the MLP starts at 33).  The second batch is requested as before once the Wo registers are free.
+  if (pf_off > 0 && wave < 7 && (int)blockIdx.x * 7 + wave < (mc.F + 3) / 4)
+    mc_lds_prefetch(mc, lane, (int)blockIdx.x * 7 + wave, MC_LDS_IT0, smem + pf_off + wave * 16384);
   // the attention output: one wave watches a 1 KB sample (192 workgroups asking for all 16 KB in a loop would load the fabric
   // while the attention workgroups are inside their latency chain), then every wave takes its share
   if (wave == 0) {
@@ -952,7 +957,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
-    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines);
+    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines, pf_off);
     AB_T(5)
   }
 #undef AB_T
@@ -960,9 +965,9 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
 
 template <int DH, int G>
 __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, int n_attn,
-                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
+                                                           const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu, int pf_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  decode_layer_body<DH, G>(a, p, mc, n_attn, *step_epoch, vthr_qkv, stage_off, vthr_gu, smem, nullptr, nullptr, p.trace);
+  decode_layer_body<DH, G>(a, p, mc, n_attn, *step_epoch, vthr_qkv, stage_off, vthr_gu, smem, nullptr, nullptr, p.trace, pf_off);
 }
 
 // All decoder layers of a batch-1 decode step in ONE launch: workgroup b runs layer after layer; the residual stream crosses the
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(512) void decode_layer_kernel(PcyDecAttnArgs a, Pcy
 // workgroups' finishing times (6-8 us per layer) is absorbed by the next layer's prefetch instead of waited out.
 template <int DH, int G>
 __global__ __launch_bounds__(512) void decode_step_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, PcyDecodeStepArgs st, int n_attn,
-                                                          const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
+                                                          const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu, int pf_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned xepoch = *step_epoch;
   for (int l = 0; l < st.n_layers; ++l) {
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(512) void decode_step_kernel(PcyDecAttnArgs a, PcyA
     uint32_t* xout = l + 1 < st.n_layers ? st.x_lines + (size_t)l * st.x_lines_stride : nullptr;
     if (l > 0) __syncthreads();   // the previous layer's LDS is dead
     decode_layer_body<DH, G>(al, p, mc, n_attn, xepoch, vthr_qkv, stage_off, vthr_gu, smem, xin, xout,
-                             p.trace ? p.trace + (size_t)l * 256 * 16 : nullptr);
+                             p.trace ? p.trace + (size_t)l * 256 * 16 : nullptr, pf_off);
   }
 }
 
@@ -1009,6 +1014,11 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
   const size_t smem_mlp = (size_t)(2 * mc.d + mc.F) * 2 + 128;
   size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
   smem = smem > smem_mlp ? smem : smem_mlp;
+  // 7 x 16 KB behind the projection workgroups' own LDS for the gate/up batch they prefetch while the attention runs (PCY_DISABLE=lds_prefetch:
+  // without; same bits); the attention workgroups do not touch it
+  size_t pf_off = ((smem_o > smem_mlp ? smem_o : smem_mlp) + 1023) & ~(size_t)1023;
+  if (pcy_off("lds_prefetch") || pf_off + 7 * 16384 > 160 * 1024) pf_off = 0;
+  if (pf_off && pf_off + 7 * 16384 > smem) smem = pf_off + 7 * 16384;
   static size_t configured[2] = {0, 0};
   if (smem > 65536 && smem > configured[st ? 1 : 0]) {
     if (st) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_step_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1026,10 +1036,10 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
   if (!resident[ri]) return false;
   if (st)
     hipLaunchKernelGGL((decode_step_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, *st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
-                       stage_off, pcy_gemv_rms_threads(mc.F));
+                       stage_off, pcy_gemv_rms_threads(mc.F), (int)pf_off);
   else
     hipLaunchKernelGGL((decode_layer_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
-                       stage_off, pcy_gemv_rms_threads(mc.F));
+                       stage_off, pcy_gemv_rms_threads(mc.F), (int)pf_off);
   return true;
 }
 

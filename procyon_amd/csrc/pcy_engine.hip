@@ -187,7 +187,7 @@ bool decode_step_enabled() { return !pcy_off("decode_step"); }
 // layer against 110 us launch by launch at batch 32 -- a grid barrier under a saturated memory system costs ~10 us, more than the kernel
 // boundary it replaces; removed in round 4, numbers in DESIGN.md)
 bool qkv_finish_launch() { return pcy_off("attn_qkv_finish"); }   // the qkv K-split finish as its own launch instead of inside the attention's
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0); }
+int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) | (pcy_off("lds_prefetch") ? 256 : 0); }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]

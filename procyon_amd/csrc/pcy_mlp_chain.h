@@ -8,13 +8,17 @@
 namespace {
 
 constexpr int MC_NT = 512, MC_WV = 8, MC_UNB_D = 7;
+constexpr int MC_LDS_IT0 = 4;      // the gate/up batch (k-iterations 4, 5 of a wave's first unit) the decode layer's projection workgroups keep in LDS
 
 // One wave streams its units (RW weight rows each, row i of unit u at W + row_off(u, i)) against xs, UNB k-iterations of 512
 // elements per batch, two batches in flight (wa / wb).  primed: the first two batches of (u0, it 0) are already in wa / wb.
 // before_batch(it0) runs ahead of the arithmetic of every batch (the down stage waits there for the second half of its input).
-template <int RW, int UNB, typename RowOff, typename Finish, typename Before>
+// LDS_IT0 >= 0 and lds_batch != nullptr: the batch (u0, LDS_IT0) waits in LDS (this wave's own 16 KB, image of mc_lds_prefetch: register j of lane l at
+// j * 1024 + l * 16) and is taken from there instead of from memory.
+template <int RW, int UNB, int LDS_IT0 = -1, typename RowOff, typename Finish, typename Before>
 __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, const bf16_t* xs, int lane, int u0, int ustride, int uend,
-                                          uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch) {
+                                          uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch,
+                                          const char* lds_batch = nullptr) {
   static_assert(RW * UNB <= 16, "batch size");
   const int nit = K >> 9;
   auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
@@ -47,6 +51,28 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
   if (!primed) {
     if (have) issue(u, 0, wa);
     if (have1) issue(u1, it1, wb);
+  }
+  if constexpr (LDS_IT0 >= 0) {
+    // The first unit's third batch waits in LDS: a straight-line prologue (nothing of this in the loop below: a test there cost 5 spilled
+    // VGPRs, and a spill reload is a VMEM operation whose wait drains every weight load in flight -- decode step 2.57 -> 3.15 ms).
+    //   b0 (wa) -> request b3 into wa | b1 (wb) | b2: LDS -> wb, compute -> request the next unit's b0 into wb | loop from b3 (wa), next (wb)
+    static_assert(LDS_IT0 < 0 || (UNB == 2 && LDS_IT0 == 4), "prologue written for 4 batches of 2 k-iterations per unit");
+    if (lds_batch != nullptr && nit == 8 && have && u0 + ustride < uend) {
+      before_batch(0);
+      compute(0, wa);
+      issue(u0, 6, wa);
+      before_batch(2);
+      compute(2, wb);
+      // LDS-DMA copies are not covered by the compiler's wait insertion.  They are older than b3's 16 loads (and b1's before them); loads
+      // return in order, so "at most 16 outstanding" means they have landed -- and b3 stays in flight.
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wb[j] = *reinterpret_cast<const uint4*>(lds_batch + j * 1024 + lane * 16);
+      before_batch(4);
+      compute(4, wb);
+      issue(u0 + ustride, 0, wb);
+      u = u0; it0 = 6; u1 = u0 + ustride; it1 = 0; have = true; have1 = true;
+    }
   }
 #define PCY_MC_STEP(CUR)                                   \
   {                                                        \
@@ -104,6 +130,19 @@ struct McRowG {
     return (size_t)((fc >> 4) * 32 + (fc & 15) + (i >= 4 ? 16 : 0)) * d;
   }
 };
+// LDS-DMA of the batch (k-iterations it0, it0 + 1) of this wave's first gate/up unit into the wave's own 16 KB at dst (register j of lane l
+// at j * 1024 + l * 16): what mc_stream<.., LDS_IT0 = it0>(lds_batch = dst) expects.  Issued by the projection workgroups of the decode layer
+// while the attention runs: their registers are full (Wo rows + the first batch), their LDS is idle.
+__device__ __forceinline__ void mc_lds_prefetch(const PcyMlpChainArgs& a, int lane, int gidx, int it0, char* dst) {
+  typedef __attribute__((address_space(3))) void* mc_lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* mc_gptr_t;
+  const McRowG row_g{a.F, a.d};
+#pragma unroll
+  for (int un = 0; un < 2; ++un)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((mc_gptr_t)(a.wgu + row_g(gidx, i) + ((it0 + un) * 64 + lane) * 8), (mc_lds_ptr_t)(dst + (un * 8 + i) * 1024), 16, 0, 2);
+}
 // first batch (k-iterations 0, 1) of this wave's first gate/up unit -> wa, and with `both` the second (2, 3) -> wb: what
 // mc_mlp_body(primed = 1 / 3) expects to find
 __device__ __forceinline__ void mc_prime_gate_up(const PcyMlpChainArgs& a, int lane, int gidx, uint4 (&wa)[16], uint4 (&wb)[16], bool both) {
@@ -130,9 +169,12 @@ __device__ __forceinline__ void mc_prime_gate_up(const PcyMlpChainArgs& a, int l
 // (mc_prime_gate_up).
 // x_out_lines != nullptr: the result is handed over as tagged words, workgroup wg's 16 rows in the first half of line wg
 // (mc_fetch_vector_lines), instead of being stored to a.x_out.
+// pf_off > 0: the batch of k-iterations MC_LDS_IT0.. of each wave's first gate/up unit waits in LDS at smem + pf_off + wave * 16 KB
+// (mc_lds_prefetch, issued by the caller), see mc_stream.
 template <bool XLDS>
 __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem, int vthr_gu, uint32_t tag, int G, int wg, int primed,
-                                            uint4 (&wa)[16], uint4 (&wb)[16], unsigned long long* tr, uint32_t* x_out_lines = nullptr) {
+                                            uint4 (&wa)[16], uint4 (&wb)[16], unsigned long long* tr, uint32_t* x_out_lines = nullptr,
+                                            int pf_off = 0) {
   const int d = a.d, F = a.F;
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* xa = xs + d;
@@ -157,7 +199,8 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
     }
   });
   if (wave < 7) {
-    mc_stream<8, 2>(a.wgu, d, xs, lane, gidx, NWG7, units_g, wa, wb, true, row_g, [&](int u, const float (&acc)[8]) __attribute__((always_inline)) {
+    const char* lds_batch = (pf_off > 0 && gidx < units_g) ? smem + pf_off + wave * 16384 : nullptr;
+    mc_stream<8, 2, MC_LDS_IT0>(a.wgu, d, xs, lane, gidx, NWG7, units_g, wa, wb, true, row_g, [&](int u, const float (&acc)[8]) __attribute__((always_inline)) {
       if (lane == 0) {
         uint32_t o[4];
 #pragma unroll
@@ -168,7 +211,7 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
         st8_agent(a.act_tag + u * 4, o[0], o[1]);
         st8_agent(a.act_tag + u * 4 + 2, o[2], o[3]);
       }
-    }, [](int) __attribute__((always_inline)) {});
+    }, [](int) __attribute__((always_inline)) {}, lds_batch);
     MC_T(1)
     // ---- stage 2 begins for this wave: first half of act, then the first two batches of its down rows ----
     mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);

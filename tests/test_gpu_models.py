@@ -268,7 +268,8 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
     to the launch-per-stage step (with and without the fused attention + o launch), eager and under hipGraph replay, over enough
     steps that a stale tag or a vector read too early would show -- T = 1100 also crosses into the key-split exchange of the
     attention workgroups, T = 765..773 walks over its threshold (768 keys) inside one run with a 4096-slot cache (the attention's
-    LDS image then exceeds 64 KB); the watchdog word must stay clear (Context.sync raises on it)."""
+    LDS image then exceeds 64 KB); the watchdog word must stay clear (Context.sync raises on it).  With and without the gate/up batch
+    that the projection workgroups park in LDS during the attention (PCY_DISABLE=lds_prefetch)."""
     from procyon_amd import synth
     from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
     kw = dict(vocab=4096, d=4096, n_layers=n_layers, n_heads=32, n_kv_heads=8, ffn=14336)
@@ -276,8 +277,9 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
     torch.manual_seed(4)
     emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
 
-    def run(layer, attn_o, use_graph, step=False):
-        pcy_disable(monkeypatch, "" if layer else "decode_layer", "" if step else "decode_step", "" if attn_o else "attn_o")
+    def run(layer, attn_o, use_graph, step=False, lds=True):
+        pcy_disable(monkeypatch, "" if layer else "decode_layer", "" if step else "decode_step", "" if attn_o else "attn_o",
+                    "" if lds else "lds_prefetch")
         cache = eng.new_cache(1, cap or T + N + 2)
         st = GenState(1, kw["vocab"], N + 2, "cuda")
         logits, _ = eng.prefill(emb, None, cache, "last")
@@ -294,11 +296,13 @@ def test_decode_layer_launch_bit_identical(monkeypatch, T, N, n_layers, cap):
                 cache.v[:, 0, :, T:T + N].cpu())
 
     ref = run(False, False, False)
-    for layer, attn_o, use_graph, step in ((False, True, False, False), (True, True, False, False), (True, True, True, False),
-                                            (True, True, False, True), (True, True, True, True), (True, True, True, True)):
-        got = run(layer, attn_o, use_graph, step)
+    # (lds: the projection workgroups keep a gate/up batch in LDS while the attention runs -- default; off = the round-3 form)
+    for layer, attn_o, use_graph, step, lds in ((False, True, False, False, True), (True, True, False, False, True), (True, True, True, False, True),
+                                                 (True, True, False, True, True), (True, True, True, True, True), (True, True, True, True, True),
+                                                 (True, True, True, True, False), (True, True, False, False, False)):
+        got = run(layer, attn_o, use_graph, step, lds)
         for x, y in zip(got, ref):
-            assert torch.equal(x, y), (layer, attn_o, use_graph, step)
+            assert torch.equal(x, y), (layer, attn_o, use_graph, step, lds)
 
 
 def test_decode_layers_only_entry_runs_the_layer_launches():
