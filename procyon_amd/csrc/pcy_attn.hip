@@ -816,7 +816,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
       bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
       mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);   // by the wave that has no gate/up rows (and nothing in flight)
       AB_T(3)
-      mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines);
+      mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, tr ? tr + 8 : nullptr, x_out_lines);
       AB_T(5)
     }
     return;
@@ -957,7 +957,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
     __syncthreads();                                     // every wave is done with the attention output in LDS
     bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
     mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
-    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, nullptr, x_out_lines, pf_off);
+    mc_mlp_body<true>(mc, smem, vthr_gu, tag, gridDim.x, blockIdx.x, 3, wa, wb, tr ? tr + 8 : nullptr, x_out_lines, pf_off);
     AB_T(5)
   }
 #undef AB_T

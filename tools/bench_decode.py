@@ -38,11 +38,13 @@ if os.environ.get("PCY_MC_TRACE"):
         r = (tl - t0) / 100.0   # us (100 MHz)
         print(title, "(us since first WG start)  min / median / max")
         for i, nm in enumerate(names):
-            if tl[:, i].max() == 0: continue
+            if nm == "-" or tl[:, i].max() == 0: continue
             print(f"  {nm:22s} {r[:, i].min():7.2f} {np.median(r[:, i]):7.2f} {r[:, i].max():7.2f}")
     for l in (1, 16, 30):
         show(t[1, l, :64], ["start", "q/k/v staged", "attention done", "x after o in LDS", "-", "layer end"], f"layer {l} attention block, 64 attention WGs")
-        show(t[1, l, 64:], ["start", "qkv rows stored", "ao sample seen", "ao in LDS", "o done", "layer end", "x sample seen", "x fetched"], f"layer {l} attention block, 192 projection WGs")
+        show(t[1, l, 64:], ["start", "qkv rows stored", "ao sample seen", "ao in LDS", "o done", "layer end", "x sample seen", "x fetched", "-",
+                            "gate/up done (wave 0)", "act first half in LDS", "act second half in LDS"], f"layer {l} attention block, 192 projection WGs")
+        show(t[1, l, :64], ["start", "-", "-", "-", "-", "-", "-", "-", "-", "gate/up done (wave 0)", "act first half in LDS", "act second half in LDS"], f"layer {l} MLP stamps, 64 attention WGs")
         if t[0, l].max() > 0:
             show(t[0, l], ["start", "s1 done(w0)", "act A in LDS", "act B in LDS", "s2 done"], f"layer {l} MLP chain")
             print("  gap attention block end -> chain start: %.2f us ; chain end -> next block start: %.2f us" % (
