@@ -1167,16 +1167,19 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
   // Mid-M (128 <= M < 2048 and the 256 x 256 tiling under-fills the chip: one 1024-residue protein, one 512-token prompt): the GEMM is
   // ONE round of tiles, so the tile shape is chosen for CU fill and the k-loop for latency -- gemm_kernel_mid (pcy_gemm_mid.h), shape
   // by a cost model fitted on tools/bench_gemm_mid.py (cold weights): rounds(tiles / 256 CUs) x tile area / efficiency, efficiency
-  // 0.6 / 0.8 / 1.0 for 8 waves of 32 x 32 / 32 x 64 / 64 x 64.  Same bits as the kernels below (same k order per element).
+  // 0.6 / 0.7 / 0.8 / 1.0 for 8 waves of 32 x 32 / 32 x 48 / 32 x 64 / 64 x 64.  Same bits as the kernels below (same k order per element).
+  // (128 x 96: N = 6144 at M <= 512 -- the Llama qkv projection of one prompt -- is ONE full round of 256 tiles instead of 192 of 128 x 128:
+  // 42.5 -> 38.0 us, prefill of a 512-token prompt 9.67 -> 9.55 ms)
   // In the encoder (rocprofv3 kernel time per 1024-residue protein, tools/insitu_ab.py): 5.97 -> 4.78 ms; o + fc2 38.9 -> 22.5 us avg.
   if constexpr (EPI != EPI_GELU_ERF) {
     if (a.mid_cfg == 0 && a.M >= 128) {
-      static const int cand[3][4] = {{5, 128, 64, 6}, {3, 128, 128, 8}, {6, 256, 128, 10}};   // id, TM, TN, 10 x efficiency
+      static const int cand[4][4] = {{5, 128, 64, 6}, {3, 128, 128, 8}, {6, 256, 128, 10}, {14, 128, 96, 7}};   // id, TM, TN, 10 x efficiency
       int best = 0;
       double best_cost = 0;
-      for (int i = 0; i < 3; ++i) {
-        const int fn = cand[i][2] / 2 / 16;   // feature tiles per wave (two waves along N in all three)
+      for (int i = 0; i < 4; ++i) {
+        const int fn = cand[i][2] / 2 / 16;   // feature tiles per wave (two waves along N in all of them)
         if (a.rope_cos != nullptr && fn % 4 != 0) continue;
+        if (EPI == EPI_SWIGLU && fn % 2 != 0) continue;
         const long t = (long)((a.M + cand[i][1] - 1) / cand[i][1]) * ((a.N + cand[i][2] - 1) / cand[i][2]);
         const double cost = (double)((t + 255) / 256) * cand[i][1] * cand[i][2] * 10.0 / cand[i][3];
         if (!best || cost < best_cost) { best = cand[i][0]; best_cost = cost; }

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel_mid(PcyGemmArgs a) {
   X(9, 64, 64, 2, 2, 8)   /* 4 waves of 32 x 32, 128 KiB */                                                        \
   X(10, 256, 128, 4, 2, 2) /* as 6, two stages (96 KiB) */                                                         \
   X(11, 128, 128, 2, 2, 3) /* as 1, 96 KiB */                                                                      \
-  X(12, 128, 128, 2, 2, 5) /* as 1, 160 KiB */
+  X(12, 128, 128, 2, 2, 5) /* as 1, 160 KiB */                                                                     \
+  X(13, 128, 96, 4, 2, 5)  /* 8 waves of 32 tokens x 48 features, 140 KiB: N = 6144 at M = 512 in ONE full round of 256 tiles */ \
+  X(14, 128, 96, 4, 2, 4)  /* as 13, 112 KiB */
 
 template <int EPI, int TM, int TN, int WM, int WN, int S>
 void launch_mid_cfg(hipStream_t s, const PcyGemmArgs& a0) {

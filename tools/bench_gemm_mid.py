@@ -14,7 +14,7 @@ LLAMA = [("llama qkv", 512, 6144, 4096, L.EPI_STORE), ("llama o", 512, 4096, 409
          ("llama gate/up", 512, 28672, 4096, L.EPI_SWIGLU), ("llama down", 512, 4096, 14336, L.EPI_RESID)]
 which = os.environ.get("SHAPES", "all")
 shapes = (ESM if which in ("esm", "all") else []) + (LLAMA if which in ("llama", "all") else [])
-cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,3,4,5,6,7,8,9,10,11,12").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "1,2,3,4,5,6,7,8,9,10,11,12,13,14").split(",")]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, K, epi in shapes:
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
