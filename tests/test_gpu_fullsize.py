@@ -3,7 +3,7 @@ finish these in seconds, so parity is checked through size-independent propertie
 import pytest
 import torch
 
-from conftest import record_parity, rel_err
+from conftest import pcy_disable, record_parity, rel_err
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -50,6 +50,21 @@ def test_llama_full_determinism_and_graph_equals_eager(llama):
     assert torch.equal(t1, t2) and torch.equal(lp1, lp2), "decode is not run-to-run deterministic"
     assert torch.equal(t1, t3), "hipGraph replay and eager launches disagree"
     assert int(t1.min()) >= 0 and int(t1.max()) < 128263
+
+
+def test_llama_full_decode_lds_batch_same_bits_over_400_steps(llama, monkeypatch):
+    """32 layers, 400 replayed decode steps from a 500-token prompt (t = 500 .. 900: across the key-split threshold of the attention):
+    the layer launch with the gate/up batch parked in LDS during the attention (default) and without it (PCY_DISABLE=lds_prefetch) --
+    12 800 hand-overs each, same weights in the same order: tokens, log-probability and the last step's logits must be the same bits.
+    A batch read before its LDS copy has landed would show here."""
+    emb = _emb(1, 500, 3)
+    pcy_disable(monkeypatch, "lds_prefetch")
+    t0, lp0, _, (st0, _) = llama.generate_greedy(emb, None, 401, use_graph=True)
+    l0 = st0.logits.clone()
+    pcy_disable(monkeypatch)
+    for _ in range(2):
+        t1, lp1, _, (st1, _) = llama.generate_greedy(emb, None, 401, use_graph=True)
+        assert torch.equal(t0, t1) and torch.equal(lp0, lp1) and torch.equal(l0, st1.logits)
 
 
 @pytest.mark.parametrize("damped", [False, True])
