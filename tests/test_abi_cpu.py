@@ -74,3 +74,28 @@ def test_no_kernel_spills_registers(tmp_path):
     assert len(found) > 200 and any("decode_step_kernel" in k for k in found) and any("mlp_chain_kernel" in k for k in found), len(found)
     bad = {k: v for k, v in found.items() if v != (0, 0)}
     assert not bad, bad
+
+
+def test_switch_list_matches_whole_names_only(tmp_path):
+    """procyon_amd/csrc/pcy_switch.h: PCY_DISABLE is a comma-separated list of names; a name must match as a whole entry
+    (`decode_step` must not be switched off by `decode_stepx`, nor `attn_o` by `xattn_o` or `attn_o_extra`), wherever it stands."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "pcy_switch.h"\n#include <stdio.h>\nint main(int c, char** v) { for (int i = 1; i < c; ++i) printf("%d", (int)pcy_off(v[i])); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O1", "-I", os.path.join(ROOT, "procyon_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+
+    def run(env_value, *names):
+        env = dict(os.environ)
+        env.pop("PCY_DISABLE", None)
+        if env_value is not None:
+            env["PCY_DISABLE"] = env_value
+        return subprocess.run([str(exe), *names], env=env, capture_output=True, text=True, check=True).stdout
+
+    assert run(None, "attn_o", "decode_step") == "00"
+    assert run("", "attn_o") == "0"
+    assert run("attn_o", "attn_o", "decode_step") == "10"
+    assert run("decode_step,attn_o", "attn_o", "decode_step", "decode_layer") == "110"
+    assert run("decode_stepx,xattn_o,attn_o_extra", "attn_o", "decode_step") == "00"
+    assert run("xattn_o,attn_o", "attn_o") == "1"          # a later whole entry still counts
+    assert run("gemv_lds", "gemv_lds", "gemv_mfma4", "lds_prefetch") == "100"
