@@ -1053,8 +1053,10 @@ void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
     if (units >= 128) ds = 128;
     else if (units >= 64) ds = 64;
     if (force == 16 || force == 64 || force == 128) ds = force;
+    if (a.force_ds == 16 || a.force_ds == 32 || a.force_ds == 64 || a.force_ds == 128) ds = a.force_ds;   // (the twin of the small-batch step)
     if (ds == 128) return launch_dec_ds<DH, G, 128>(s, a);
     if (ds == 64) return launch_dec_ds<DH, G, 64>(s, a);
+    if constexpr (G == 4) { if (ds == 32) return launch_dec_ds<DH, G, 32>(s, a); }
   }
   launch_dec_ds<DH, G, 16>(s, a);
 }

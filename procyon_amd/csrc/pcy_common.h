@@ -141,8 +141,17 @@ __device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// (The pointer is cast to the GLOBAL address space: a weight pointer that the kernel has itself loaded from memory -- the per-layer table of
+// decode_step_kernel -- is otherwise a generic pointer, and hipcc emits flat_load for it.  A flat load counts in lgkmcnt as well as in vmcnt,
+// so every wait for an LDS read also waited for all weight loads in flight.)
+typedef const __attribute__((address_space(1))) u32x4_t* pcy_gptr_u32x4;
 __device__ __forceinline__ uint4 ldg_nt(const bf16_t* p) {
-  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  const u32x4_t v = __builtin_nontemporal_load((pcy_gptr_u32x4)(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// plain 16-byte load from global memory (same reason)
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+  const u32x4_t v = *(pcy_gptr_u32x4)(p);
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 

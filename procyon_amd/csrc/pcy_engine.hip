@@ -67,6 +67,10 @@ struct pcy_ctx {
   int mc_tags_mode = -1;
   uint64_t layers_fp = 0;              // fingerprint of the weight pointers dev_layers was built from
   PcyLayerWeightsDev* dev_layers = nullptr;   // device copy of the layers' weight pointers (decode_step_kernel)
+  // small-batch decode step (pcy_decode_nb.hip): hand-over slots and tag counter PER BATCH SIZE (a slot is rewritten in every step of its
+  // own batch size and its counter only advances with those steps, so a word with the current tag can only come from the current step)
+  uint32_t* nb_tags[9] = {};
+  unsigned* nb_sync = nullptr;        // [16] tag counters, index = batch size
   uint32_t* op_tags = nullptr;        // tagged `act` vector of pcy_decode_mlp ([ffn] words, its own counter)
   size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
@@ -187,7 +191,24 @@ bool decode_step_enabled() { return !pcy_off("decode_step"); }
 // layer against 110 us launch by launch at batch 32 -- a grid barrier under a saturated memory system costs ~10 us, more than the kernel
 // boundary it replaces; removed in round 4, numbers in DESIGN.md)
 bool qkv_finish_launch() { return pcy_off("attn_qkv_finish"); }   // the qkv K-split finish as its own launch instead of inside the attention's
-int decode_mode() { return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) | (pcy_off("lds_prefetch") ? 256 : 0); }
+// PCY_DISABLE=decode_nb: batches of 2..8 rows take the pre-round-5 path (streaming GEMVs below 4 rows, MFMA GEMVs from 4 on) instead of the
+// small-batch step (pcy_decode_nb.hip).  PCY_DISABLE=decode_nb_step: its launch-per-stage twin (gemv_stream_kernel + attn_dec_kernel with the
+// same column slices) instead of the one launch -- same bits, tests compare the two.
+bool decode_nb_enabled() { return !pcy_off("decode_nb"); }
+bool decode_nb_step_enabled() { return !pcy_off("decode_nb_step"); }
+int decode_mode() {
+  return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0);
+}
+// geometry of the small-batch step: Llama-3-8B, 256 CUs
+bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
+  return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
+         c->n_cu >= 256 && m->n_layers <= 128;
+}
+int decode_xmin() {   // cached keys from which the decode attention splits its keys across the slice workgroups (read per call: tests compare)
+  const char* xe = getenv("PCY_AO_XMIN");
+  return xe ? atoi(xe) : 768;
+}
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
@@ -225,7 +246,7 @@ uint64_t layers_fingerprint(const pcy_llama_desc* m) {   // FNV-1a over every we
   }
   return h;
 }
-int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
+int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m, int B = 1) {
   if (int r = ensure_sync_words(c)) return r;
   // A tagged word counts as delivered when its tag equals the chain epoch, so the slots must never hold anything but words of
   // earlier chain launches OF THE SAME LAYOUT: another model -> zeroed slots and a restarted epoch (next tag 1).
@@ -242,6 +263,7 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mc_tags), words * 4));
     HIP_TRY(hipMemset(c->mc_tags, 0, words * 4));
     HIP_TRY(hipMemset(c->ao_sync + 1, 0, 4));
+    for (auto& t : c->nb_tags) { if (t) HIP_TRY(hipFree(t)); t = nullptr; }
     if (c->dev_layers) HIP_TRY(hipFree(c->dev_layers));
     c->dev_layers = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->dev_layers), (size_t)m->n_layers * sizeof(PcyLayerWeightsDev)));
@@ -252,6 +274,17 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m) {
     }
     HIP_TRY(hipMemcpy(c->dev_layers, lw.data(), lw.size() * sizeof(PcyLayerWeightsDev), hipMemcpyHostToDevice));
     c->mc_tags_model = m; c->mc_tags_words = words; c->mc_tags_mode = decode_mode(); c->layers_fp = fp;
+  }
+  if (decode_nb_enabled() && decode_nb_covers(c, m, B) && !c->nb_tags[B]) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->nb_sync) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->nb_sync), 16 * sizeof(unsigned)));
+      HIP_TRY(hipMemset(c->nb_sync, 0, 16 * sizeof(unsigned)));
+    }
+    const size_t nbw = (size_t)m->n_layers * (pcy_decode_nb_tag_words(B) + pcy_decode_nb_line_words(B));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->nb_tags[B]), nbw * 4));
+    HIP_TRY(hipMemset(c->nb_tags[B], 0, nbw * 4));
+    HIP_TRY(hipMemset(c->nb_sync + B, 0, 4));   // zeroed slots, next tag 1
   }
   return 0;
 }
@@ -280,19 +313,45 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
   const size_t sk_bytes = B >= pcy_mfma_min_batch() ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
-  const bool batched = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
+  const bool batched_head = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
+  // 2..8 rows: the small-batch step (pcy_decode_nb.hip) -- one launch for all layers, or its launch-per-stage twin; lm_head as before
+  const bool nb_on = decode_nb_enabled() && decode_nb_covers(c, m, B) && c->nb_tags[B] && c->nb_sync && c->dev_layers && c->ao_sync && c->xwg_err;
+  const bool batched = batched_head && !nb_on;
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
   bool try_layer = decode_layer_enabled() && try_ao && c->mc_tags;   // one launch per decoder layer
+  const bool nb_step = nb_on && decode_nb_step_enabled();
   if (layers_only) {
-    if (try_ao) pcy_launch_bump(s, c->ao_sync);
+    if (try_ao || nb_step) pcy_launch_bump(s, c->ao_sync);
     if (try_layer) pcy_launch_bump(s, c->ao_sync + 1);
+    if (nb_step) pcy_launch_bump(s, c->nb_sync + B);
   } else {
-    pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, try_ao ? c->ao_sync : nullptr,
-                                try_layer ? c->ao_sync + 1 : nullptr);
+    pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, (try_ao || nb_step) ? c->ao_sync : nullptr,
+                                try_layer ? c->ao_sync + 1 : (nb_step ? c->nb_sync + B : nullptr));
   }
   const size_t tag_stride = tag_words_per_layer(m);
   const size_t layer_stride = (size_t)kv->B * Hkv * kv->Tmax * dh;
   bool step_done = false;
+  if (nb_step) {
+    PcyDecAttnArgs t{};
+    t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k; t.vcache = (bf16_t*)kv->v;
+    t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
+    t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
+    t.scale = 1.0f / sqrtf((float)dh);
+    t.xflags = c->ao_sync + 64 + AO_MAX_LAYERS * AO_FLAGS;
+    PcyAttnBlockArgs bp{};
+    bp.x = x; bp.d = d; bp.Nq = qkvw; bp.rms_eps = m->rms_eps; bp.rms_cast = m->rms_cast; bp.epoch = c->nb_sync + B; bp.err = c->xwg_err;
+    PcyMlpChainArgs mc{};
+    mc.x = x; mc.x_out = x; mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast; mc.epoch = c->nb_sync + B; mc.err = c->xwg_err;
+    PcyDecodeStepArgs sa{};
+    sa.layers = c->dev_layers; sa.n_layers = m->n_layers; sa.kv_layer_stride = layer_stride;
+    sa.tags = c->nb_tags[B]; sa.tag_stride = pcy_decode_nb_tag_words(B); sa.xflags_stride = AO_FLAGS;
+    sa.x_lines = c->nb_tags[B] + (size_t)m->n_layers * sa.tag_stride; sa.x_lines_stride = pcy_decode_nb_line_words(B);
+    if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode_nb.py): in-kernel time stamps, [layer][workgroup][16]
+      if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
+      bp.trace = g_mc_trace + (size_t)128 * 256 * 16;
+    }
+    step_done = pcy_launch_decode_step_nb(s, c->device, t, bp, mc, sa, c->n_cu, c->ao_sync, B, decode_xmin());
+  }
   if (try_layer && decode_step_enabled() && c->dev_layers) {   // all layers in one launch
     PcyDecAttnArgs t{};
     t.qkv = qkv; t.ld = qkvw; t.kcache = (bf16_t*)kv->k; t.vcache = (bf16_t*)kv->v;
@@ -320,7 +379,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     PcyGemvArgs g{};
     g.W = (const bf16_t*)L.wqkv; g.x = x; g.y = qkv; g.rms_w = (const bf16_t*)L.ln1; g.rms_eps = m->rms_eps;
     g.rms_cast = m->rms_cast; g.N = qkvw; g.K = d; g.B = B; g.ldx = d; g.ldy = qkvw; g.epi = EPI_STORE;
-    g.splitk_ws = sk_ws; g.splitk_ws_bytes = sk_bytes;
+    g.splitk_ws = sk_ws; g.splitk_ws_bytes = sk_bytes; g.force_stream = nb_on;
     if (batched) {   // (the previous layer's down projection may have written xn already, fused into its K-split finish)
       if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln1, xn, B, d, m->rms_eps, m->rms_cast);
       xn_ready = 0;
@@ -331,9 +390,10 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.o = ao; t.ldo = H * dh; t.pos_dev = st->pos; t.cos_t = (const bf16_t*)m->rope_cos; t.sin_t = (const bf16_t*)m->rope_sin;
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
+    t.force_ds = nb_on ? pcy_decode_nb_ds(B) : 0;
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
-    o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes;
+    o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes; o.force_stream = nb_on;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
     if (try_layer) {   // the whole layer as one launch
@@ -365,7 +425,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     }
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
-    u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU;
+    u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU; u.force_stream = nb_on;
     if (batched) {
       if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, B, d, m->rms_eps, m->rms_cast);
       xn_ready = 0;
@@ -374,7 +434,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     pcy_launch_gemv(s, u);
     PcyGemvArgs w{};
     w.W = (const bf16_t*)L.wdown; w.x = act; w.y = x; w.resid = x; w.N = d; w.K = F; w.B = B; w.ldx = F; w.ldy = d; w.epi = EPI_RESID;
-    w.splitk_ws = sk_ws; w.splitk_ws_bytes = sk_bytes;
+    w.splitk_ws = sk_ws; w.splitk_ws_bytes = sk_bytes; w.force_stream = nb_on;
     if (batched && B <= 32) {
       w.next_rms_w = (const bf16_t*)(l + 1 < m->n_layers ? m->layers[l + 1].ln1 : m->final_norm);
       w.next_xn = xn; w.fused_next = &xn_ready; w.rms_eps = m->rms_eps; w.rms_cast = m->rms_cast;
@@ -385,7 +445,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   PcyGemvArgs h{};
   h.W = (const bf16_t*)m->lm_head; h.x = x; h.y = (bf16_t*)st->logits; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
   h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = B; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
-  if (batched) {
+  if (batched_head) {
     if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)m->final_norm, xn, B, d, m->rms_eps, m->rms_cast);
     h.x = xn; h.rms_w = nullptr;
   }
@@ -521,6 +581,8 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->ao_sync) hipFree(c->ao_sync);
   if (c->mc_tags) hipFree(c->mc_tags);
   if (c->dev_layers) hipFree(c->dev_layers);
+  for (auto& t : c->nb_tags) if (t) hipFree(t);
+  if (c->nb_sync) hipFree(c->nb_sync);
   if (c->op_tags) hipFree(c->op_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);
@@ -1128,7 +1190,7 @@ int pcy_llama_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c, m)) return r;
+  if (int r = ensure_decode_state(c, m, B)) return r;
   enqueue_decode(c, m, kv, st, B);
   return check_launch("pcy_llama_decode");
 }
@@ -1137,7 +1199,7 @@ int pcy_llama_decode_layers(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_ca
   PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode_layers: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c, m)) return r;
+  if (int r = ensure_decode_state(c, m, B)) return r;
   for (int i = 0; i < reps; ++i) enqueue_decode(c, m, kv, st, B, true);
   return check_launch("pcy_llama_decode_layers");
 }
@@ -1191,7 +1253,7 @@ int pcy_llama_greedy(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_greedy: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c, m)) return r;
+  if (int r = ensure_decode_state(c, m, B)) return r;
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       enqueue_decode(c, m, kv, st, B);
@@ -1206,7 +1268,7 @@ int pcy_llama_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cac
   PCY_STICKY(c);
   if (B > kv->B) return fail(1, "pcy_llama_decode_graph: B=%d exceeds cache rows %d", B, kv->B);
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c, m)) return r;
+  if (int r = ensure_decode_state(c, m, B)) return r;
   return replay_decode_graph(c, m, kv, st, B, 1, 1);
 }
 
@@ -1229,7 +1291,7 @@ int pcy_llama_sample(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv
   if (!(temperature > 0.f) || nucleus_prob >= 1.f) return fail(1, "pcy_llama_sample: temperature > 0 and nucleus_prob < 1 required");
   if (m->vocab > pcy_sample_max_vocab()) return fail(1, "pcy_llama_sample: vocabulary %d unsupported (<= %d)", m->vocab, pcy_sample_max_vocab());
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax))) return r;
-  if (int r = ensure_decode_state(c, m)) return r;
+  if (int r = ensure_decode_state(c, m, B)) return r;
   if (int r = ensure_sample_state(c, B, m->vocab)) return r;
   for (int i = 0; i < n_steps; ++i) {
     enqueue_decode(c, m, kv, st, B);

@@ -24,6 +24,9 @@ struct PcyGemvArgs {
   // report the number of splits in *defer_finish (0: y has been written as usual) -- the consumer adds them up itself
   // (decode attention: PcyDecAttnArgs::qkv_partials)
   int* defer_finish;
+  // 1: the streaming kernel (one dot product per row and lane, rows in groups of <= 4) whatever the batch -- the launch-per-stage twin of the
+  // small-batch decode step (pcy_decode_nb.hip) is built from it
+  int force_stream;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 
@@ -171,6 +174,9 @@ struct PcyDecAttnArgs {
   // The attention workgroup adds the G + 2 rows of ITS kv head in split order (what gemv_splitk_finish_kernel does: same bits)
   // into LDS -- one launch less per decoder layer.
   const float* qkv_partials; int qkv_splits;
+  // stand-alone launch only: output columns per workgroup (16 / 32 / 64 / 128; 0 = the launcher's choice) -- the summation order of P.V
+  // depends on it, and the launch-per-stage twin of the small-batch decode step must use the fused launch's
+  int force_ds;
 };
 void pcy_launch_attn_decode(hipStream_t s, const PcyDecAttnArgs& a);
 struct PcyGemvArgs;
@@ -213,6 +219,14 @@ bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAtt
                             int n_cu, const unsigned* step_epoch);
 bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
                              const unsigned* step_epoch, unsigned* xflags);
+// Small-batch decode step (pcy_decode_nb.hip): every decoder layer for 2..8 rows in ONE launch, the weights streamed once.  Hand-over slots
+// per layer: pcy_decode_nb_tag_words(B) words (act | qkv | attention output | x after o, B rows each), residual stream between two layers:
+// pcy_decode_nb_line_words(B) words; p.epoch = the tag counter of THIS batch size's slots.  false = not covered, nothing launched.
+size_t pcy_decode_nb_tag_words(int B);
+size_t pcy_decode_nb_line_words(int B);
+int pcy_decode_nb_ds(int B);   // output columns per attention workgroup of the B-row step (what the launch-per-stage twin must use)
+bool pcy_launch_decode_step_nb(hipStream_t s, int device, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc,
+                               const PcyDecodeStepArgs& st, int n_cu, const unsigned* step_epoch, int B, int xmin);
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
 int pcy_gemv_rms_threads(int N);
 
