@@ -35,6 +35,40 @@ template <int NB> struct NbGeom {
   static constexpr int P2 = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
 };
 
+// Hand-over loads of this launch: ONE 16-byte sc1 buffer load per lane (the compiler counts it in vmcnt like any load) instead of ld16_agent's
+// two 8-byte atomic loads -- half the instructions in the CU's memory queue per vector.  Every tagged vector of a step lives in one allocation
+// (base); a word is validated by its own tag, so a load torn between two stores of a line is harmless.
+struct NbBuf { __amdgpu_buffer_rsrc_t rs; const uint32_t* base; };
+__device__ __forceinline__ uint4 nb_ld16(const NbBuf& nb, const void* p) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(nb.rs, (int)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(nb.base)), 0, 16 /* sc1 */);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+// mc_fetch_issue / mc_fetch_finish (pcy_handover.h) on these loads
+template <int NV>
+__device__ __forceinline__ void nb_fetch_issue(const NbBuf& nb, const uint32_t* src, int w0, int lane, uint4 (&pre)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) pre[j] = nb_ld16(nb, src + w0 + (j * 64 + lane) * 4);
+}
+template <int NV>
+__device__ __forceinline__ void nb_fetch_finish(const NbBuf& nb, const uint32_t* src, int w0, int lane, uint32_t tag, bf16_t* dst, uint4 (&pre)[NV], unsigned* err,
+                                                unsigned code) {
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
+    if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+    if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
+    __builtin_amdgcn_s_sleep(16);
+    nb_fetch_issue<NV>(nb, src, w0, lane, pre);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    *reinterpret_cast<uint2*>(dst + w0 + (j * 64 + lane) * 4) =
+        make_uint2((pre[j].x & 0xffffu) | (pre[j].y << 16), (pre[j].z & 0xffffu) | (pre[j].w << 16));
+}
+
 // Wave totals of N values in N - 1 exchanges (+ the steps that are left when N < 64) instead of 6 N: at offset 32 a lane of the lower
 // half keeps the even value of every pair and receives the partner's copy of it, the upper half the odd one; and so on.  Lane l ends with
 // the total of value nb_red_index<N>(l).  The additions of one value form the xor butterfly of wave_sum (own + partner at offsets
@@ -80,39 +114,51 @@ __device__ __forceinline__ bool nb_red_owner(int lane) {
 // gemv_stream_kernel launched with `vthr` threads (mc_rms_stage).  K == 4096, 512 threads.  Ends with a barrier.
 template <int NB>
 __device__ __forceinline__ void nb_rms_stage(const bf16_t* x, const bf16_t* __restrict__ w, int vthr, float eps, int cast, bf16_t* xs, float* red) {
-  constexpr int K = NBD;
+  constexpr int K = NBD, P2 = NbGeom<NB>::P2;
   const int tid = pcy_tid(), lane = tid & 63, wave = tid >> 6;
   const uint4 g = ldg16(w + tid * 8);
-  float ss[NB];
+  // every row's values of this thread in registers first (independent LDS reads), then ONE transposing wave reduction for all rows: row by
+  // row (six dependent exchanges each, a dependent LDS read per partial sum) the stage took 3.5 us at 4 rows and 6.5 us at 8 -- twice per layer
+  uint4 xv[NB], xw[NB];
+  const bool second = tid < vthr && (tid + vthr) * 8 < K;   // (K = 4096 <= 2 x vthr x 8 for every launch shape: at most two chunks per thread)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    float s = 0.f;
+    xv[b] = *reinterpret_cast<const uint4*>(x + b * K + tid * 8);
+    xw[b] = second ? *reinterpret_cast<const uint4*>(x + b * K + (tid + vthr) * 8) : make_uint4(0, 0, 0, 0);
+  }
+  float ss[P2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = (tid + i * vthr) * 8;
-      if (tid < vthr && k < K) {
-        const uint4 v = *reinterpret_cast<const uint4*>(x + b * K + k);
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+  for (int b = 0; b < P2; ++b) {
+    float s = 0.f;
+    if (b < NB) {
+      const uint32_t w4[4] = {xv[b < NB ? b : 0].x, xv[b < NB ? b : 0].y, xv[b < NB ? b : 0].z, xv[b < NB ? b : 0].w};
+      const uint32_t v4[4] = {xw[b < NB ? b : 0].x, xw[b < NB ? b : 0].y, xw[b < NB ? b : 0].z, xw[b < NB ? b : 0].w};
+      if (tid < vthr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); s += f0 * f0 + f1 * f1; }
       }
-    }
-    ss[b] = wave_sum(s);
-  }
-  lds_barrier();
-  if (lane == 0) {
+      if (second) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) red[b * 8 + wave] = ss[b];
+        for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(v4[j]), f1 = hi_bf(v4[j]); s += f0 * f0 + f1 * f1; }
+      }
+    }
+    ss[b] = s;
   }
+  const float tot = nb_wave_reduce<P2>(ss, lane);
+  const int rb_ = nb_red_index<P2>(lane);
+  lds_barrier();
+  if (nb_red_owner<P2>(lane) && rb_ < NB) red[rb_ * 8 + wave] = tot;
   lds_barrier();
   const int nw = vthr >> 6;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(red + b * 8), r1 = *reinterpret_cast<const f32x4*>(red + b * 8 + 4);
+    const float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
     float t = 0.f;
-    for (int i = 0; i < nw; ++i) t += red[b * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += i < nw ? rr[i] : 0.f;   // the first nw partial sums in order (+ 0 changes nothing)
     const float rs = rsqrtf(t / (float)K + eps);
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + b * K + tid * 8);
-    const uint32_t xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {g.x, g.y, g.z, g.w};
+    const uint32_t xin[4] = {xv[b].x, xv[b].y, xv[b].z, xv[b].w}, gin[4] = {g.x, g.y, g.z, g.w};
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -127,13 +173,14 @@ __device__ __forceinline__ void nb_rms_stage(const bf16_t* x, const bf16_t* __re
 
 // NB tagged vectors of 4096 words (row stride `sstride` words) -> LDS dst [NB][4096] bf16: one wave watches a sample of the last row,
 // then every wave takes its 512 words of every row, four rows per round trip.  All 512 threads; ends with a barrier.
-template <int NB>
-__device__ __forceinline__ void nb_fetch_vectors(const uint32_t* src, size_t sstride, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+template <int NB, typename AfterIssue>
+__device__ __forceinline__ void nb_fetch_vectors(const NbBuf& nbuf, const uint32_t* src, size_t sstride, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code,
+                                                 AfterIssue after_issue) {
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   if (wave == watch_wave) {
     unsigned spins = 0;
     for (;;) {
-      const uint4 v = ld16_agent(src + (size_t)(NB - 1) * sstride + NBD - 256 + lane * 4);
+      const uint4 v = nb_ld16(nbuf, src + (size_t)(NB - 1) * sstride + NBD - 256 + lane * 4);
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
@@ -147,10 +194,11 @@ __device__ __forceinline__ void nb_fetch_vectors(const uint32_t* src, size_t sst
     uint4 t[CH][2];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if (b0 + c < NB) mc_fetch_issue<2>(src + (size_t)(b0 + c) * sstride, wave * 512, lane, t[c]);
+      if (b0 + c < NB) nb_fetch_issue<2>(nbuf, src + (size_t)(b0 + c) * sstride, wave * 512, lane, t[c]);
+    if (b0 + CH >= NB) after_issue();   // (weight prefetches go out BEHIND the last hand-over loads: a CU's loads return in order)
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if (b0 + c < NB) mc_fetch_finish<2>(src + (size_t)(b0 + c) * sstride, wave * 512, lane, tag, dst + (b0 + c) * NBD, t[c], err, code);
+      if (b0 + c < NB) nb_fetch_finish<2>(nbuf, src + (size_t)(b0 + c) * sstride, wave * 512, lane, tag, dst + (b0 + c) * NBD, t[c], err, code);
   }
   __syncthreads();
 }
@@ -158,14 +206,14 @@ __device__ __forceinline__ void nb_fetch_vectors(const uint32_t* src, size_t sst
 // The residual stream between two layers: workgroup g of the producing layer owns words [g * XS, g * XS + 16 NB) of `src`, element
 // 16 g + i of row b at word g * XS + 16 b + i (a line has one writer for even NB).  -> dst [NB][4096] bf16.  Ends with a barrier.
 template <int NB>
-__device__ __forceinline__ void nb_fetch_lines(const uint32_t* src, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+__device__ __forceinline__ void nb_fetch_lines(const NbBuf& nbuf, const uint32_t* src, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
   constexpr int XS = NbGeom<NB>::XS;
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   auto word_of = [&](int g, int b, int piece) __attribute__((always_inline)) { return g * XS + b * 16 + piece * 4; };
   if (wave == watch_wave) {   // the last 16 workgroups' words of the last row
     unsigned spins = 0;
     for (;;) {
-      const uint4 v = ld16_agent(src + word_of(256 - 16 + (lane >> 2), NB - 1, lane & 3));
+      const uint4 v = nb_ld16(nbuf, src + word_of(256 - 16 + (lane >> 2), NB - 1, lane & 3));
       const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
@@ -185,7 +233,7 @@ __device__ __forceinline__ void nb_fetch_lines(const uint32_t* src, int watch_wa
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (b0 + c < NB) {
-            t[c][j] = ld16_agent(src + word_of(wave * 32 + j * 16 + (lane >> 2), b0 + c, lane & 3));
+            t[c][j] = nb_ld16(nbuf, src + word_of(wave * 32 + j * 16 + (lane >> 2), b0 + c, lane & 3));
             ok = ok && (t[c][j].x >> 16) == tag && (t[c][j].y >> 16) == tag && (t[c][j].z >> 16) == tag && (t[c][j].w >> 16) == tag;
           }
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
@@ -210,43 +258,67 @@ __device__ __forceinline__ void nb_gather(const float (&acc)[RW][NB], float (&v)
   for (int idx = 0; idx < NP; ++idx) v[idx] = (idx / RW < NB) ? acc[idx % RW][(idx / RW) < NB ? idx / RW : 0] : 0.f;
 }
 
+// first (which & 1) / second (which & 2) batch of UB k-iterations of this wave's first gate/up unit -> wa / wb: what nb_mlp_body expects to find
+template <int UB>
+__device__ __forceinline__ void nb_prime_gate_up(const PcyMlpChainArgs& a, int lane, int gidx, uint4 (&wa)[8 * UB], uint4 (&wb)[8 * UB], int which) {
+  const McRowG row_g{a.F, a.d};
+  if (which & 1) {
+#pragma unroll
+    for (int un = 0; un < UB; ++un)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wa[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + (un * 64 + lane) * 8);
+  }
+  if (which & 2) {
+#pragma unroll
+    for (int un = 0; un < UB; ++un)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wb[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + ((UB + un) * 64 + lane) * 8);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The MLP of one layer for NB rows (every workgroup; `wg` = its index, 256 of them).  Entry: x after the o projection is on its way as
-// the tagged vectors xo_tag [NB][4096]; wa / wb hold the first two batches of this wave's first gate/up unit (waves 0..6).
-// ra / rb: the two LDS regions [NB][4096]; misc: >= 2 KB.
-template <int NB>
-__device__ __forceinline__ void nb_mlp_body(const PcyMlpChainArgs& a, const uint32_t* xo_tag, char* smem, int vthr_gu, uint32_t tag, int wg,
-                                            uint4 (&wa)[16], uint4 (&wb)[16], unsigned long long* tr, uint32_t* x_out_lines) {
+// the tagged vectors xo_tag [NB][4096]; wa / wb hold the first two batches (UB k-iterations of 8 rows each) of this wave's first gate/up
+// unit (waves 0..6).  ra / rb: the two LDS regions [NB][4096]; misc: >= 2 KB behind them.
+//
+// gate/up: 7 waves x 2 units of 4 features, as at batch 1.
+// down: K is split four ways.  A hand-over load returns behind everything its CU has in flight (~10 us under a saturated memory system),
+// and with the whole of act needed by every workgroup the down stage was a chain of four such fetches (35 us for 117 MB at 4 rows).  Now
+// workgroup group g = (wg % 8) / 2 -- two XCDs -- owns the 512-blocks {g + 4 j, j < 7} of K for ALL 4096 rows: 8 rows per wave, ONE fetch of
+// NB x 3584 act values per workgroup (wave j takes block g + 4 j), partial sums handed to the workgroup that owns the row as {tag, fp32}
+// words, which adds the four in group order, the residual, and publishes the row as before.  Per row:
+//   p_g = wave_sum( sum over j of dot8 over block g + 4 j, in j order ) ;  x_out = bf16( bf16(((p0 + p1) + p2) + p3) + x )
+// -- the arithmetic of gemv_kwin4_kernel (pcy_gemv.hip), the launch-per-stage twin.
+template <int NB, int UB>
+__device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChainArgs& a, const uint32_t* xo_tag, unsigned long long* part, char* smem, int vthr_gu, uint32_t tag,
+                                            int wg, uint4 (&wa)[8 * UB], uint4 (&wb)[8 * UB], unsigned long long* tr, uint32_t* x_out_lines, bool prime_second) {
   constexpr int d = NBD, F = NBF, XS = NbGeom<NB>::XS, P2 = NbGeom<NB>::P2;
+  constexpr int GB = 8 / UB;                    // batches per gate/up unit
+  constexpr int DB = (7 + UB - 1) / UB;         // batches of the down stage (7 k-iterations)
   bf16_t* ra = reinterpret_cast<bf16_t*>(smem);
   bf16_t* rb = ra + NB * d;
   float* red = reinterpret_cast<float*>(rb + NB * d);                 // [NB][8]
   uint32_t* line = reinterpret_cast<uint32_t*>(red + NB * 8);         // [NB][32]
-  bf16_t* xres = reinterpret_cast<bf16_t*>(line + NB * 32);           // [NB][16] this workgroup's rows of x (the down epilogue's residual)
+  bf16_t* xres = reinterpret_cast<bf16_t*>(line + NB * 32);           // [NB][16] this workgroup's rows of x (the epilogue's residual)
   const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define NB_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
-  nb_fetch_vectors<NB>(xo_tag, d, 7, tag, rb, a.err, 13u);
+  // prime_second (workgroup-uniform): the second gate/up batch of the wave's first unit is requested here, behind the loads that fetch x
+  nb_fetch_vectors<NB>(nbuf, xo_tag, d, 7, tag, rb, a.err, 13u, [&]() __attribute__((always_inline)) {
+    if (prime_second && wave < 7) nb_prime_gate_up<UB>(a, lane, wg * 7 + wave, wa, wb, 2);
+  });
   NB_T(8)
   if (tid < NB * 16) xres[tid] = rb[(tid >> 4) * d + wg * 16 + (tid & 15)];
   nb_rms_stage<NB>(rb, a.ln2, vthr_gu, a.rms_eps, a.rms_cast, ra, red);
-  // ---- gate/up: units gidx and gidx + 1792 of 4 features (8 weight rows), 4 batches of 2 k-iterations each ----
-  const int gw = wg * MC_WV + wave;
-  auto issue_down = [&](int q, uint4 (&w)[16]) __attribute__((always_inline)) {
+  // down: this workgroup's K blocks and this wave's 8 rows
+  const int kg = (wg & 7) >> 1, kq = (wg >> 3) * 2 + (wg & 1);       // group (an XCD pair), index in the group
+  const int dr0 = (kq * 8 + wave) * 8;
+  auto issue_down = [&](int t, uint4 (&w)[8 * UB]) __attribute__((always_inline)) {   // batch t = k-iterations [t UB, t UB + UB) of the 7
 #pragma unroll
-    for (int un = 0; un < MC_UNB_D; ++un)
+    for (int un = 0; un < UB; ++un)
+      if (t * UB + un < 7) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) w[un * 2 + i] = ldg_nt(a.wdown + (size_t)(gw * 2 + i) * F + ((q * MC_UNB_D + un) * 64 + lane) * 8);
-  };
-  uint4 tq[NB][2];
-  auto win_issue = [&](int q) __attribute__((always_inline)) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) mc_fetch_issue<2>(a.act_tag + (size_t)b * F + q * NBWIN, wave * 512, lane, tq[b]);
-  };
-  auto win_finish = [&](int q, bf16_t* slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      mc_fetch_finish<2>(a.act_tag + (size_t)b * F + q * NBWIN, wave * 512, lane, tag, slot + b * NBWIN, tq[b], a.err, 20u + (unsigned)q);
-    }
+        for (int i = 0; i < 8; ++i) w[un * 8 + i] = ldg_nt(a.wdown + (size_t)(dr0 + i) * F + ((kg + 4 * (t * UB + un)) * 64 + lane) * 8);
+      }
   };
   if (wave < 7) {
     const McRowG row_g{F, d};
@@ -278,15 +350,17 @@ __device__ __forceinline__ void nb_mlp_body(const PcyMlpChainArgs& a, const uint
     // (the lane index goes through an optimisation barrier in every iteration: otherwise all lane-derived addresses of the loop -- and of
     // the down rows requested at its end -- are hoisted in front of it and kept live: 28 + VGPRs, spills)
     int ln = lane;
-    auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
+    auto issue = [&](int t, uint4 (&w)[8 * UB]) __attribute__((always_inline)) {      // batch t of the 2 GB batches of the two units
+      const int u = t < GB ? u1 : u2, it0 = (t < GB ? t : t - GB) * UB;
 #pragma unroll
-      for (int un = 0; un < 2; ++un)
+      for (int un = 0; un < UB; ++un)
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[un * 8 + i] = ldg_nt(a.wgu + row_g(u, i) + ((it0 + un) * 64 + ln) * 8);
     };
-    auto compute = [&](int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
+    auto compute = [&](int t, const uint4 (&w)[8 * UB]) __attribute__((always_inline)) {
+      const int it0 = (t < GB ? t : t - GB) * UB;
 #pragma unroll
-      for (int un = 0; un < 2; ++un)
+      for (int un = 0; un < UB; ++un)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const uint4 xv = *reinterpret_cast<const uint4*>(ra + b * d + ((it0 + un) * 64 + ln) * 8);
@@ -295,84 +369,108 @@ __device__ __forceinline__ void nb_mlp_body(const PcyMlpChainArgs& a, const uint
         }
     };
 #pragma unroll 1
-    for (int s = 0; s < 3; ++s) {
+    for (int pr = 0; pr < GB - 1; ++pr) {       // pairs of batches; wa / wb hold batches 2 pr, 2 pr + 1 on entry
       asm volatile("" : "+v"(ln));
-      const int u = s < 2 ? u1 : u2, it0 = (s & 1) * 4;
-      const int un_ = s + 1 < 2 ? u1 : u2, itn = ((s + 1) & 1) * 4;
-      compute(it0, wa);
-      issue(un_, itn, wa);
-      compute(it0 + 2, wb);
-      if (s & 1) finish(u);
-      issue(un_, itn + 2, wb);
+      compute(2 * pr, wa);
+      issue(2 * pr + 2, wa);
+      compute(2 * pr + 1, wb);
+      if (2 * pr + 1 == GB - 1) finish(u1);
+      issue(2 * pr + 3, wb);
     }
     asm volatile("" : "+v"(ln));
-    compute(4, wa);
-    compute(6, wb);
+    compute(2 * GB - 2, wa);
+    compute(2 * GB - 1, wb);
     finish(u2);
     NB_T(9)
   }
-  // (one piece of code for all eight waves: with the requests inside the branch above and in an else-branch for wave 7 the two
-  // definitions of wa / wb met in 32 four-register copies and the allocator spilled both batches)
-  if (wave < 7) win_issue(0);
+  // ---- down ----
+  // (one piece of code for all eight waves: requests inside the branch above and in an else-branch for wave 7 met in 32 four-register
+  // copies and the allocator spilled both batches)
+  uint4 tq[NB][2];
+  if (wave < 7) {   // wave j: block kg + 4 j of act, all rows -- in front of the weight rows (a CU's loads return in order)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
+  }
   issue_down(0, wa);
   issue_down(1, wb);
-  if (wave < 7) { win_finish(0, rb); win_issue(1); }
-  lds_barrier();   // window 0 is in rb; nobody reads ra (normalised x) any more
+  NB_T(5)
+  if (wave < 7) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      nb_fetch_finish<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tag, rb + b * NBWIN + wave * 512, tq[b], a.err, 20u);
+    NB_T(6)
+  }
+  lds_barrier();   // this group's act values are in rb
   NB_T(10)
-  // ---- down: rows 2 gw, 2 gw + 1; batch q = k-iterations [7 q, 7 q + 7) against window q ----
-  float dacc[2][NB];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) dacc[i][b] = 0.f;
-  auto dcompute = [&](const bf16_t* slot, const uint4 (&w)[16]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int un = 0; un < MC_UNB_D; ++un)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(slot + b * NBWIN + (un * 64 + lane) * 8);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dacc[i][b] = dot8(w[un * 2 + i], xv, dacc[i][b]);
-      }
-    // the sums are pinned here: otherwise the dot products of ALL four batches sink to the end of the function (their results are only used
-    // there), behind the window barriers, and four batches of weights stay live -- 224 VGPRs, 80 + spilled
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(dacc[i][b]));
-  };
-  dcompute(rb, wa);
-  issue_down(2, wa);
-  if (wave < 7) { win_finish(1, ra); win_issue(2); }
-  lds_barrier();   // window 1 in ra; everyone is done with window 0
-  dcompute(ra, wb);
-  issue_down(3, wb);
-  if (wave < 7) { win_finish(2, rb); win_issue(3); }
-  lds_barrier();
-  NB_T(11)
-  dcompute(rb, wa);
-  if (wave < 7) win_finish(3, ra);
-  lds_barrier();
-  dcompute(ra, wb);
-  // ---- x_out = x + act . Wdown^T ----
   {
-    constexpr int NP = 2 * P2;
+    float dacc[8][NB];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) dacc[i][b] = 0.f;
+    auto dcompute = [&](int t, const uint4 (&w)[8 * UB]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int un = 0; un < UB; ++un)
+        if (t * UB + un < 7) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(rb + b * NBWIN + ((t * UB + un) * 64 + lane) * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dacc[i][b] = dot8(w[un * 8 + i], xv, dacc[i][b]);
+          }
+        }
+      // the sums are pinned here: otherwise the dot products of ALL batches sink to the end of the function (their results are only used
+      // there) and every batch of weights stays live -- spills
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(dacc[i][b]));
+    };
+#pragma unroll
+    for (int t = 0; t < DB; t += 2) {
+      dcompute(t, wa);
+      if (t + 2 < DB) issue_down(t + 2, wa);
+      if (t + 1 < DB) {
+        dcompute(t + 1, wb);
+        if (t + 3 < DB) issue_down(t + 3, wb);
+      }
+    }
+    NB_T(11)
+    // partial sums of this wave's 8 rows x NB -> the rows' owners: word (row, kg, b) = {fp32 : tag}
+    constexpr int NP = 8 * P2;
     float v[NP];
 #pragma unroll
-    for (int idx = 0; idx < NP; ++idx) v[idx] = (idx >> 1) < NB ? dacc[idx & 1][(idx >> 1) < NB ? (idx >> 1) : 0] : 0.f;
+    for (int idx = 0; idx < NP; ++idx) v[idx] = (idx >> 3) < NB ? dacc[idx & 7][(idx >> 3) < NB ? (idx >> 3) : 0] : 0.f;
     const float tot = nb_wave_reduce<NP>(v, lane);
-    const int idx = nb_red_index<NP>(lane), b = idx >> 1, i = idx & 1;
-    if (nb_red_owner<NP>(lane) && b < NB) {
-      float r = rbf(tot);
-      r = rbf(r + bf2f(xres[b * 16 + wave * 2 + i]));
-      line[b * 16 + wave * 2 + i] = f2bf(r);
-    }
+    const int idx = nb_red_index<NP>(lane), b = idx >> 3, i = idx & 7;
+    if (nb_red_owner<NP>(lane) && b < NB)
+      __hip_atomic_store(part + ((size_t)(dr0 + i) * 4 + kg) * NB + b, ((unsigned long long)__float_as_uint(tot) << 32) | tag, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
   }
-  lds_barrier();
+  // ---- x_out = x + act . Wdown^T: rows [16 wg, 16 wg + 16) of every batch row, thread (b, e) ----
   if (tid < NB * 16) {
     const int b = tid >> 4, e = tid & 15;
-    if (x_out_lines) __hip_atomic_store(x_out_lines + wg * XS + tid, (tag << 16) | line[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else a.x_out[(size_t)b * d + wg * 16 + e] = (bf16_t)line[tid];
+    const unsigned long long* src = part + ((size_t)(wg * 16 + e) * 4) * NB + b;
+    unsigned long long pw[4];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pw[g] = __hip_atomic_load(src + (size_t)g * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (uint32_t)pw[g] == tag;
+      }
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (pcy_wait_give_up(spins, 1u << 19, a.err, 24u, lane)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    float r = __uint_as_float((uint32_t)(pw[0] >> 32)) + __uint_as_float((uint32_t)(pw[1] >> 32));
+    r += __uint_as_float((uint32_t)(pw[2] >> 32));
+    r += __uint_as_float((uint32_t)(pw[3] >> 32));
+    r = rbf(r);
+    r = rbf(r + bf2f(xres[tid]));
+    if (x_out_lines) __hip_atomic_store(x_out_lines + wg * XS + tid, (tag << 16) | f2bf(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.x_out[(size_t)b * d + wg * 16 + e] = f2bf(r);
   }
   NB_T(12)
 #undef NB_T
@@ -381,9 +479,9 @@ __device__ __forceinline__ void nb_mlp_body(const PcyMlpChainArgs& a, const uint
 // ------------------------------------------------------------------------------------------------
 // One decoder layer for NB rows (see the head of the file).  x_in_lines == nullptr: the layer's input is p.x [NB][4096] in global memory
 // (written before the launch); x_out_lines == nullptr: the result goes to mc.x_out [NB][4096].
-template <int DH, int G, int NB>
-__device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_attn, unsigned xepoch,
-                                              int vthr_qkv, size_t stage_off, int vthr_gu, char* smem, const uint32_t* x_in_lines,
+template <int DH, int G, int NB, int UB>
+__device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, unsigned long long* part, int n_attn,
+                                              unsigned xepoch, int vthr_qkv, size_t stage_off, int vthr_gu, char* smem, const uint32_t* x_in_lines,
                                               uint32_t* x_out_lines, unsigned long long* tr_base) {
   constexpr int DS = NbGeom<NB>::DS, SLICES = NbGeom<NB>::SLICES, P2 = NbGeom<NB>::P2;
   constexpr int d = NBD, K = NBD;
@@ -395,7 +493,7 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   const int wg = (int)blockIdx.x;
   if (wg < n_attn) {
     // ---- attention of one (row, kv head, column slice); units beyond SLICES x Hkv x NB (NB = 3, 5, 6, 7) have none ----
-    uint4 wa[16], wb[16];
+    uint4 wa[8 * UB], wb[8 * UB];
     const int unit = wg;
     const int kvh = unit % a.Hkv, bx = (unit / a.Hkv) % SLICES, b = unit / (a.Hkv * SLICES);   // kv head in the low digits: the slices of a head share an XCD's L2
     if (b < NB) {
@@ -416,7 +514,7 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
           uint4 v = make_uint4(0, 0, 0, 0);
           unsigned spins = 0;
           for (;;) {
-            if (mine) v = ld16_agent(qt + w0);
+            if (mine) v = nb_ld16(nbuf, qt + w0);
             const bool ok = !mine || ((v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag);
             if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
             if (pcy_wait_give_up(spins, 1u << 19, err, 9u, lane)) break;
@@ -430,9 +528,9 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       attn_dec_body<DH, G, DS>(a, smem, bx, kvh, b, hook);
     }
     NB_T(2)
-    if (wave < 7) mc_prime_gate_up(mc, lane, wg * 7 + wave, wa, wb, true);   // 32 KB per wave while x is on its way
+    if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 3);   // two batches per wave while x is on its way
     __syncthreads();                                   // the attention's LDS is dead
-    nb_mlp_body<NB>(mc, p.xo_tag, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines);
+    nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, false);
     return;
   }
   // ---- projection workgroups (192): 4 qkv rows per wave; the first d / 32 of them also 4 o rows per wave ----
@@ -451,13 +549,15 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
 #pragma unroll
       for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(r0 + i) * d + (it * 64 + lane) * 8);
     if (x_in_lines) {
-      nb_fetch_lines<NB>(x_in_lines, 7, tag, rb, p.err, 14u);
+      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u);
     } else {
 #pragma unroll
       for (int b = 0; b < NB; ++b) *reinterpret_cast<uint4*>(rb + b * d + tid * 8) = ldg16(p.x + (size_t)b * d + tid * 8);
       __syncthreads();
     }
+    NB_T(13)
     nb_rms_stage<NB>(rb, p.ln1, vthr_qkv, p.rms_eps, p.rms_cast, ra, red);
+    NB_T(14)
     float acc[4][NB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -477,14 +577,15 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
     const int idx = nb_red_index<NP>(lane), b = idx >> 2, i = idx & 3;
     // the workgroup's 32 rows of a row b = one 128-byte line of its tagged vector, stored by one instruction
     if (nb_red_owner<NP>(lane) && b < NB) line[b * 32 + wave * 4 + i] = (tag << 16) | f2bf(rbf(tot));
+    NB_T(15)
   }
   __syncthreads();   // (also: every wave is done with RMSNorm(x) in ra)
   if (wave < NB && lane < 32)
     __hip_atomic_store(p.qkv_tag + (size_t)wave * NBNQ + (r0 & ~31) + lane, line[wave * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NB_T(1)
-  uint4 wa[16], wb[16];
-  // the first gate/up batch of the MLP while the attention runs (16 KB per wave)
-  if (wave < 7) mc_prime_gate_up(mc, lane, wg * 7 + wave, wa, wb, false);
+  uint4 wa[8 * UB], wb[8 * UB];
+  // the first gate/up batch of the MLP while the attention runs
+  if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 1);
   if (active) {
     uint4 w[32];   // o rows [r0, r0 + 4) wait in registers while the attention runs
 #pragma unroll
@@ -496,7 +597,7 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       const int bw = lane % NB;
       unsigned spins = 0;
       for (;;) {
-        const uint4 v = ld16_agent(p.ao_tag + (size_t)bw * K + (lane / NB) * 4);
+        const uint4 v = nb_ld16(nbuf, p.ao_tag + (size_t)bw * K + (lane / NB) * 4);
         const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
         if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
         if (pcy_wait_give_up(spins, 1u << 19, p.err, 10u, lane)) break;
@@ -511,10 +612,10 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       uint4 t[2][2];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        if (b0 + c < NB) mc_fetch_issue<2>(p.ao_tag + (size_t)(b0 + c) * K, wave * 512, lane, t[c]);
+        if (b0 + c < NB) nb_fetch_issue<2>(nbuf, p.ao_tag + (size_t)(b0 + c) * K, wave * 512, lane, t[c]);
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        if (b0 + c < NB) mc_fetch_finish<2>(p.ao_tag + (size_t)(b0 + c) * K, wave * 512, lane, tag, ra + (b0 + c) * K, t[c], p.err, 11u);
+        if (b0 + c < NB) nb_fetch_finish<2>(nbuf, p.ao_tag + (size_t)(b0 + c) * K, wave * 512, lane, tag, ra + (b0 + c) * K, t[c], p.err, 11u);
     }
     __syncthreads();
     NB_T(3)
@@ -545,18 +646,18 @@ __device__ __forceinline__ void nb_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       __hip_atomic_store(p.xo_tag + (size_t)wave * d + (r0 & ~31) + lane, line[wave * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     NB_T(4)
   }
-  // the second 16 KB of this wave's gate/up rows while the residual stream is on its way
-  if (wave < 7) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, wg * 7 + wave, 256 * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d});
   __syncthreads();                                     // every wave is done with this phase's LDS
-  nb_mlp_body<NB>(mc, p.xo_tag, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines);
+  // (the second batch of this wave's gate/up rows is requested inside, behind the fetch of the residual stream)
+  nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, true);
 #undef NB_T
 }
 
-template <int DH, int G, int NB>
+template <int DH, int G, int NB, int UB>
 __global__ __launch_bounds__(512) void decode_step_nb_kernel(PcyDecAttnArgs a, PcyAttnBlockArgs p, PcyMlpChainArgs mc, PcyDecodeStepArgs st, int n_attn,
                                                              const unsigned* step_epoch, int vthr_qkv, size_t stage_off, int vthr_gu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned xepoch = *step_epoch;
+  const NbBuf nbuf{__builtin_amdgcn_make_buffer_rsrc((void*)st.tags, 0, 0x7fffffff, 0x00020000), st.tags};
   for (int l = 0; l < st.n_layers; ++l) {
     const PcyLayerWeightsDev lw = st.layers[l];
     p.ln1 = lw.ln1; p.wqkv = lw.wqkv; p.wo = lw.wo;
@@ -564,21 +665,22 @@ __global__ __launch_bounds__(512) void decode_step_nb_kernel(PcyDecAttnArgs a, P
     PcyDecAttnArgs al = a;
     al.kcache = a.kcache + (size_t)l * st.kv_layer_stride; al.vcache = a.vcache + (size_t)l * st.kv_layer_stride;
     al.xflags = a.xflags ? a.xflags + (size_t)l * st.xflags_stride : nullptr;
-    uint32_t* tags = st.tags + (size_t)l * st.tag_stride;   // act [NB][F] | qkv [NB][Nq] | attention output [NB][H dh] | x after o [NB][d]
+    uint32_t* tags = st.tags + (size_t)l * st.tag_stride;   // act [NB][F] | qkv [NB][Nq] | attention output [NB][H dh] | x after o [NB][d] | down partials [d][4][NB] x 8 B
     mc.act_tag = tags; p.qkv_tag = tags + (size_t)NB * NBF; p.ao_tag = p.qkv_tag + (size_t)NB * NBNQ; p.xo_tag = p.ao_tag + (size_t)NB * NBD;
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(p.xo_tag + (size_t)NB * NBD);
     const uint32_t* xin = l > 0 ? st.x_lines + (size_t)(l - 1) * st.x_lines_stride : nullptr;
     uint32_t* xout = l + 1 < st.n_layers ? st.x_lines + (size_t)l * st.x_lines_stride : nullptr;
     if (l > 0) __syncthreads();   // the previous layer's LDS is dead
-    nb_layer_body<DH, G, NB>(al, p, mc, n_attn, xepoch, vthr_qkv, stage_off, vthr_gu, smem, xin, xout,
+    nb_layer_body<DH, G, NB, UB>(nbuf, al, p, mc, part, n_attn, xepoch, vthr_qkv, stage_off, vthr_gu, smem, xin, xout,
                              p.trace ? p.trace + (size_t)l * 256 * 16 : nullptr);
   }
 }
 
 struct NbLaunchCache { size_t configured = 0; int resident = -1; size_t resident_smem = 0; };
-NbLaunchCache g_nb_cache[16][9];   // [device][NB]
+NbLaunchCache g_nb_cache[16][9][2];   // [device][NB][UB - 1]
 
-template <int NB>
-bool launch_nb(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
+template <int NB, int UB>
+bool launch_nb_ub(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
                const unsigned* step_epoch, int n_cu, int xmin) {
   constexpr int DH = 128, G = 4, DS = NbGeom<NB>::DS, SLICES = NbGeom<NB>::SLICES;
   constexpr int n_attn = 64;   // (units beyond SLICES x Hkv x NB idle through the attention phase)
@@ -591,9 +693,9 @@ bool launch_nb(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockAr
   const size_t smem_attn = stage_off + (size_t)(G + 2) * DH * 2, smem_body = (size_t)NB * 16384 + 4096;
   const size_t smem = smem_attn > smem_body ? smem_attn : smem_body;
   if (smem > 160 * 1024 || device < 0 || device >= 16) return false;
-  NbLaunchCache& lc = g_nb_cache[device][NB];
+  NbLaunchCache& lc = g_nb_cache[device][NB][UB - 1];
   if (smem > 65536 && smem > lc.configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_step_nb_kernel<DH, G, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_step_nb_kernel<DH, G, NB, UB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
@@ -601,19 +703,29 @@ bool launch_nb(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockAr
   }
   // every workgroup waits for words the others write: all 256 must be resident at once
   if (lc.resident < 0 || lc.resident_smem != smem) {
-    lc.resident = pcy_all_resident(decode_step_nb_kernel<DH, G, NB>, 512, smem, 256, n_cu) ? 1 : 0;
+    lc.resident = pcy_all_resident(decode_step_nb_kernel<DH, G, NB, UB>, 512, smem, 256, n_cu) ? 1 : 0;
     lc.resident_smem = smem;
   }
   if (!lc.resident) return false;
-  hipLaunchKernelGGL((decode_step_nb_kernel<DH, G, NB>), dim3(256), dim3(512), smem, s, a, p, mc, st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
+  hipLaunchKernelGGL((decode_step_nb_kernel<DH, G, NB, UB>), dim3(256), dim3(512), smem, s, a, p, mc, st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
                      stage_off, pcy_gemv_rms_threads(mc.F));
   return true;
+}
+
+// UB = k-iterations per weight batch of the MLP streams (two batches in flight per wave: 16 or 32 KB); PCY_NB_UB=1|2 overrides (measurement)
+template <int NB>
+bool launch_nb(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
+               const unsigned* step_epoch, int n_cu, int xmin) {
+  const char* e = getenv("PCY_NB_UB");
+  const int ub = e ? atoi(e) : 2;
+  if (ub == 1) return launch_nb_ub<NB, 1>(s, device, a, p, mc, st, step_epoch, n_cu, xmin);
+  return launch_nb_ub<NB, 2>(s, device, a, p, mc, st, step_epoch, n_cu, xmin);
 }
 
 }  // namespace
 
 // Words of tagged hand-over slots per layer / of the residual stream between two layers for an NB-row step
-size_t pcy_decode_nb_tag_words(int NB) { return (size_t)NB * (NBF + NBNQ + NBD + NBD); }
+size_t pcy_decode_nb_tag_words(int NB) { return (size_t)NB * (NBF + NBNQ + NBD + NBD) + (size_t)NBD * 4 * NB * 2; }
 size_t pcy_decode_nb_line_words(int NB) { return (size_t)256 * (((size_t)NB * 16 + 31) / 32 * 32); }
 int pcy_decode_nb_ds(int B) { return B <= 1 ? 16 : B == 2 ? 32 : B <= 4 ? 64 : 128; }
 

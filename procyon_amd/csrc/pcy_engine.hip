@@ -439,6 +439,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       w.next_rms_w = (const bf16_t*)(l + 1 < m->n_layers ? m->layers[l + 1].ln1 : m->final_norm);
       w.next_xn = xn; w.fused_next = &xn_ready; w.rms_eps = m->rms_eps; w.rms_cast = m->rms_cast;
     }
+    if (nb_on && pcy_launch_gemv_kwin4(s, w)) continue;   // (the four-way K split of the small-batch step's down projection)
     pcy_launch_gemv(s, w);
   }
   if (layers_only) return;

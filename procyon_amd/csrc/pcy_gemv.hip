@@ -1042,6 +1042,29 @@ __global__ __launch_bounds__(MC_NT, 2) void mlp_chain_kernel(PcyMlpChainArgs a, 
   if (tr && tid == 0) tr[4] = wall_clock64();
 }
 
+// Launch-per-stage twin of the small-batch decode step's down projection (pcy_decode_nb.hip): K is walked as four interleaved sets of
+// 512-element blocks {g + 4 j}, each set accumulated per lane in j order and reduced over the wave, the four partial sums added in g order:
+//   y = bf16( bf16(((p0 + p1) + p2) + p3) + resid ).   One wave per output row; not a fast kernel.
+__global__ __launch_bounds__(256) void gemv_kwin4_kernel(PcyGemvArgs a) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.N) return;
+  const int nj = a.K / 2048;
+  for (int b = 0; b < a.B; ++b) {
+    float p[4];
+    for (int g = 0; g < 4; ++g) {
+      float acc = 0.f;
+      for (int j = 0; j < nj; ++j) {
+        const int k = ((g + 4 * j) * 64 + lane) * 8;
+        acc = dot8(ldg_nt(a.W + (size_t)row * a.K + k), ldg16(a.x + (size_t)b * a.ldx + k), acc);
+      }
+      p[g] = wave_sum(acc);
+    }
+    float v = rbf(((p[0] + p[1]) + p[2]) + p[3]);
+    if (a.resid) v = rbf(v + bf2f(a.resid[(size_t)b * a.ldy + row]));
+    if (lane == 0) a.y[(size_t)b * a.ldy + row] = f2bf(v);
+  }
+}
+
 }  // namespace
 
 bool pcy_launch_splitk_finish_norm(hipStream_t s, const float* ws, int splits, int rows, int N, const bf16_t* resid, bf16_t* y,
@@ -1080,6 +1103,12 @@ bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
 // Smallest batch that takes the MFMA GEMVs (weights once per 16 / 32 rows) instead of the streaming kernel (x rows in LDS, one
 // dot product per row and lane): decode step at T = 128, batch 2 / 3 / 4: 3.49 / 3.99 / 4.42 ms streaming, 4.01 / 4.01 / 4.02 MFMA
 int pcy_mfma_min_batch() { return 4; }
+
+bool pcy_launch_gemv_kwin4(hipStream_t s, const PcyGemvArgs& a) {
+  if (a.K % 2048 || a.bias || a.rms_w || (a.epi != EPI_RESID && a.epi != EPI_STORE)) return false;
+  hipLaunchKernelGGL(gemv_kwin4_kernel, dim3((a.N + 3) / 4), dim3(256), 0, s, a);
+  return true;
+}
 
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   PcyGemvArgs a0 = a00;

@@ -29,6 +29,9 @@ struct PcyGemvArgs {
   int force_stream;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
+// y = bf16(bf16(sum of four interleaved K-block partial sums) [+ resid]): the down projection of the small-batch decode step's launch-per-stage
+// twin (pcy_decode_nb.hip); K % 2048 == 0, no bias / norm; false = not covered
+bool pcy_launch_gemv_kwin4(hipStream_t s, const PcyGemvArgs& a);
 
 // Launches whose workgroups wait for each other INSIDE the launch need every workgroup resident at once: true when the occupancy
 // query says `grid` workgroups of `block` threads with `smem` bytes of dynamic LDS fit on `n_cu` compute units at the same time

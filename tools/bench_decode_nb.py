@@ -90,8 +90,8 @@ def timing():
                 tr = buf[n // 2:].reshape(128, 256, 16)[:32].astype(np.int64)
                 lay = tr[5]
                 t0 = lay[:, 0].min()
-                names = {0: "start", 1: "qkv stored / q,k,v staged", 2: "attention done / ao seen", 3: "ao in LDS", 4: "o stored", 8: "xo in LDS",
-                         9: "gate/up done", 10: "window 0 in LDS", 11: "down half", 12: "end"}
+                names = {0: "start", 13: "x in LDS", 14: "RMSNorm done", 15: "qkv rows computed", 1: "qkv stored / q,k,v staged", 2: "attention done / ao seen", 3: "ao in LDS", 4: "o stored", 8: "xo in LDS",
+                         9: "gate/up done", 5: "down rows requested", 6: "window 0 tags ok (wave 0)", 10: "window 0 in LDS", 11: "down rows done", 12: "end (rows published)"}
                 for grp, sl in (("attn wgs", slice(0, 64)), ("proj wgs", slice(64, 192)), ("qkv-only wgs", slice(192, 256))):
                     print(f"  -- {grp}")
                     for i, nm in names.items():
