@@ -205,8 +205,9 @@ __device__ __forceinline__ void nb_fetch_vectors(const NbBuf& nbuf, const uint32
 
 // The residual stream between two layers: workgroup g of the producing layer owns words [g * XS, g * XS + 16 NB) of `src`, element
 // 16 g + i of row b at word g * XS + 16 b + i (a line has one writer for even NB).  -> dst [NB][4096] bf16.  Ends with a barrier.
-template <int NB>
-__device__ __forceinline__ void nb_fetch_lines(const NbBuf& nbuf, const uint32_t* src, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+template <int NB, typename AfterIssue>
+__device__ __forceinline__ void nb_fetch_lines(const NbBuf& nbuf, const uint32_t* src, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code,
+                                               AfterIssue after_issue) {
   constexpr int XS = NbGeom<NB>::XS;
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   auto word_of = [&](int g, int b, int piece) __attribute__((always_inline)) { return g * XS + b * 16 + piece * 4; };
@@ -236,6 +237,7 @@ __device__ __forceinline__ void nb_fetch_lines(const NbBuf& nbuf, const uint32_t
             t[c][j] = nb_ld16(nbuf, src + word_of(wave * 32 + j * 16 + (lane >> 2), b0 + c, lane & 3));
             ok = ok && (t[c][j].x >> 16) == tag && (t[c][j].y >> 16) == tag && (t[c][j].z >> 16) == tag && (t[c][j].w >> 16) == tag;
           }
+      if (b0 + 4 >= NB && spins == 0) after_issue();   // (weight rows go out BEHIND the last hand-over loads: a CU's loads return in order)
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
       __builtin_amdgcn_s_sleep(8);
@@ -386,13 +388,22 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   // ---- down ----
   // (one piece of code for all eight waves: requests inside the branch above and in an else-branch for wave 7 met in 32 four-register
   // copies and the allocator spilled both batches)
+  // Wave j takes block kg + 4 j of act, all rows.  A block of the first half of act (its units were finished half way through gate/up) is
+  // requested in FRONT of the weight rows (a CU's loads return in order); a block of the second half BEHIND them: it is complete only when the
+  // slowest workgroup has finished gate/up, a request that finds a stale word costs a second trip through the loaded queue (~10 us), and
+  // behind 32 KB of weights the request is served ~10 us later anyway (window in LDS 23 -> ? us after the end of gate/up at 4 rows).
   uint4 tq[NB][2];
-  if (wave < 7) {   // wave j: block kg + 4 j of act, all rows -- in front of the weight rows (a CU's loads return in order)
+  const bool late_block = kg + 4 * wave >= 14;
+  if (wave < 7 && !late_block) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
   }
   issue_down(0, wa);
   issue_down(1, wb);
+  if (wave < 7 && late_block) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
+  }
   NB_T(5)
   if (wave < 7) {
 #pragma unroll
@@ -543,14 +554,19 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
   const int r0 = gwo * 4;
   const bool active = r0 < d;                  // workgroup-uniform (d % 32 == 0)
   {
-    uint4 w[32];   // qkv rows [r0, r0 + 4): all 32 KB of this wave requested in front of the wait for x
+    uint4 w[32];   // qkv rows [r0, r0 + 4): 16 KB of this wave requested in front of the wait for x, 16 KB behind the loads that fetch it
+    auto load_rows = [&](int i0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = i0; i < i0 + 2; ++i)
 #pragma unroll
-      for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(r0 + i) * d + (it * 64 + lane) * 8);
+        for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(r0 + i) * d + (it * 64 + lane) * 8);
+    };
+    load_rows(0);
     if (x_in_lines) {
-      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u);
+      // (all 32 KB in front: B = 4 / 8 at 3.41 / 4.18 ms per step; all behind: 3.36 / 4.11; half and half: 3.32 / 4.16)
+      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u, [&]() __attribute__((always_inline)) { load_rows(2); });
     } else {
+      load_rows(2);
 #pragma unroll
       for (int b = 0; b < NB; ++b) *reinterpret_cast<uint4*>(rb + b * d + tid * 8) = ldg16(p.x + (size_t)b * d + tid * 8);
       __syncthreads();
