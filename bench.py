@@ -200,10 +200,13 @@ def main():
     esm_eng = model.protein_seq_encoder.engine
     for _ in range(3):
         esm_eng.forward(prot)
-    ctx.timer_start()
+    # one call per timed region: replays of ONE captured launch chain queued back to back wait for each other on the host side (10 ms per call
+    # in some runs against 4.5 ms of kernels, tools/t_esm_graph_count.py) -- the generation loop issues one call per protein, never a queue
+    enc_ms = 0.0
     for _ in range(5):
+        ctx.timer_start()
         esm_eng.forward(prot)
-    enc_ms = ctx.timer_stop() / 5
+        enc_ms += ctx.timer_stop() / 5
     S_ = a.residues + 2
     enc_flop = (2 * 648806400 * S_ + 168960 * S_ * S_) if a.geometry == "full" else None
     phases.update(encode_kernels_ms=enc_ms)
@@ -315,6 +318,7 @@ def main():
     # chunks in rank order, one final all-gather of the token ids / probabilities) -- the 1 -> 8 GPU scaling curve of configs[3].
     configs = None
     batched_roofline = None
+    decode_curve = None
     if not a.no_configs and a.geometry == "full":
         from procyon_amd import workloads as WL
         model.text_encoder.max_new_tokens = 512
@@ -323,6 +327,11 @@ def main():
         configs = {"config3_4a_batch32_mixed_residues_T512": WL.run_config4(model, new_tokens=512, ragged=False),
                    "config3_4b_batch32_ragged_prompts": WL.run_config4(model, new_tokens=512, ragged=True),
                    "config4_pair_scoring_256": WL.run_config5(model, pairs=256, chunk=64, fp8=True)}
+        if not dist:
+            # per-batch decode curve (beam search = batch beam_size; the N-GPU points of configs[3] run 32 / N rows per GPU) and the 1 -> 8 GPU
+            # curve of configs[3] projected from single-GPU runs of every rank's chunk (replicas, no traffic inside the loop)
+            decode_curve = WL.decode_batch_curve(model)
+            configs["config3_projected_scaling"] = WL.config3_projected_scaling(model, new_tokens=512, single_gpu=configs["config3_4a_batch32_mixed_residues_T512"])
         if not dist:
             # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like
             # regime instead of the chaotic random-init one), LAST because it rewrites the decoder's weights in place
@@ -342,6 +351,8 @@ def main():
                "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
         if configs is not None:
             out["configs"] = configs
+        if decode_curve is not None:
+            out["batched_decode_curve"] = decode_curve
         if batched_roofline is not None:
             out["batched_decode_roofline"] = batched_roofline
         if not a.no_cpu_baseline and a.geometry == "full" and world == 1:   # reported at N = 1 only

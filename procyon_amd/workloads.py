@@ -117,9 +117,54 @@ def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
     t_mean = prompt + 8 + n / 2.0
     kv_bytes = rows * t_mean * (2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2)
     gbps = (w_bytes + kv_bytes) / 1e9 / (ms / 1e3)
-    return {"bound": "hbm", "kernel": "batched decode step (hipGraph: per layer qkv / attention (+ qkv finish) / o / finish+norm / gate-up / down / finish+norm launches, lm_head, pick)",
+    kernel = ("small-batch decode step (hipGraph: embed, decode_step_nb_kernel = all layers in one launch, lm_head, pick)" if 2 <= rows <= 8 else
+              "batched decode step (hipGraph: per layer qkv / attention (+ qkv finish) / o / finish+norm / gate-up / down / finish+norm launches, lm_head, pick)")
+    return {"bound": "hbm", "kernel": kernel,
             "rows": rows, "mean_cache_len": round(t_mean, 1), "ms_per_step": round(ms, 4), "tokens_per_s_decode_only": round(rows * 1e3 / ms, 1),
             "bytes_per_step": int(w_bytes + kv_bytes), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
+
+
+def decode_batch_curve(model, rows_list=(2, 4, 5, 8, 16, 32), prompt=696, new_tokens=144):
+    """ms per decode step and fraction of the HBM peak for each batch size at a mean cache length of ~768 keys (beam search runs at
+    batch = beam_size, /root/reference/procyon/model/model_unified.py:751-832; the N-GPU points of configs[3] at 32 / N rows per GPU)."""
+    out = []
+    for rows in rows_list:
+        r = batched_decode_roofline(model, rows=rows, prompt=prompt, new_tokens=new_tokens)
+        out.append({k: r[k] for k in ("rows", "mean_cache_len", "ms_per_step", "tokens_per_s_decode_only", "achieved", "frac", "kernel")})
+    return out
+
+
+def config3_projected_scaling(model, new_tokens=512, rows=32, ranks=(2, 4, 8), single_gpu=None):
+    """The 1 -> 8 GPU curve of configs[3] from ONE GPU: generation shards as replicas (the rows split across the
+    ranks, no traffic inside the loop, one final gather of <= 64 KB of token ids), so the N-GPU time is the time of the slowest rank's
+    rows/N rows.  Every rank's chunk (`distributed.shard_indices`, the chunks the N-rank job would hand out) is generated here in turn
+    and the slowest taken; tokens/s(N) = rows x new_tokens / that time.  `single_gpu`: the measured N = 1 result (run_config4)."""
+    from .distributed import shard_indices
+
+    def gen(idx):
+        make, _, _ = config4_inputs(False, rows, subset=idx)
+        toks, *_ = model.generate(make(), max_len=new_tokens, method="greedy")
+        return toks
+
+    pts = []
+    if single_gpu is not None:
+        pts.append({"gpus": 1, "rows_per_gpu": rows, "seconds": single_gpu["seconds"], "tokens_per_s": single_gpu["tokens_per_s"], "measured": "this GPU, all rows"})
+    for n in ranks:
+        worst = 0.0
+        gen(shard_indices(rows, 0, n))       # warm-up of the shape (pinned logits record, graph capture)
+        for r in range(n):
+            _sync()
+            t0 = time.perf_counter()
+            gen(shard_indices(rows, r, n))
+            _sync()
+            worst = max(worst, time.perf_counter() - t0)
+        pts.append({"gpus": n, "rows_per_gpu": rows // n, "seconds": round(worst, 3), "tokens_per_s": round(rows * new_tokens / worst, 1),
+                    "measured": f"slowest of the {n} rank chunks, each run on this GPU"})
+    base = pts[0]["tokens_per_s"]
+    for p in pts:
+        p["speedup_vs_first_point"] = round(p["tokens_per_s"] / base, 2)
+    return {"what": "projected from single-GPU runs of every rank's chunk (no N > 1 hardware run): replicas with no traffic inside the loop; "
+                    "the final gather of the token ids (<= 64 KB) is not included", "new_tokens": new_tokens, "points": pts}
 
 
 def config5_inputs(pairs=256, chunk=64, seed=7):

@@ -1,0 +1,146 @@
+"""Round 5: the small-batch decode step (procyon_amd/csrc/pcy_decode_nb.hip) -- every decoder layer of a decode step for 2..8 rows in ONE
+launch (beam search runs at batch = beam_size: /root/reference/procyon/model/model_unified.py:751-832, :887; the N-GPU points of
+BASELINE configs[3] run 32 / N rows per GPU)."""
+import pytest
+import torch
+
+from conftest import pcy_disable
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+KW = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    from procyon_amd import synth
+    from procyon_amd.engine import LlamaConfig, LlamaEngine
+    return LlamaEngine(synth.llama_state_dict(**KW), LlamaConfig(**KW, max_pos=2048))
+
+
+def _dispatches():
+    from procyon_amd import _lib as L
+    return L
+
+
+@pytest.mark.parametrize("B,T,N,xmin", [(2, 300, 9, 0), (3, 100, 7, 0), (4, 300, 9, 0), (5, 64, 7, 0), (6, 40, 5, 0), (7, 90, 5, 0), (8, 300, 7, 0),
+                                        (4, 800, 6, 0), (2, 1100, 5, 0), (4, 420, 6, 384), (2, 500, 6, 384)])
+def test_decode_nb_step_bit_identical(eng2, monkeypatch, B, T, N, xmin):
+    """decode_step_nb_kernel (all layers of a B-row step in one launch: NB dot products per weight row, tagged hand-overs, four-way K split
+    of the down projection with {tag, fp32} partial sums) against its launch-per-stage twin (PCY_DISABLE=decode_nb_step: gemv_stream_kernel
+    + attn_dec_kernel with the same column slices + gemv_kwin4_kernel): logits of every step, tokens and the appended K / V rows must be
+    BIT-identical, eager and under hipGraph replay (the second replayed run starts at the tag / flag state the first one left); T = 800 /
+    1100 and PCY_AO_XMIN = 384 put the attention's key split + score exchange on (2 / 4 column slices); no watchdog (Context.sync raises)."""
+    from procyon_amd.engine import Context, GenState
+    if xmin:
+        monkeypatch.setenv("PCY_AO_XMIN", str(xmin))
+    torch.manual_seed(B * 1000 + T)
+    emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(step, use_graph):
+        pcy_disable(monkeypatch, "" if step else "decode_nb_step")
+        cache = eng2.new_cache(B, T + N + 2)
+        st = GenState(B, KW["vocab"], N + 2, "cuda")
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng2.pick(cache, st, B, advance_pos=False)
+        out = []
+        for i in range(N):
+            if i % 3 == 2:
+                continue
+            eng2.greedy_steps(cache, st, B, 2 if i % 3 == 1 else 1, use_graph=use_graph)
+            out.append(st.logits.clone())
+        Context.get().sync()
+        return torch.stack(out).cpu(), st.tokens_out[:, :N + 1].cpu(), st.logprob.cpu().clone(), cache.k[:, :, :, T:T + N].cpu(), cache.v[:, :, :, T:T + N].cpu()
+
+    ref = run(False, False)
+    assert torch.isfinite(ref[0].float()).all()
+    for use_graph in (False, True, True):
+        got = run(True, use_graph)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), (B, T, use_graph)
+
+
+def test_decode_nb_rows_are_independent(eng2, monkeypatch):
+    """A row's logits in a 4-row step do not depend on its batch mates (every row has its own accumulators, hand-over vectors and cache
+    rows): four different prompts decoded together == the same four decoded as (row, three copies of another row)."""
+    from procyon_amd.engine import Context, GenState
+    pcy_disable(monkeypatch)
+    torch.manual_seed(11)
+    T, N = 200, 5
+    emb = (torch.randn(4, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(e):
+        cache = eng2.new_cache(4, T + N + 2)
+        st = GenState(4, KW["vocab"], N + 2, "cuda")
+        logits, _ = eng2.prefill(e, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng2.pick(cache, st, 4, advance_pos=False)
+        out = []
+        for _ in range(N):
+            eng2.greedy_steps(cache, st, 4, 1)
+            out.append(st.logits.clone())
+        Context.get().sync()
+        return torch.stack(out).cpu()
+
+    a = run(emb)
+    b = run(torch.stack([emb[2], emb[0], emb[0], emb[0]]).contiguous())
+    assert torch.equal(a[:, 2], b[:, 0]) and torch.equal(a[:, 0], b[:, 1]) and torch.equal(b[:, 1], b[:, 2])
+
+
+def test_decode_nb_beam_loop_bit_identical(eng2, monkeypatch):
+    """The reference's production path: diverse beam search, beam 5 (scripts/caption_bulk.py:123-132) = a 5-row decode step + pcy_beam_step
+    + the K/V reorder of every step.  One launch per step vs the launch-per-stage twin: tokens, running scores and the parent chain equal."""
+    from procyon_amd.engine import BeamState, Context, GenState
+    torch.manual_seed(5)
+    T, steps, beam = 120, 14, 5
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda().repeat(beam, 1, 1).contiguous()
+
+    def run(step):
+        pcy_disable(monkeypatch, "" if step else "decode_nb_step")
+        cache = eng2.new_cache(beam, T + steps + 2)
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        bs = BeamState(1, beam, steps, 2, prompt_len=T, device="cuda")
+        st = GenState(beam, KW["vocab"], 1, "cuda")
+        st.pos, st.next_tok = bs.pos, bs.next_tok
+        st.c.pos, st.c.next_tok = bs.pos.data_ptr(), bs.next_tok.data_ptr()
+        lg = logits.contiguous()
+        for i in range(steps):
+            if i > 0:
+                eng2.decode_graph(cache, st, beam)
+                lg = st.logits
+            eng2.beam_step(lg, bs, 5, 0.8)
+            eng2.kv_reorder(cache, bs.src, T + i)
+        out, n = bs.tokens()
+        Context.get().sync()
+        return out.cpu(), bs.cur.cpu().clone(), bs.anc[:n].cpu().clone()
+
+    ref, got = run(False), run(True)
+    for x, y in zip(got, ref):
+        assert torch.equal(x, y)
+
+
+def test_decode_nb_switch_restores_round4_path(eng2, monkeypatch):
+    """PCY_DISABLE=decode_nb: batches of 2..8 rows take the pre-round-5 launches (MFMA GEMVs from 4 rows on); a different arithmetic (other
+    accumulation orders), so the logits agree to bf16 noise, not bit for bit -- and switching back and forth inside one process keeps every
+    path's own results (per-batch-size tag slots and counters)."""
+    from procyon_amd.engine import Context, GenState
+    torch.manual_seed(3)
+    B, T, N = 4, 150, 4
+    emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(*off):
+        pcy_disable(monkeypatch, *off)
+        cache = eng2.new_cache(B, T + N + 2)
+        st = GenState(B, KW["vocab"], N + 2, "cuda")
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng2.pick(cache, st, B, advance_pos=False)
+        eng2.greedy_steps(cache, st, B, N)
+        Context.get().sync()
+        return st.logits.cpu().clone()
+
+    new1, old, new2 = run(), run("decode_nb"), run()
+    assert torch.equal(new1, new2)
+    err = float((new1.float() - old.float()).norm() / old.float().norm())
+    assert err < 2e-2, err
