@@ -893,6 +893,20 @@ int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, voi
 
 static int esm_encode_enqueue(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                               const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out);
+// FNV-1a over EVERY model pointer and constant a captured pcy_esm_encode chain bakes in (the CONTENTS of the host layer array, not its address:
+// a freed engine's descriptor array and device blocks can come back at the same addresses with other weights behind them)
+static uint64_t esm_weights_fingerprint(const pcy_esm_desc* m) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+  mix((uint64_t)(uintptr_t)m->layers); mix((uint64_t)(uintptr_t)m->final_ln_w); mix((uint64_t)(uintptr_t)m->final_ln_b);
+  mix((uint64_t)(uintptr_t)m->rope_cos); mix((uint64_t)(uintptr_t)m->rope_sin);
+  uint32_t eps; memcpy(&eps, &m->ln_eps, 4); mix(eps); mix((uint64_t)(uint32_t)m->vocab);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(&m->layers[l]);
+    for (size_t i = 0; i < sizeof(pcy_esm_layer); ++i) mix(p[i]);
+  }
+  return h;
+}
 // tokens at or below which pcy_esm_encode replays a captured launch chain (PCY_DISABLE=esm_graph: always launch by launch; read per call)
 static int esm_graph_max_tokens() {
   return pcy_off("esm_graph") ? 0 : 4200;
@@ -906,7 +920,7 @@ int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, con
   // switches that select kernels (read per launch from the environment: a changed switch is another key)
   auto envh = [](const char* n) { const char* e = getenv(n); uint64_t h = 1469598103934665603ull; for (; e && *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ull; return h; };
   uint64_t key[16] = {(uint64_t)(uintptr_t)tokens, (uint64_t)(uintptr_t)pos, (uint64_t)(uintptr_t)cu, (uint64_t)(uintptr_t)vt_cu,
-                      (uint64_t)(uintptr_t)hidden_out, (uint64_t)(uintptr_t)m->layers, (uint64_t)(uintptr_t)m->embed,
+                      (uint64_t)(uintptr_t)hidden_out, esm_weights_fingerprint(m), (uint64_t)(uintptr_t)m->embed,
                       ((uint64_t)(uint32_t)ntok << 32) | (uint32_t)nseq, ((uint64_t)(uint32_t)max_len << 32) | (uint32_t)vt_total,
                       ((uint64_t)(uint32_t)m->d << 32) | (uint32_t)m->ffn, ((uint64_t)(uint32_t)m->n_layers << 32) | (uint32_t)m->n_heads,
                       (uint64_t)mask_pads | ((uint64_t)m->rope_mode << 8), 0 /* workspace base, below */,

@@ -18,11 +18,6 @@ def eng2():
     return LlamaEngine(synth.llama_state_dict(**KW), LlamaConfig(**KW, max_pos=2048))
 
 
-def _dispatches():
-    from procyon_amd import _lib as L
-    return L
-
-
 @pytest.mark.parametrize("B,T,N,xmin", [(2, 300, 9, 0), (3, 100, 7, 0), (4, 300, 9, 0), (5, 64, 7, 0), (6, 40, 5, 0), (7, 90, 5, 0), (8, 300, 7, 0),
                                         (4, 800, 6, 0), (2, 1100, 5, 0), (4, 420, 6, 384), (2, 500, 6, 384)])
 def test_decode_nb_step_bit_identical(eng2, monkeypatch, B, T, N, xmin):
@@ -144,3 +139,31 @@ def test_decode_nb_switch_restores_round4_path(eng2, monkeypatch):
     assert torch.equal(new1, new2)
     err = float((new1.float() - old.float()).norm() / old.float().norm())
     assert err < 2e-2, err
+
+
+def test_esm_replayed_chain_is_keyed_on_the_weights(monkeypatch):
+    """pcy_esm_encode replays a captured launch chain for short inputs; the chain bakes in every weight pointer.  Two engines of the same
+    geometry with DIFFERENT weights built one after the other in one process (the second may get the freed addresses of the first's
+    descriptor array and device blocks): each must reproduce its own launch-by-launch result (PCY_DISABLE=esm_graph) on a shape the other
+    has already captured."""
+    import gc
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig, EsmEngine
+    kw = dict(d=640, n_layers=3, n_heads=20, ffn=2560)
+    toks = synth.protein_tokens([200], seed=4)
+    outs = []
+    for seed in (1, 2, 1):
+        sd = synth.esm_state_dict(**kw)
+        if seed == 2:                            # other weights behind (possibly) the same addresses
+            sd = {k: (v * 1.25).to(v.dtype) if v.dim() == 2 else v for k, v in sd.items()}
+        eng = EsmEngine(sd, EsmConfig(**kw))
+        pcy_disable(monkeypatch, "esm_graph")
+        ref = eng.forward(toks).cpu()
+        pcy_disable(monkeypatch)
+        for _ in range(4):                      # first sight, capture, replays
+            got = eng.forward(toks).cpu()
+            assert torch.equal(got, ref), seed
+        outs.append(ref)
+        del eng
+        gc.collect(); torch.cuda.empty_cache()
+    assert not torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
