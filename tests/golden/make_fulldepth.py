@@ -22,7 +22,7 @@ Round 4: the same runs on DAMPED weights (`synth.damp_residual_branches`, residu
 f3_llama8b_damped_T64.npz, f4_esm650m_damped_1024.npz -- where the bf16 oracle agrees with the fp32 truth on (nearly) every argmax, so the
 GPU test can assert token agreement between the HIP path and the bf16 ORACLE itself and a bound on err(HIP, oracle_bf16).
 
-    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped]
+    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256]
 """
 from __future__ import annotations
 
@@ -68,10 +68,11 @@ def rel(a, b):
 
 
 @torch.no_grad()
-def llama_run(sd, geom, ids, dtype, forced=None):
+def llama_run(sd, geom, ids, dtype, forced=None, ndec=None):
     """prefill + NDEC cached steps through the oracle's own layer_forward, weights cast per layer to `dtype`
     (bf16: no-op).  forced: tokens to feed (teacher forcing) or None = greedy on this run's own logits.
     Returns logits [NDEC+1, V], final-normed hidden rows [NDEC+1, d], tokens [NDEC+1]."""
+    NDEC = globals()["NDEC"] if ndec is None else ndec
     c = lambda t: t.to(dtype)
     emb_w = sd["model.embed_tokens.weight"]
     T = ids.shape[1]
@@ -102,6 +103,38 @@ def llama_run(sd, geom, ids, dtype, forced=None):
 
 
 @torch.no_grad()
+def llama_run_rows(sd, geom, ids, mask, dtype, ndec, forced=None):
+    """B left-padded rows through the reference's own call pattern: prefill with the attention mask and
+    positions arange(T) for EVERY row whatever its padding (pmc_llama.py:546-588), then cached steps with attention_mask = None -- every
+    cached slot, left pads included, is attended -- at position = cache length (model_unified.py:769, :887).  Weights cast per layer to
+    `dtype`.  -> logits [ndec+1, B, V], tokens [ndec+1, B]."""
+    c = lambda t: t.to(dtype)
+    emb_w = sd["model.embed_tokens.weight"]
+    B = ids.shape[0]
+    past = [None] * geom.n_layers
+    logits_all, toks = [], []
+    x_ids = ids
+    for step in range(ndec + 1):
+        h = c(F.embedding(x_ids, emb_w))
+        _, Tq, _ = h.shape
+        t_past = 0 if past[0] is None else past[0][0].shape[2]
+        cos_t, sin_t = LR.rope_tables(geom, dtype, t_past + Tq)
+        cos = cos_t[t_past:t_past + Tq][None].expand(B, Tq, -1)
+        sin = sin_t[t_past:t_past + Tq][None].expand(B, Tq, -1)
+        add_mask = LR.build_additive_mask(mask if step == 0 else None, B, Tq, t_past, dtype)
+        for i in range(geom.n_layers):
+            lw = {k: c(v) for k, v in LR._layer_weights(sd, i).items()}
+            h, past[i] = LR.layer_forward(h, lw, geom, cos, sin, add_mask, past[i])
+        h = LR.rms_norm(h[:, -1], c(sd["model.norm.weight"]), geom.rms_eps, geom.rms_cast)
+        lg = F.linear(h, c(sd["lm_head.weight"]))
+        logits_all.append(lg)
+        tok = lg.argmax(-1) if forced is None else forced[step]
+        toks.append(tok)
+        x_ids = tok[:, None]
+        print(f"    {dtype} step {step}: argmax {lg.argmax(-1).tolist()} fed {tok.tolist()}", flush=True)
+    return torch.stack(logits_all), torch.stack(toks)
+
+
 def llama_truth(sd, geom, ids, toks):
     """fp32 truth of the same NDEC+1 positions in ONE causal pass over ids ++ toks[:-1] (teacher forcing makes every input
     known up front; a causal prefill and an incremental decode are the same function, and in fp32 their difference
@@ -121,14 +154,49 @@ def llama_truth(sd, geom, ids, toks):
     return F.linear(h, c(sd["lm_head.weight"])), h
 
 
-def make_llama(damped=False):
+def make_llama_leftpad():
+    """f5: two rows, the second left-padded by 21 of 64 slots, 16 teacher-forced cached steps in the reference's compat mode (Q1 / Q2) at
+    FULL depth: bf16 oracle and the same procedure in fp32 (a single causal pass is not the same function here: the pad slots' K / V rows
+    and the position offset are part of what is checked)."""
+    sd = synth.llama_state_dict(**LLAMA)
+    geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
+    T, ndec, npad = 64, 16, 21
+    g = torch.Generator().manual_seed(5151)
+    ids = torch.randint(0, 128000, (2, T), generator=g)
+    mask = torch.ones(2, T)
+    mask[1, :npad] = 0
+    ids[1, :npad] = 128001            # whatever sits in the pad slots is embedded and cached like any token
+    t0 = time.time()
+    lb, toks = llama_run_rows(sd, geom, ids, mask, torch.bfloat16, ndec)
+    print(f"  leftpad bf16 oracle {time.time() - t0:.0f}s", flush=True)
+    t0 = time.time()
+    lf, _ = llama_run_rows(sd, geom, ids, mask, torch.float32, ndec, forced=toks)
+    print(f"  leftpad fp32 truth {time.time() - t0:.0f}s", flush=True)
+    V = lb.shape[-1]
+    cols = set(range(0, V, 127))
+    for s in range(ndec + 1):
+        for b in range(2):
+            cols |= set(lf[s, b].topk(8).indices.tolist()) | set(lb[s, b].float().topk(8).indices.tolist())
+    cols = torch.tensor(sorted(cols))
+    top_f, top_b = lf.topk(8, dim=-1), lb.float().topk(8, dim=-1)
+    err_full = torch.tensor([[rel(lb[s, b].float(), lf[s, b]) for b in range(2)] for s in range(ndec + 1)])
+    print(f"  leftpad: bf16-vs-fp32 err {err_full.tolist()}\n   argmax agree {(lb.float().argmax(-1) == lf.argmax(-1)).tolist()}")
+    save("f5_llama8b_leftpad_T64", ids=ids.to(torch.int32), mask=mask.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
+         logits_bf16=lb[..., cols], logits_fp32=lf[..., cols], norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
+         top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values, top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
+
+
+def make_llama(damped=False, long=False):
+    global NDEC
+    if long:       # round 5: the headline's generation length (256 tokens) at T = 512 -> f1_llama8b_T512_N256.npz
+        NDEC = 256
     t0 = time.time()
     sd = synth.llama_state_dict(**LLAMA)
     if damped:   # the trained-like regime (synth.damp_residual_branches): fixtures f3_*, on which token agreement is a meaningful rate
         synth.damp_residual_branches(sd, 0.25)
     print(f"llama weights generated in {time.time() - t0:.0f}s", flush=True)
     geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
-    for T in ((64,) if damped else (64, 512)):
+    for T in ((512,) if long else (64,) if damped else (64, 512)):
         g = torch.Generator().manual_seed(4242 + T)
         ids = torch.randint(0, 128000, (1, T), generator=g)
         t0 = time.time()
@@ -149,7 +217,7 @@ def make_llama(damped=False):
         print(f"  T={T}: bf16-vs-fp32 logits err full {err_full.tolist()}\n         cols {err_cols.tolist()}")
         print(f"         argmax agree {(lb.float().argmax(-1) == lf.argmax(-1)).tolist()} "
               f"fp32 top-2 margin {(top_f.values[:, 0] - top_f.values[:, 1]).tolist()}")
-        save(f"f3_llama8b_damped_T{T}" if damped else f"f1_llama8b_T{T}", ids=ids.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
+        save(f"f1_llama8b_T{T}_N{NDEC}" if long else f"f3_llama8b_damped_T{T}" if damped else f"f1_llama8b_T{T}", ids=ids.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
              logits_bf16=lb[:, cols], logits_fp32=lf[:, cols], hidden_bf16=hb[:1], hidden_fp32=hf[:1],
              norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
              top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values,
@@ -192,3 +260,7 @@ if __name__ == "__main__":
         make_esm(damped=True)
     if "llama_damped" in what:
         make_llama(damped=True)
+    if "llama_leftpad" in what:
+        make_llama_leftpad()
+    if "llama256" in what:
+        make_llama(long=True)

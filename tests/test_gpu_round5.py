@@ -167,3 +167,24 @@ def test_esm_replayed_chain_is_keyed_on_the_weights(monkeypatch):
         del eng
         gc.collect(); torch.cuda.empty_cache()
     assert not torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_create_mlp_reference_signature_on_the_engine():
+    """`create_mlp(n_layers, in, out, hidden, dropout)` -> load_state_dict of the reference module's weights (fixture g3, made by the
+    reference's own create_mlp) -> forward on the HIP projector: bf16 and fp32 parameters, 1 and 3 layers."""
+    from conftest import load_golden, rel_err
+    from procyon.model.model_utils import create_mlp
+    g = load_golden("g3_mlp")
+    for nl in (1, 3):
+        for nm, dt in (("bf16", BF), ("f32", torch.float32)):
+            m = create_mlp(nl, 24, 40, hidden_features=32, dropout_rate=0.25)
+            keys = [k for k in m.state_dict()]
+            sd = {}
+            for i in range(nl):
+                sd[keys[0].replace("0.", f"{3 * i}.") if nl > 1 else "0.weight"] = g[f"w_{nl}_{nm}_{i}"]
+                if nl > 1:
+                    sd[f"{3 * i}.bias"] = g[f"b_{nl}_{nm}_{i}"]
+            m.load_state_dict(sd)
+            m = m.to(dt).cuda().eval()
+            y = m(g[f"x_{nl}_{nm}"].to(dt).cuda()).cpu()
+            assert y.dtype == dt and rel_err(y, g[f"y_{nl}_{nm}"].to(dt)) < (2e-3 if dt == BF else 1e-5), (nl, nm)

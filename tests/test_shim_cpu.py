@@ -380,3 +380,25 @@ def test_protein_retrieval_cli_without_inference(tmp_path):
     env.pop("CHECKPOINT_PATH")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "CHECKPOINT_PATH" in r.stderr
+
+
+def test_create_mlp_has_the_reference_signature_and_state_dict_layout():
+    """`create_mlp(n_layers, in_features, out_features, hidden_features, dropout_rate)` (/root/reference/procyon/model/model_utils.py:13-41):
+    the module indices of the reference's Sequential (Linear at 0, 3, 6 with dropout; 0, 2, 4 without; one bias-free Linear for n_layers
+    == 1), so that checkpoint keys load; and NO CPU path behind the forward."""
+    import torch
+    from procyon.model.model_utils import create_mlp
+    m = create_mlp(3, 24, 40, hidden_features=32, dropout_rate=0.25)
+    assert list(m.state_dict()) == ["0.weight", "0.bias", "3.weight", "3.bias", "6.weight", "6.bias"]
+    assert m[0].weight.shape == (32, 24) and m[3].weight.shape == (32, 32) and m[6].weight.shape == (40, 32)
+    assert list(create_mlp(3, 24, 40, 32, None).state_dict()) == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+    one = create_mlp(1, 24, 40)
+    assert list(one.state_dict()) == ["0.weight"] and one[0].bias is None
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert torch.equal(m[3].bias, sd["3.bias"])
+    import pytest as _pt
+    with _pt.raises(RuntimeError):
+        m.eval()(torch.zeros(2, 24))            # CPU input: the product path refuses, it does not fall back
+    with _pt.raises(RuntimeError):
+        m.train()(torch.zeros(2, 24))
