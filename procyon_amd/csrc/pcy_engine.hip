@@ -1176,10 +1176,19 @@ int llama_prefill_impl(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* 
     pcy_launch_rmsnorm(s, lastx, (const bf16_t*)m->final_norm, lastx, n_logit_rows, d, m->rms_eps, m->rms_cast);
     linear(s, lastx, d, (const bf16_t*)m->lm_head, nullptr, nullptr, 0, (bf16_t*)logits_out, m->vocab, n_logit_rows, m->vocab, d, EPI_STORE);
   } else if (n_logit_rows > 0 && logits_out) {
+    // final norm of the selected rows, then lm_head on the MFMA GEMV (32 rows per pass over the matrix) for EVERY row count, one row
+    // included: the same arithmetic per row whatever the number of rows asked for (the fused-norm streaming GEMV it replaces ran 4 rows
+    // per pass: QA / pair scoring with more than 64 rows streamed the 1 GB matrix rows / 4 times -- advisor finding, round 4)
     pcy_launch_copy_rows(s, x, d, lastx, d, logit_rows, n_logit_rows, d);
     PcyGemvArgs h{};
-    h.W = (const bf16_t*)m->lm_head; h.x = lastx; h.y = (bf16_t*)logits_out; h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps;
-    h.rms_cast = m->rms_cast; h.N = m->vocab; h.K = d; h.B = n_logit_rows; h.ldx = d; h.ldy = m->vocab; h.epi = EPI_STORE;
+    h.W = (const bf16_t*)m->lm_head; h.x = lastx; h.y = (bf16_t*)logits_out; h.N = m->vocab; h.K = d; h.B = n_logit_rows; h.ldx = d; h.ldy = m->vocab;
+    h.epi = EPI_STORE;
+    if (d % 512 == 0) {
+      pcy_launch_rmsnorm(s, lastx, (const bf16_t*)m->final_norm, lastx, n_logit_rows, d, m->rms_eps, m->rms_cast);
+      h.force_mfma = 1;
+    } else {   // (toy geometries: the streaming kernel with the norm fused)
+      h.rms_w = (const bf16_t*)m->final_norm; h.rms_eps = m->rms_eps; h.rms_cast = m->rms_cast;
+    }
     pcy_launch_gemv(s, h);
   }
   return check_launch("pcy_llama_prefill");

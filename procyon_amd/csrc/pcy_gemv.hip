@@ -1115,7 +1115,7 @@ void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   a0.plain_loads = 0;
   // batches from pcy_mfma_min_batch() on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused
   // RMSNorm prologue is a feature of the streaming kernel)
-  if (!a0.force_stream && a0.B >= pcy_mfma_min_batch() && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
+  if (!a0.force_stream && (a0.B >= pcy_mfma_min_batch() || a0.force_mfma) && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
     for (int b0 = 0; b0 < a0.B; b0 += 32) {
       PcyGemvArgs a = a0;
       a.B = (a0.B - b0) < 32 ? (a0.B - b0) : 32;

@@ -27,6 +27,9 @@ struct PcyGemvArgs {
   // 1: the streaming kernel (one dot product per row and lane, rows in groups of <= 4) whatever the batch -- the launch-per-stage twin of the
   // small-batch decode step (pcy_decode_nb.hip) is built from it
   int force_stream;
+  // 1: the MFMA kernel (x already normalised, rms_w == NULL) whatever the batch, one row included -- the prefill's lm_head, so that a row's
+  // logits are the same bits for every number of rows asked for AND 32 rows share a pass over the 1 GB matrix
+  int force_mfma;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 // y = bf16(bf16(sum of four interleaved K-block partial sums) [+ resid]): the down projection of the small-batch decode step's launch-per-stage

@@ -338,10 +338,13 @@ class UnifiedProCyon:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, inputs, return_mlm=False, retrieval=False, get_full_labels=False, aaseq_type='protein',
-                exclude_protein_structure=False, crop_off=False, output_attentions=False):
+                exclude_protein_structure=False, crop_off=False, output_attentions=False, full_logits=False):
         """`forward` (model_unified.py:483-581), inference branches.  QA: logits only at the position the QA readers
         use (last [ANSWER] index, data/inference_utils.py:582-604) -> outputs.logits [B,1,V] and
-        out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D]."""
+        out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D].
+        full_logits=True (opt-in, not in the reference's signature): outputs.logits [B, T_real, V] for EVERY position like the
+        reference's `outputs.logits` (:548-554; the reference pads every row to max_text_len and materialises [B, 2048, V] -- the
+        trailing all-pad columns are not computed here), for callers that index `logits[:, pos]` themselves."""
         if return_mlm:
             raise NotImplementedError("return_mlm is a training path (model_unified.py:505-509)")
         self._require_bf16_or_fp32("forward")
@@ -370,7 +373,7 @@ class UnifiedProCyon:
         sum_all = retrieval and self.config.ret_token_access == 'all'
         ret_rows = ret_idx[:, :real].reshape(-1).nonzero()[:, 0] if sum_all else None   # flat b*T + t, row-major like boolean indexing
         outputs = self.text_encoder(input_embeds=emb, attn_masks=attn_masks[:, :real], full_labels=full_labels,
-                                    logit_positions=answer_pos if not retrieval else torch.zeros(B, dtype=torch.long),
+                                    logit_positions=None if full_logits else (answer_pos if not retrieval else torch.zeros(B, dtype=torch.long)),
                                     want_hidden=retrieval and not sum_all, hidden_sum_positions=ret_rows, lazy_hidden=True)
         out = {'outputs': outputs, 'text_toks': input_ids, 'full_labels': full_labels if get_full_labels else None,
                'contrastive_out': None, 'contrastive_loss': None, 'answer_positions': answer_pos}

@@ -157,6 +157,15 @@ def test_forward_retrieval_and_qa(env):
     assert torch.equal(out["answer_positions"], PR.get_after_answer_tokens(ids, m.answer_idx) - 1)
     assert torch.allclose(probs[:, m.yes_token].float(), yes_ref.float(), rtol=0.05, atol=1e-6)
     assert torch.allclose(probs[:, m.no_token].float(), no_ref.float(), rtol=0.05, atol=1e-6)
+    # full_logits=True (opt-in): every position, as the reference's outputs.logits (model_unified.py:548-554) up to the last real column;
+    # the row a QA reader would index itself equals the answer-row-only result
+    full = m.forward(_inputs(m, env["prot"], instr, [[0, 1], [1]], text_slots=[[], []]), retrieval=False, full_logits=True)
+    fl = full["outputs"].logits
+    assert fl.shape[:2] == (2, real) and fl.shape[2] == out["outputs"].logits.shape[2]
+    picked = fl[torch.arange(2), out["answer_positions"].to(fl.device)]
+    assert rel_err(picked.cpu(), out["outputs"].logits[:, 0].cpu()) < 2e-2
+    valid = mask[:, :real].bool()
+    assert rel_err(fl.cpu()[valid], r["logits"][valid]) < 2e-2
 
 
 def test_sampling_probability_vector_and_nucleus_mask(env):
