@@ -311,6 +311,12 @@ int pcy_f32_attention(pcy_ctx*, const float* q, int ldq, int qcol0, const float*
                       float* o, int ldo, const int32_t* cu, const uint8_t* keep, int nseq, int max_len, int H, int Hkv, int dh, int causal,
                       float scale);
 
+/* fp32 decode attention (callers that never call .bfloat16() and generate: /root/reference/scripts/caption_bulk.py:70-73, 123-132): the new
+ * token's q [B, H*dh] (roped) against slots [0, nkeys) of token-major caches [B][Tmax][Hkv*dh] (row stride ldkv floats); every slot is
+ * attended (/root/reference/procyon/model/model_unified.py:769, :887 pass no mask after the prefill). */
+int pcy_f32_attn_decode(pcy_ctx*, const float* q, int ldq, const float* kcache, const float* vcache, int ldkv, int Tmax, float* o, int ldo, int B,
+                        int H, int Hkv, int dh, int nkeys, float scale);
+
 #ifdef __cplusplus
 }
 #endif

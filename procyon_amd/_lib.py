@@ -101,6 +101,7 @@ SIGNATURES = {
     "pcy_f32_acc_rows": (ci, [vp, vp, ci, vp, vp, ci, ci]),
     "pcy_f32_pool": (ci, [vp, vp, ci, vp, vp, ci, ci, vp]),
     "pcy_f32_attention": (ci, [vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, C.c_float]),
+    "pcy_f32_attn_decode": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, ci, ci, ci, ci, ci, C.c_float]),
     "pcy_quant_rows_fp8": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "pcy_gemm_fp8": (ci, [vp, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_mlp_forward": (ci, [vp, C.POINTER(MlpDesc), vp, ci, vp]),

@@ -294,6 +294,49 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
   }
 }
 
+// Decode attention in fp32: one wave per (head h, row b); the new token's query against the first `nkeys` slots of the row's cache
+// (token-major [B][Tmax][Hkv dh]; every slot is attended: the reference passes no mask after the prefill, model_unified.py:769, :887).
+__global__ __launch_bounds__(64) void attn_dec_f32_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                          int ldkv, int Tmax, float* __restrict__ o, int ldo, int H, int Hkv, int dh, int nkeys,
+                                                          float scale) {
+  extern __shared__ float smem_f[];
+  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  float* qs = smem_f;            // [dh]
+  float* sc = smem_f + dh;       // [nkeys]
+  const int hk = h / (H / Hkv);
+  const float* qrow = q + (size_t)b * ldq + h * dh;
+  for (int e = lane; e < dh; e += 64) qs[e] = qrow[e];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const float* kb = kc + (size_t)b * Tmax * ldkv + hk * dh;
+  const float* vb = vc + (size_t)b * Tmax * ldkv + hk * dh;
+  float mx = -INFINITY;
+  for (int j = lane; j < nkeys; j += 64) {
+    const float* kr = kb + (size_t)j * ldkv;
+    float a = 0.f;
+    for (int e = 0; e < dh; e += 4) {
+      const float4 kv = *reinterpret_cast<const float4*>(kr + e);
+      a = fmaf(qs[e], kv.x, a); a = fmaf(qs[e + 1], kv.y, a); a = fmaf(qs[e + 2], kv.z, a); a = fmaf(qs[e + 3], kv.w, a);
+    }
+    const float s_ = a * scale;
+    sc[j] = s_;
+    mx = fmaxf(mx, s_);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nkeys; j += 64) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  float* orow = o + (size_t)b * ldo + h * dh;
+  for (int e = lane; e < dh; e += 64) {
+    float a = 0.f;
+    for (int j = 0; j < nkeys; ++j) a = fmaf(sc[j] * inv, vb[(size_t)j * ldkv + e], a);
+    orow[e] = a;
+  }
+}
+
 int launch_ok(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { pcy_set_error("kernel launch failed in %s: %s", what, hipGetErrorString(e)); return 3; }
@@ -374,6 +417,19 @@ int pcy_f32_attention(pcy_ctx* c, const float* q, int ldq, int qcol0, const floa
                        cu, keep, H, Hkv, dh, causal, scale);
   }
   return launch_ok("pcy_f32_attention");
+}
+
+int pcy_f32_attn_decode(pcy_ctx* c, const float* q, int ldq, const float* kcache, const float* vcache, int ldkv, int Tmax, float* o, int ldo, int B,
+                        int H, int Hkv, int dh, int nkeys, float scale) {
+  if (dh % 4 || H % Hkv || ldkv % 4) { pcy_set_error("pcy_f32_attn_decode: head_dim %% 4, Hkv | H and 16-byte aligned cache rows required"); return 1; }
+  if (nkeys < 1 || nkeys > Tmax) { pcy_set_error("pcy_f32_attn_decode: %d keys outside the cache (%d slots)", nkeys, Tmax); return 1; }
+  const size_t smem = (size_t)(dh + nkeys) * sizeof(float);
+  if (smem > 160 * 1024 - 1024) { pcy_set_error("pcy_f32_attn_decode: %d keys exceed the LDS score buffer", nkeys); return 1; }
+  if (B > 0) {
+    if (smem > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_dec_f32_kernel, dim3(H, B), dim3(64), smem, pcy_ctx_stream(c), q, ldq, kcache, vcache, ldkv, Tmax, o, ldo, H, Hkv, dh, nkeys, scale);
+  }
+  return launch_ok("pcy_f32_attn_decode");
 }
 
 }  // extern "C"

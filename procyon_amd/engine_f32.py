@@ -74,6 +74,15 @@ class F32Ops:
                                            _p(cu), _p(keep), nseq, max_len, H, Hkv, dh, int(causal), scale), "pcy_f32_attention")
         return o
 
+    def attn_decode(self, q, kcache, vcache, nkeys, H, Hkv, dh, scale):
+        """q [B, H*dh] (a view with row stride q.stride(0) is fine) against slots [0, nkeys) of token-major caches [B, Tmax, Hkv*dh]"""
+        _chk(kcache, vcache)
+        B = q.shape[0]
+        o = torch.empty(B, H * dh, dtype=F32, device=q.device)
+        L.check(self.lib.pcy_f32_attn_decode(self.h, _p(q), q.stride(0), _p(kcache), _p(vcache), kcache.shape[2], kcache.shape[1], _p(o), H * dh, B,
+                                             H, Hkv, dh, nkeys, scale), "pcy_f32_attn_decode")
+        return o
+
     def embed(self, table, ids, soft=None, soft_map=None):
         _chk(table, soft)
         out = torch.empty(ids.numel(), table.shape[1], dtype=F32, device=table.device)
@@ -188,8 +197,25 @@ class EsmEngineF32:
         return out
 
 
+class KVCacheF32:
+    """token-major fp32 K (roped) / V caches [L, B, Tmax, Hkv*dh]"""
+
+    def __init__(self, cfg: LlamaConfig, B, Tmax, device):
+        kw = cfg.n_kv_heads * cfg.head_dim
+        self.k = torch.zeros(cfg.n_layers, B, Tmax, kw, dtype=F32, device=device)
+        self.v = torch.zeros(cfg.n_layers, B, Tmax, kw, dtype=F32, device=device)
+        self.B, self.Tmax = B, Tmax
+
+    def reorder_(self, src_rows):
+        """row b takes the cache of row src_rows[b] (beam search, model_unified.py:830-832)"""
+        idx = src_rows.to(self.k.device).long()
+        self.k = self.k.index_select(1, idx).contiguous()
+        self.v = self.v.index_select(1, idx).contiguous()
+
+
 class LlamaEngineF32:
-    """Llama decoder PREFILL in fp32 (HF layout state dict): embedding + splice, L layers, final norm, logits at chosen rows."""
+    """Llama decoder in fp32 (HF layout state dict): embedding + splice, L layers, final norm, logits at chosen rows; with a cache also
+    the KV-cached decode step (one launch per operator: a compatibility path for callers that generate without .bfloat16(), not a fast one)."""
 
     def __init__(self, sd, cfg: LlamaConfig, device=None, ctx=None):
         self.ops = F32Ops(ctx, device)
@@ -217,7 +243,36 @@ class LlamaEngineF32:
             soft = soft.to(self.device, F32).contiguous()
         return self.ops.embed(self.embed, ids_d, soft if soft_map is not None else None, sm).view(B, T, self.cfg.d)
 
-    def prefill(self, embeds, attn_mask=None, logit_rows="last", want_hidden=False, sum_rows=None):
+    def new_cache(self, B, Tmax):
+        return KVCacheF32(self.cfg, B, Tmax, self.device)
+
+    def decode(self, cache: KVCacheF32, ids, t):
+        """one new token per row (ids [B]) at cache length / rotary position t for EVERY row, no mask (reference quirks Q1 / Q2,
+        model_unified.py:769, :887) -> logits [B, V] fp32; appends K / V at slot t"""
+        ops, cfg = self.ops, self.cfg
+        H, Hkv, dh = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
+        B = ids.numel()
+        if t + 1 > cache.Tmax:
+            raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
+        ids_d, = _h2d_many([ids.reshape(-1).to(torch.int32).cpu()], self.device)
+        x = ops.embed(self.embed, ids_d)
+        pos = torch.full((B,), t, dtype=torch.int32, device=self.device)
+        qw, kw = H * dh, Hkv * dh
+        for l, lw in enumerate(self.layers):
+            xn = ops.rmsnorm(x, lw["ln1"], cfg.rms_eps)
+            qkv = ops.linear(xn, lw["wqkv"])
+            ops.rope(qkv, 0, H, dh, pos, self.cos, self.sin)
+            ops.rope(qkv, qw, Hkv, dh, pos, self.cos, self.sin)
+            cache.k[l, :, t] = qkv[:, qw:qw + kw]
+            cache.v[l, :, t] = qkv[:, qw + kw:]
+            ao = ops.attn_decode(qkv, cache.k[l], cache.v[l], t + 1, H, Hkv, dh, dh ** -0.5)
+            x = ops.linear(ao, lw["wo"], resid=x)
+            xn = ops.rmsnorm(x, lw["ln2"], cfg.rms_eps)
+            act = ops.silu_mul(ops.linear(xn, lw["wg"]), ops.linear(xn, lw["wu"]))
+            x = ops.linear(act, lw["wd"], resid=x)
+        return ops.linear(ops.rmsnorm(x, self.final_norm, cfg.rms_eps), self.lm_head)
+
+    def prefill(self, embeds, attn_mask=None, logit_rows="last", want_hidden=False, sum_rows=None, cache=None):
         """embeds [B,T,d] fp32; attn_mask [B,T] 0/1 or None -> (logits [n,V] fp32, final-normed hidden [B,T,d] | None[, sum over the
         L+1 hidden states at `sum_rows` (flat b*T+t) [n,d]]) -- the return contract of `LlamaEngine.prefill`"""
         ops, cfg = self.ops, self.cfg
@@ -236,13 +291,16 @@ class LlamaEngineF32:
         if srows is not None:
             hsum = torch.zeros(srows.numel(), d, dtype=F32, device=self.device)
         qw, kw = H * dh, Hkv * dh
-        for lw in self.layers:
+        for li, lw in enumerate(self.layers):
             if hsum is not None:
                 ops.acc_rows(hsum, x, srows)
             xn = ops.rmsnorm(x, lw["ln1"], cfg.rms_eps)
             qkv = ops.linear(xn, lw["wqkv"])
             ops.rope(qkv, 0, H, dh, pos, self.cos, self.sin)
             ops.rope(qkv, qw, Hkv, dh, pos, self.cos, self.sin)
+            if cache is not None:
+                cache.k[li, :B, :T] = qkv[:, qw:qw + kw].view(B, T, kw)
+                cache.v[li, :B, :T] = qkv[:, qw + kw:].view(B, T, kw)
             ao = ops.attention(qkv, 0, qkv, qw, qkv, qw + kw, cu, keep, B, T, H, Hkv, dh, True, dh ** -0.5)
             x = ops.linear(ao, lw["wo"], resid=x)
             xn = ops.rmsnorm(x, lw["ln2"], cfg.rms_eps)

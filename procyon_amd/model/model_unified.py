@@ -550,6 +550,92 @@ class UnifiedProCyon:
         eng.ctx.sync()      # stream complete + the sticky watchdog word of the fused launches checked (raises PcyError)
         return (out.unflatten(0, (B, beam_size)), cur.unflatten(0, (B, beam_size)), out_logits.unflatten(0, (B, beam_size)))
 
+    # ---- fp32 generation (/root/reference/scripts/caption_bulk.py:70-73 never casts the model and calls generate(method="beam")): the
+    # reference's own loops over the sub-module waist, every operator on the fp32 family (procyon_amd/engine_f32.py) -- a compatibility
+    # path, one launch per operator and a host round trip per step, not a fast one
+    @torch.no_grad()
+    def _generate_sampling_f32(self, input_embeds, attn_masks, max_len=64, num_text_per_instance=1, temperature=1.0, greedy=False,
+                               nucleus_prob=None):
+        """`_generate_sampling` (model_unified.py:861-921) in fp32: prefill, then max_len - 1 cached steps; greedy argmax, or multinomial
+        on softmax(logits / temperature) / the un-renormalised nucleus-masked softmax; chosen log-probabilities summed; no EOS stop."""
+        assert nucleus_prob is None or (0 < nucleus_prob < 1)
+        enc = self.text_encoder
+        B = len(input_embeds)
+        keep_new = enc.max_new_tokens
+        enc.max_new_tokens = max(keep_new, max_len)
+        try:
+            outs, lps, lgs = [], [], []
+            for _ in range(num_text_per_instance):
+                toks, past, rec = None, None, []
+                total = torch.zeros(B, device=self.device)
+                for i in range(max_len):
+                    o = enc(input_embeds=input_embeds, attn_masks=attn_masks, use_cache=True, logit_positions=torch.full((B,), input_embeds.shape[1] - 1)) \
+                        if i == 0 else enc(input_ids=toks[:, -1:], use_cache=True, past_key_values=past)
+                    past = o.past_key_values
+                    logits = o.logits[:, -1, :]
+                    rec.append(logits.cpu())
+                    lsm = logits.log_softmax(-1)
+                    nxt = logits.argmax(-1, keepdim=True) if greedy else torch.multinomial(self._sampling_probs(logits, temperature, nucleus_prob), 1)
+                    total += lsm.gather(1, nxt)[:, 0]
+                    toks = nxt if toks is None else torch.cat([toks, nxt], -1)
+                outs.append(toks.cpu()); lps.append(total.cpu()); lgs.append(torch.stack(rec, 1))
+        finally:
+            enc.max_new_tokens = keep_new
+        return torch.stack(outs, 1), torch.stack(lps).T, torch.stack(lgs, 1)
+
+    @torch.no_grad()
+    def _generate_beam_search_f32(self, input_embeds, attn_mask, max_len=64, beam_size=5, beam_group_size=5, diversity_penalty=0.8):
+        """`_generate_beam_search` (model_unified.py:702-842) in fp32: the prompt repeated beam_size times before the prefill; step 0 extends
+        beam 0 of every group only, later steps the group's g x V candidates; groups after the first lose penalty x (count of the tokens
+        the earlier groups of the same input chose this step) IN the running score; outputs, scores, the logits record and the K / V rows
+        follow the selected parents; stops when every beam holds an EOS."""
+        if beam_size % beam_group_size != 0:
+            raise ValueError(f"beam_group_size must evenly divide beam_size, got: {beam_size} % {beam_group_size} != 0")
+        enc = self.text_encoder
+        dev = self.device
+        B = input_embeds.shape[0]
+        BB, V, T = B * beam_size, enc.cfg.vocab, input_embeds.shape[1]
+        groups = beam_size // beam_group_size
+        emb = torch.repeat_interleave(input_embeds, beam_size, dim=0)
+        mask = torch.repeat_interleave(attn_mask, beam_size, dim=0)
+        cur = torch.zeros(BB, device=dev)
+        out = torch.zeros(BB, max_len, dtype=torch.int64, device=dev)
+        rec = None
+        keep_new = enc.max_new_tokens
+        enc.max_new_tokens = max(keep_new, max_len)
+        try:
+            past = None
+            for i in range(max_len):
+                o = enc(input_embeds=emb, attn_masks=mask, use_cache=True, logit_positions=torch.full((BB,), T - 1)) if i == 0 else \
+                    enc(input_ids=out[:, i - 1:i], use_cache=True, past_key_values=past)
+                past = o.past_key_values
+                logits = o.logits[:, -1, :]
+                step_rec = logits.cpu().unsqueeze(1)
+                rec = step_rec if rec is None else torch.cat([rec, step_rec], 1)
+                lp = logits.log_softmax(-1) + cur[:, None]
+                src = torch.arange(BB, device=dev)
+                for b in range(B):
+                    b0 = b * beam_size
+                    for gi in range(groups):
+                        g0 = b0 + gi * beam_group_size
+                        g1 = g0 + beam_group_size
+                        cand = lp[g0:(g0 + 1 if i == 0 else g1)]
+                        if gi != 0:
+                            cand -= diversity_penalty * torch.bincount(out[b0:g0, i], minlength=V).to(dev)
+                        top_v, top_i = cand.ravel().topk(beam_group_size)
+                        parents = top_i // V + g0
+                        out[g0:g1] = out[parents]
+                        out[torch.arange(g0, g1), i] = top_i % V
+                        cur[g0:g1] = top_v
+                        rec[g0:g1] = rec[parents.cpu()]
+                        src[g0:g1] = src[parents]        # (the K / V rows of every layer follow the parents, :830-832)
+                past.cache.reorder_(src)
+                if bool((out == self.tokenizer.eos_token_id).any(dim=1).all()):
+                    break
+        finally:
+            enc.max_new_tokens = keep_new
+        return (out.cpu().unflatten(0, (B, beam_size)), cur.cpu().unflatten(0, (B, beam_size)), rec.unflatten(0, (B, beam_size)))
+
     @torch.no_grad()
     def generate(self, inputs, max_len=64, aaseq_type='protein', method="sampling", temperature=1.0, greedy=False,
                  num_text_per_instance=1, return_all_internals=False, beam_size=5, beam_group_size=5,
@@ -559,7 +645,7 @@ class UnifiedProCyon:
         means `nucleus_prob` (default 0.9) reaches `_generate_sampling` for every non-beam method, as written there;
         pass nucleus_prob=None for plain temperature sampling."""
         assert method in ["sampling", "temperature", "greedy", "beam", "nucleus"]
-        self._require_bf16("generate")
+        self._require_bf16_or_fp32("generate")      # fp32 (a caller that never called .bfloat16()): the operator-by-operator fp32 loops below
         if method == "beam":
             num_text_per_instance = beam_size
         elif method == "greedy":
@@ -575,11 +661,11 @@ class UnifiedProCyon:
         gt_text = [inputs["data"]["text"][i] for i in inputs["target"]["text"]] if inputs["target"]["text"] is not None else None
         batch_size = input_embeds.shape[0]
         if method == "beam":
-            tokens, log_probs, logits = self._generate_beam_search(
+            tokens, log_probs, logits = (self._generate_beam_search_f32 if self._f32 else self._generate_beam_search)(
                 input_embeds, attn_masks, max_len=max_len, beam_size=beam_size, diversity_penalty=diversity_penalty,
                 beam_group_size=beam_group_size)
         else:
-            tokens, log_probs, logits = self._generate_sampling(
+            tokens, log_probs, logits = (self._generate_sampling_f32 if self._f32 else self._generate_sampling)(
                 input_embeds, attn_masks, max_len=max_len, num_text_per_instance=num_text_per_instance,
                 temperature=temperature, greedy=greedy, nucleus_prob=nucleus_prob)
         flattened = torch.flatten(tokens, start_dim=0, end_dim=1)

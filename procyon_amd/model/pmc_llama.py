@@ -8,6 +8,13 @@ import torch
 from ..engine import GenState, KVCache, LlamaConfig, LlamaEngine
 
 
+class _PastF32:
+    """fp32 KV cache handle of an fp32 generation: `.cache` (engine_f32.KVCacheF32), `.t` keys held"""
+
+    def __init__(self, cache, t):
+        self.cache, self.t = cache, t
+
+
 class _Past:
     """past_key_values: indexable [layer][0|1] -> [B,Hkv,t,dh] VIEWS of the engine cache, so the in-place row
     re-indexing the reference's beam search performs (model_unified.py:830-832) acts on the live cache.  The views are
@@ -113,6 +120,11 @@ class LlamaPostTokenization:
                 use_cache=False, output_attentions=None, logit_positions=None, want_hidden=True, hidden_sum_positions=None,
                 output_hidden_states=False, lazy_hidden=False):
         assert (input_embeds is not None) != (input_ids is not None), "Only one of input_embeds or input_ids can be provided"
+        if isinstance(past_key_values, _PastF32):      # cached decode of an fp32 generation
+            assert input_ids is not None and input_ids.shape[1] == 1, "cached decode takes input_ids [B,1]"
+            cache, t = past_key_values.cache, past_key_values.t
+            logits = self.engine_f32.decode(cache, input_ids.view(-1), t)
+            return SimpleNamespace(logits=logits.view(input_ids.shape[0], 1, -1), past_key_values=_PastF32(cache, t + 1), hidden_states=None, loss=None)
         if input_embeds is not None and input_embeds.dtype == torch.float32:
             return self._forward_f32(input_embeds, attn_masks, past_key_values, use_cache, logit_positions, want_hidden, hidden_sum_positions)
         eng = self.engine
@@ -166,20 +178,22 @@ class LlamaPostTokenization:
                                hidden_states=None, loss=None)
 
     def _forward_f32(self, input_embeds, attn_masks, past_key_values, use_cache, logit_positions, want_hidden, hidden_sum_positions):
-        """fp32 embeddings in -> the fp32 prefill (the callers that never call `.bfloat16()`; one forward pass, no KV cache)"""
-        if past_key_values is not None or use_cache:
-            raise RuntimeError("the fp32 path is a prefill-only path (QA scoring / retrieval); cached decode computes in bf16 only -- "
-                               "call model.bfloat16() for generation")
+        """fp32 embeddings in -> the fp32 prefill (the callers that never call `.bfloat16()`); use_cache=True keeps the K / V rows in an fp32
+        cache for the cached decode steps of an fp32 generation (/root/reference/scripts/caption_bulk.py:70-73, 123-132)"""
+        if past_key_values is not None:
+            raise RuntimeError("a prefill with input_embeds takes no past_key_values")
         eng = self.engine_f32
         B, T, _ = input_embeds.shape
+        cache = eng.new_cache(B, T + self.max_new_tokens) if use_cache else None
         rows = "all" if logit_positions is None else (torch.arange(B) * T + logit_positions.cpu().long())
         hsum = None
         if hidden_sum_positions is not None:
-            logits, hidden, hsum = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True, sum_rows=hidden_sum_positions)
+            logits, hidden, hsum = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True, sum_rows=hidden_sum_positions, cache=cache)
         else:
-            logits, hidden = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True)
+            logits, hidden = eng.prefill(input_embeds, attn_masks, rows, want_hidden=True, cache=cache)
         hs = _HiddenStates(self.cfg.n_layers + 1, hidden, lambda: (_ for _ in ()).throw(
             RuntimeError("the fp32 path keeps the final hidden state only (hidden_states[-1])")))
-        return SimpleNamespace(logits=logits.view(B, -1, self.cfg.vocab), past_key_values=None, hidden_states=hs, hidden_state_sum_rows=hsum, loss=None)
+        return SimpleNamespace(logits=logits.view(B, -1, self.cfg.vocab), past_key_values=_PastF32(cache, T) if use_cache else None,
+                               hidden_states=hs, hidden_state_sum_rows=hsum, loss=None)
 
     __call__ = forward

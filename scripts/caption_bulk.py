@@ -1,9 +1,10 @@
 """Bulk captioning over the MI355X engine: the command line of the reference's scripts/caption_bulk.py (same arguments, same output
 files), batched across proteins (`--batch_size`).  See procyon_amd/pipelines.py.
 
-One permanent difference from the reference script: it generates with the model as loaded (fp32, /root/reference/scripts/caption_bulk.py:72-73);
-KV-cached generation computes in bf16 only on the MI355X engine, so this script casts the model first, as the evaluation framework and the
-retrieval service do (the fp32 operator family covers `forward` -- QA scoring, retrieval -- and `forward_sequences`, not decode)."""
+Like the reference script it generates with the model AS LOADED (fp32 checkpoint -> fp32 arithmetic, /root/reference/scripts/caption_bulk.py:70-73):
+the fp32 operator family with its cached decode step -- a compatibility path, one launch per operator.  `--bf16` casts the model first, as the
+evaluation framework and the retrieval service do (evaluate/framework/procyon.py:64-65): the fused bf16 engine (one launch per decode step),
+~10 x faster."""
 import argparse
 
 import pandas as pd
@@ -18,7 +19,8 @@ def main(args):
     device = torch.device("cuda")
     data_args, model_args, _ = UnifiedProCyon.get_checkpoint_configs(resume_from_checkpoint=args.ckpt)
     model, _ = UnifiedProCyon.from_pretrained(checkpoint_dir=args.ckpt)
-    model.bfloat16()
+    if args.bf16:
+        model.bfloat16()
     model.to(device)
     model.eval()
     set_seed(1234)
@@ -41,5 +43,6 @@ if __name__ == "__main__":
     p.add_argument("--beam_size", default=10, type=int)
     p.add_argument("--max_len", default=200, type=int)
     p.add_argument("--diversity_penalty", default=0.8, type=float)
+    p.add_argument("--bf16", action="store_true", help="cast the model to bfloat16 first (the fused engine; the reference script runs fp32)")
     p.add_argument("--batch_size", default=8, type=int, help="proteins per engine call (the reference script: 1)")
     main(p.parse_args())

@@ -145,7 +145,7 @@ def test_f32_llama_engine_vs_oracle():
 def test_fp32_model_runs_as_the_unchanged_fp32_callers_drive_it():
     """The model exactly as protpep_qa_scores.py:55-58 / qa_filter_captions.py:17-18 use it -- built from an fp32 checkpoint, `.eval()`,
     NO `.bfloat16()` -- answers `forward` (QA yes/no at [ANSWER]; retrieval [PROT] embedding, ret_token_access last / all) and
-    `forward_sequences` in fp32 arithmetic, <= 1e-4 from the oracle pipeline in fp32; `generate` raises (decode is bf16-only); after
+    `forward_sequences` AND `generate` (greedy, diverse beam) in fp32 arithmetic, <= 1e-4 from the oracle pipeline in fp32; after
     `.bfloat16()` the same object runs the bf16 engine and its fp32 copies are gone."""
     from oracle import esm_ref as ER
     from oracle import llama_ref as LR
@@ -200,9 +200,25 @@ def test_fp32_model_runs_as_the_unchanged_fp32_callers_drive_it():
         assert got.dtype == F32 and errs[access] < 1e-4, (access, errs[access])
     m.config.ret_token_access = "last"
     record_parity("fp32/model_small_as_loaded", err_qa_logits=e_qa, err_retrieval_last=errs["last"], err_retrieval_all=errs["all"])
-    # generation is a bf16 path
-    with pytest.raises(RuntimeError, match="bfloat16"):
-        m.generate(mk(["w4 <|protein|> ? [ANSWER]"], prot, [[1]], text_slots=[[]]), max_len=4, method="greedy")
+    # generation in fp32 (/root/reference/scripts/caption_bulk.py:70-73 never casts the model and calls generate(method="beam")): greedy and
+    # diverse beam search on the fp32 operator family against the oracle's loops in fp32 -- same tokens, logits <= 1e-4
+    ginstr = ["w4 <|protein|> w5 [ANSWER]"]
+    gslots = [[1]]
+    gids, gmask = m._prepare_text_inputs_and_tokenize(list(ginstr), [[]], crop_off=True, no_pad=True, left_pad=True)
+    gsoft = PR.mlp_forward(z[[1]], w["projs"]["aaseq"])
+    gemb, _ = PR.prepare_input_embeddings(w["llama"]["model.embed_tokens.weight"], gids.long(), m.prot_replacement_idx, gsoft, ret_idx=m.prot_retrieval_idx)
+    t_ref, lg_ref, _ = LR.greedy_generate(w["llama"], lgeom, gemb, gmask, 6)
+    toks, lp, lg, _ = m.generate(mk(ginstr, prot, gslots, text_slots=[[]]), max_len=6, method="greedy")
+    assert lg.dtype == F32 and torch.equal(toks[:, 0], t_ref), (toks, t_ref)
+    e_gen = rel_err(lg[:, 0].float(), lg_ref)
+    enc = LR.make_text_encoder(w["llama"], lgeom)
+    tb_ref, sb_ref, lb_ref = LR.beam_search(enc, gemb, gmask, vocab_size=lgeom.vocab, eos_id=m.tokenizer.eos_token_id, max_len=5,
+                                            beam_size=4, beam_group_size=2, diversity_penalty=0.8)
+    tb, sb, lb, _ = m.generate(mk(ginstr, prot, gslots, text_slots=[[]]), max_len=5, method="beam", beam_size=4, beam_group_size=2, diversity_penalty=0.8)
+    assert torch.equal(tb, tb_ref) and torch.allclose(sb, sb_ref, atol=1e-3), (tb, tb_ref, sb, sb_ref)
+    e_beam = rel_err(lb.float(), lb_ref)
+    record_parity("fp32/model_small_generate", err_greedy_logits=e_gen, err_beam_logits=e_beam, greedy_tokens_equal=True, beam_tokens_equal=True)
+    assert e_gen < 1e-4 and e_beam < 1e-4, (e_gen, e_beam)
     # .bfloat16(): the bf16 engine takes over, the fp32 copies are dropped
     m.bfloat16()
     assert m.text_encoder._src_f32 is None and m.protein_seq_encoder._src_f32 is None and m.aaseq_shared_projector.src_f32 is None
