@@ -121,9 +121,12 @@ def all_gather_rows(local, n_total, group=None):
     if local.is_cuda and td.get_backend(group) == "nccl":
         return _comm_for(group).all_gather(local)[:n_total]
     world = td.get_world_size(group)
+    dev = local.device
+    if local.is_cuda:          # a host backend (gloo) does not take device tensors: through host memory (advisor finding, round 4)
+        local = local.cpu()
     full = torch.empty(world * local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
     td.all_gather_into_tensor(full, local, group=group)
-    return full[:n_total]
+    return full[:n_total].to(dev)
 
 
 def run_sharded_rows(row_fn, n_rows, rank=None, world=None, group=None):

@@ -147,7 +147,15 @@ class UnifiedProCyon:
     def _f32(self):
         return self.dtype == torch.float32
 
+    def _check_fp32_sources(self):
+        # (advisor finding, round 4: after .bfloat16() the fp32 weights are gone; a later .float() must fail HERE, not inside forward)
+        enc = self.text_encoder
+        if enc is not None and getattr(enc, "_src_f32", None) is None and getattr(enc, "_engine_f32", None) is None:
+            raise RuntimeError("UnifiedProCyon.float(): the fp32 weights of this model were dropped by .bfloat16() (or the checkpoint was bf16); "
+                               "reload the checkpoint to compute in fp32")
+
     def float(self):
+        self._check_fp32_sources()
         self.dtype = torch.float32
         return self
 
@@ -162,6 +170,8 @@ class UnifiedProCyon:
             if isinstance(a, torch.dtype):
                 if not a.is_floating_point:
                     raise TypeError(f"nn.Module.to only accepts floating point dtypes, but got desired dtype={a}")
+                if a == torch.float32 and self.dtype != torch.float32:
+                    self._check_fp32_sources()
                 self.dtype = a
             elif isinstance(a, (str, torch.device, int)) and a is not None:
                 dev = torch.device("cuda", a) if isinstance(a, int) else torch.device(a)

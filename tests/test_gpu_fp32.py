@@ -224,6 +224,5 @@ def test_fp32_model_runs_as_the_unchanged_fp32_callers_drive_it():
     assert m.text_encoder._src_f32 is None and m.protein_seq_encoder._src_f32 is None and m.aaseq_shared_projector.src_f32 is None
     ob = m.forward_sequences(prot)
     assert ob["shared"].dtype == torch.bfloat16 and rel_err(ob["shared"].float().cpu(), ref["shared"]) < 2e-2
-    m.float()
-    with pytest.raises(RuntimeError, match="fp32"):
-        m.forward_sequences(prot)
+    with pytest.raises(RuntimeError, match="fp32"):      # the fp32 weights are gone: .float() says so at once
+        m.float()
