@@ -46,7 +46,12 @@ __device__ __forceinline__ void mc_fetch_finish(const uint32_t* src, int w0, int
 
 // A whole tagged vector of 8 x 512 words -> LDS: one wave watches a 1 KB sample until it is current (a workgroup then asks for
 // 1 KB per round trip instead of 16 KB while it waits), then every wave takes its 512 words.  All 512 threads; ends with a barrier.
-__device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+struct McNoHook { __device__ __forceinline__ void operator()() const {} };
+// after_issue: runs once per wave right behind the loads that fetch the vector (weight prefetches belong THERE: a CU's loads return in
+// order, and a hand-over load queued behind 16-32 KB of weights per wave waits for all of them)
+template <typename AfterIssue = McNoHook>
+__device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code,
+                                                AfterIssue after_issue = AfterIssue()) {
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   if (wave == watch_wave) {
     unsigned spins = 0;
@@ -61,6 +66,7 @@ __device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int 
   __syncthreads();
   uint4 t[2];
   mc_fetch_issue<2>(src, wave * 512, lane, t);
+  after_issue();
   mc_fetch_finish<2>(src, wave * 512, lane, tag, dst, t, err, code);
   __syncthreads();
 }
@@ -68,7 +74,9 @@ __device__ __forceinline__ void mc_fetch_vector(const uint32_t* src, int n, int 
 // The same for a vector stored SPARSELY: producer workgroup b owns the 128-byte line b of `src` and fills its first 16 words
 // (element 16 b + i at word 32 b + i), so that no line has two writers.  n = 16 x (number of producing workgroups) elements,
 // n % 512 == 0 and n <= 4096; dst [n] bf16.
-__device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+template <typename AfterIssue = McNoHook>
+__device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code,
+                                                      AfterIssue after_issue = AfterIssue()) {
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int nlines = n >> 4;
   auto word_of = [&](int line, int piece) __attribute__((always_inline)) { return line * 32 + piece * 4; };
@@ -83,6 +91,7 @@ __device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n
     }
   }
   __syncthreads();
+  if (!(wave * 512 < n)) after_issue();
   if (wave * 512 < n) {   // this wave's 512 elements = 32 lines: two loads of 16 lines x 4 pieces
     uint4 t[2];
     unsigned spins = 0;
@@ -93,6 +102,7 @@ __device__ __forceinline__ void mc_fetch_vector_lines(const uint32_t* src, int n
         t[j] = ld16_agent(src + word_of(wave * 32 + j * 16 + (lane >> 2), lane & 3));
         ok = ok && (t[j].x >> 16) == tag && (t[j].y >> 16) == tag && (t[j].z >> 16) == tag && (t[j].w >> 16) == tag;
       }
+      if (spins == 0) after_issue();
       if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
       if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
       __builtin_amdgcn_s_sleep(8);
