@@ -60,7 +60,7 @@ def cpu_baseline(tokens, residues, prompt):
     from oracle import esm_ref as ER
     from oracle import llama_ref as LR
     from procyon_amd import synth
-    # torch-CPU bf16 is fastest at ~32 threads on the GPU box's EPYC host (tools/cpu_threads_probe.py: 8/32/64/128/256
+    # torch-CPU bf16 is fastest at ~32 threads on the GPU box's EPYC host (tools/archive/cpu_threads_probe.py: 8/32/64/128/256
     # threads -> 11.7/9.4/29.9/35.2/3334 ms per decode layer), so the baseline is not handicapped by oversubscription
     torch.set_num_threads(min(32, os.cpu_count()))
     cores = torch.get_num_threads()
@@ -246,19 +246,27 @@ def main():
     traffic, traffic_source = None, None
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
+    traffic_ratio = None
     try:
-        pname = "r04_pmc_decode_step.json" if all_layers else "r02_pmc_decode_layer.json"
+        pname = next(n for n in (("r05_pmc_decode_step.json", "r04_pmc_decode_step.json") if all_layers else ("r02_pmc_decode_layer.json",))
+                     if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
         if a.geometry == "full" and one_launch:
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pm.items() if "decode_step_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
-            traffic_source = f"profiles/{pname} (rocprofv3 --pmc passes at t = 512..536, FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+            v = [v for k, v in pm.items() if "decode_step_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
+            # the counters were taken at another cache length (t = 512..536) than this run's timed region: the measured / algorithmic
+            # RATIO carries over, the byte count is scaled to this run's launch (review, round 4: not two numbers from different lengths)
+            traffic_ratio = v["hbm_bytes_per_launch"] / v["algorithmic_bytes"]
+            traffic = int(round(traffic_ratio * k_bytes))
+            traffic_source = (f"profiles/{pname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at t = 512..536 (FETCH_SIZE doubled per MI355X_MICROARCH.md) measured "
+                              f"{v['hbm_bytes_per_launch']} B against {v['algorithmic_bytes']} algorithmic; that ratio x this launch's algorithmic bytes")
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": ("decode_step_kernel<128,4> (all 32 Llama decoder layers of a decode step in one launch: per layer qkv, attention, o, gate/up, down)"
                                            if all_layers else "decode_layer_kernel<128,4> (one Llama decoder layer per launch; 32 launches/token)"
                                            if one_launch else "decoder layer as separate launches (average per layer)"),
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_over_algorithmic": None if traffic_ratio is None else round(traffic_ratio, 4),
+                "traffic_source": traffic_source,
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2), "cache_len": t_mid}
 
     # ---- retrieval leg (config 3 shape): DP-sharded forward_sequences + ONE all-gather --------------

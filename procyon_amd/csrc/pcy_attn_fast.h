@@ -99,7 +99,7 @@ __device__ __forceinline__ void fa_softmax_block(f32x16& s, float& m, float& l, 
   }
 }
 
-// ABL != 0: measurement variants with parts of the work removed (wrong results; PCY_FA_ABL, tools/bench_attn_esm.py):
+// ABL != 0: measurement variants with parts of the work removed (wrong results; PCY_FA_ABL, tools/archive/bench_attn_esm.py):
 //   1 no O rescale, 2 no exponentials, 4 no P.V MFMAs, 8 no Q.K^T MFMAs, 16 no Vt fragment reads, 32 no K fragment reads, 64 no DMA
 // VROW: V is read where the qkv projection left it (token-major rows, a.v / a.ldv / a.vcol0) -- no transposed copy.  A V tile lands in
 // LDS as [16 key quads][4 dh blocks][4 keys][16 dh] (128-byte blocks; the LDS-DMA image is lane-linear, so the order is made on the
@@ -386,7 +386,7 @@ inline bool pcy_launch_attn_fast64(hipStream_t s, const PcyAttnArgs& a, bool vt_
     return true;
   }
   if (a.vt_total % 8) return false;
-#ifdef PCY_FA_ABL_BUILD   // measurement variants with parts of the work removed (WRONG results; tools/bench_attn_abl.py builds with it)
+#ifdef PCY_FA_ABL_BUILD   // measurement variants with parts of the work removed (WRONG results; tools/archive/bench_attn_abl.py builds with it)
   const char* e = getenv("PCY_FA_ABL");
   const int abl = e ? atoi(e) : 0;
   switch (abl) {

@@ -1054,7 +1054,7 @@ namespace {
 // PCY_GEMM_PERM=0 (read per call: interleaved A/B in one process): the 256 x 256 kernels with the natural W row order and the
 // 8-byte epilogue of the first rounds; same bits either way
 // PCY_GEMM_PERM = mask of the epilogues that use the permuted order: 1 STORE, 2 RESID, 4 ESM GELU, 8 SwiGLU, 16 the fp8 kernels.
-// Measured in one process, interleaved (tools/ab_esm_env.py, tools/ab_llama_env.py): ESM2-650M encoder at 25 x 1026 tokens 535 -> 553
+// Measured in one process, interleaved (tools/archive/ab_esm_env.py, tools/archive/ab_llama_env.py): ESM2-650M encoder at 25 x 1026 tokens 535 -> 553
 // proteins/s with 1 | 2 | 4 (K = 1280: a tile is 20 k-steps, the epilogue a fifth of it); Llama-3-8B prefill (K = 4096 / 14336) 64 x 450
 // tokens 1048 TFLOP/s with every mask, one 512-token prompt 10.43 -> 10.53 ms with the SwiGLU form (8), fp8 1804 -> 1793 TFLOP/s with
 // 16 -- so the default is 7: the bf16 STORE / RESID / ESM-GELU epilogues.
@@ -1166,7 +1166,7 @@ void launch(hipStream_t s, const PcyGemmArgs& a) {
   }
   // Mid-M (128 <= M < 2048 and the 256 x 256 tiling under-fills the chip: one 1024-residue protein, one 512-token prompt): the GEMM is
   // ONE round of tiles, so the tile shape is chosen for CU fill and the k-loop for latency -- gemm_kernel_mid (pcy_gemm_mid.h), shape
-  // by a cost model fitted on tools/bench_gemm_mid.py (cold weights): rounds(tiles / 256 CUs) x tile area / efficiency, efficiency
+  // by a cost model fitted on tools/archive/bench_gemm_mid.py (cold weights): rounds(tiles / 256 CUs) x tile area / efficiency, efficiency
   // 0.6 / 0.7 / 0.8 / 1.0 for 8 waves of 32 x 32 / 32 x 48 / 32 x 64 / 64 x 64.  Same bits as the kernels below (same k order per element).
   // (128 x 96: N = 6144 at M <= 512 -- the Llama qkv projection of one prompt -- is ONE full round of 256 tiles instead of 192 of 128 x 128:
   // 42.5 -> 38.0 us, prefill of a 512-token prompt 9.67 -> 9.55 ms)

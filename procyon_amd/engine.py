@@ -307,7 +307,7 @@ class _Stager:
     pinned allocation per call: a ring of persistent pinned staging buffers (grown on demand), ONE async copy per call into
     one device buffer, views handed out (a pageable source would make the copy wait for the queued GPU work, and the
     retrieval loop would alternate host packing and GPU encoding instead of overlapping them).  Measured equal to a
-    `pin_memory()` copy per array (tools/t_esm_percall.py: 22.1 ms per call at batch 8, 56.4 ms at batch 25, back to back);
+    `pin_memory()` copy per array (tools/archive/t_esm_percall.py: 22.1 ms per call at batch 8, 56.4 ms at batch 25, back to back);
     it replaces six pinned allocations and copies per call by one."""
     SLOTS = 3
 

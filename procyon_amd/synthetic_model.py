@@ -13,6 +13,10 @@ GEOMETRIES = {
     # ProCyon-Full as BASELINE.json sizes it: ESM2-650M + Llama-3-8B (embedding rows = len(tokenizer) - 1)
     "full": dict(llama=dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336),
                  esm=dict(d=1280, n_layers=33, n_heads=20, ffn=5120), proj_hidden=2560, proj_layers=3),
+    # ProCyon-Split (BASELINE configs[0]; /root/reference/README.md:50-51, procyon/training/training_args_IT.py:129-134): ESM2-150M + Llama-2-7B,
+    # 32000 + 8 added tokens - [EXT]
+    "split": dict(llama=dict(vocab=32007, d=4096, n_layers=32, n_heads=32, n_kv_heads=32, ffn=11008),
+                  esm=dict(d=640, n_layers=30, n_heads=20, ffn=2560), proj_hidden=2560, proj_layers=3),
     # small geometry for tests / smoke (head_dim 64, same code paths)
     "small": dict(llama=dict(vocab=128263 - 128000 + 2048, d=256, n_layers=2, n_heads=4, n_kv_heads=2, ffn=512),
                   esm=dict(d=128, n_layers=2, n_heads=2, ffn=256), proj_hidden=192, proj_layers=3),
@@ -30,7 +34,12 @@ def build(geometry="full", device="cuda", pooling="mean", max_new_tokens=256, ll
     if esm_layers is not None:
         g["esm"]["n_layers"] = esm_layers
     small = geometry == "small"
-    tok = SyntheticTokenizer(n_text=2000, base_vocab=2048 + 0, bos_token_id=2040, eos_token_id=2041) if small else SyntheticTokenizer()
+    if small:
+        tok = SyntheticTokenizer(n_text=2000, base_vocab=2048 + 0, bos_token_id=2040, eos_token_id=2041)
+    elif geometry == "split":
+        tok = SyntheticTokenizer(n_text=30000, base_vocab=32000, bos_token_id=1, eos_token_id=2)     # Llama-2 vocabulary size and bos / eos ids
+    else:
+        tok = SyntheticTokenizer()
     if small:
         g["llama"]["vocab"] = len(tok) - 1
     assert g["llama"]["vocab"] == len(tok) - 1  # model_unified.py:166: [EXT] is never embedded

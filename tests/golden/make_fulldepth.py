@@ -22,7 +22,7 @@ Round 4: the same runs on DAMPED weights (`synth.damp_residual_branches`, residu
 f3_llama8b_damped_T64.npz, f4_esm650m_damped_1024.npz -- where the bf16 oracle agrees with the fp32 truth on (nearly) every argmax, so the
 GPU test can assert token agreement between the HIP path and the bf16 ORACLE itself and a bound on err(HIP, oracle_bf16).
 
-    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256]
+    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256] [split]
 """
 from __future__ import annotations
 
@@ -249,6 +249,46 @@ def make_esm(damped=False):
          **{f"{n}_bf16": a for n, a in zip(names, out["bf16"])}, **{f"{n}_fp32": b for n, b in zip(names, out["fp32"])})
 
 
+SPLIT_LLAMA = dict(vocab=32007, d=4096, n_layers=32, n_heads=32, n_kv_heads=32, ffn=11008)    # Llama-2-7B + 8 added tokens - [EXT] (model_unified.py:166)
+SPLIT_ESM = dict(d=640, n_layers=30, n_heads=20, ffn=2560)                                       # ESM2-150M
+
+
+@torch.no_grad()
+def make_split():
+    """BASELINE configs[0] "full once" (SURVEY.md section 8d, config 1): ProCyon-Split geometry -- ESM2-150M + Llama-2-7B, ALL layers, fp32 --
+    one 256-residue protein (seed 0), a 128-token prompt with one <|protein|> and a trailing [ANSWER], 64 greedy tokens through the oracle:
+    ESM -> mean pool -> 3-layer token projector -> splice -> prefill + 63 cached steps (`_generate_sampling(greedy=True)`).  Fixture f6: pooled
+    embedding, soft token, tokens, per-step logits on a column subset + top-2 of every step."""
+    t0 = time.time()
+    dt = torch.float32
+    esd = synth.esm_state_dict(**SPLIT_ESM, dtype=dt)
+    proj = synth.mlp_layers(3, 640, 4096, 2560, seed_off=0, dtype=dt)
+    toks = synth.protein_tokens([256], seed=0)
+    z = PR.esm_plm_forward(esd, ER.EsmGeom(**SPLIT_ESM), toks)
+    soft = PR.mlp_forward(z, proj)
+    print(f"split: esm + projector {time.time() - t0:.0f}s", flush=True)
+    del esd
+    PROT, ANSWER = 32001, 32003          # <|protein|>, [ANSWER] among the added tokens (ids 32000 .. 32006)
+    ids = synth.prompt_ids(1, 128, 32000, dict(protein=PROT, answer=ANSWER), n_protein=1, seed=0)
+    ids[ids < 3] = 3
+    lsd = synth.llama_state_dict(**SPLIT_LLAMA, dtype=dt)
+    geom = LR.LlamaGeom(**SPLIT_LLAMA, max_pos=4096)
+    emb, _ = PR.prepare_input_embeddings(lsd["model.embed_tokens.weight"], ids, PROT, soft)
+    print(f"split: llama weights {time.time() - t0:.0f}s", flush=True)
+    tok, lg, lp = LR.greedy_generate(lsd, geom, emb, torch.ones(1, 128), 64)
+    print(f"split: 64 greedy tokens {time.time() - t0:.0f}s  tokens {tok[0].tolist()}", flush=True)
+    lg = lg[0]                                            # [64, V]
+    V = lg.shape[1]
+    cols = set(range(0, V, 31))
+    for s_ in range(64):
+        cols |= set(lg[s_].topk(8).indices.tolist())
+    cols = torch.tensor(sorted(cols))
+    top = lg.topk(8, dim=-1)
+    save("f6_split_config0_fp32", protein_tokens=toks.to(torch.int32), prompt_ids=ids.to(torch.int32), pooled=z[0], soft_token=soft[0],
+         tokens=tok[0].to(torch.int32), logprob=lp.float(), cols=cols.to(torch.int32), logits=lg[:, cols], norm=lg.double().norm(dim=-1).float(),
+         top_ids=top.indices.to(torch.int32), top_vals=top.values)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["esm", "llama"]
     torch.set_num_threads(os.cpu_count())
@@ -264,3 +304,5 @@ if __name__ == "__main__":
         make_llama_leftpad()
     if "llama256" in what:
         make_llama(long=True)
+    if "split" in what:
+        make_split()

@@ -188,3 +188,64 @@ def test_create_mlp_reference_signature_on_the_engine():
             m = m.to(dt).cuda().eval()
             y = m(g[f"x_{nl}_{nm}"].to(dt).cuda()).cpu()
             assert y.dtype == dt and rel_err(y, g[f"y_{nl}_{nm}"].to(dt)) < (2e-3 if dt == BF else 1e-5), (nl, nm)
+
+
+def test_split_geometry_config0_full_depth(golden):
+    """BASELINE configs[0] "full once" (SURVEY.md section 8d, config 1): ProCyon-Split geometry -- ESM2-150M (30 layers) + Llama-2-7B (32 layers,
+    32 KV heads, ffn 11008, V = 32007; /root/reference/README.md:50-51, procyon/training/training_args_IT.py:129-134), one 256-residue
+    protein, a 128-token prompt, 64 greedy tokens.  Fixture f6 = the oracle in fp32 (the reference's CPU arithmetic for this config).
+    (a) the fp32 operator family (what a caller that never calls .bfloat16() gets): SAME 64 tokens, every logit <= 1e-4;
+    (b) the bf16 engine on the bf16-rounded weights: pooled / soft token within bf16 noise, tokens equal up to the first step whose top-2
+        margin lies inside 4 x the logit noise (the margin rule), decode on the launch-per-stage path (the fused steps are Llama-3-8B's)."""
+    from conftest import record_parity, rel_err
+    from procyon_amd import synth
+    from procyon_amd.engine import EsmConfig, EsmEngine, LlamaConfig, LlamaEngine, MlpEngine
+    from procyon_amd.engine_f32 import EsmEngineF32, LlamaEngineF32, MlpEngineF32
+    F32 = torch.float32
+    g = golden("f6_split_config0_fp32")
+    LL = dict(vocab=32007, d=4096, n_layers=32, n_heads=32, n_kv_heads=32, ffn=11008)
+    ES = dict(d=640, n_layers=30, n_heads=20, ffn=2560)
+    toks, ids = g["protein_tokens"].long(), g["prompt_ids"].long()
+    T, N = ids.shape[1], g["tokens"].numel()
+    cols = g["cols"].long()
+    PROT = 32001
+    esd = synth.esm_state_dict(**ES, dtype=F32)
+    proj = synth.mlp_layers(3, 640, 4096, 2560, seed_off=0, dtype=F32)
+    lsd = synth.llama_state_dict(**LL, dtype=F32, workers=16)
+    smap = torch.full((ids.numel(),), -1, dtype=torch.int32)
+    smap[(ids == PROT).view(-1)] = 0
+    # ---- (a) fp32 family
+    z = EsmEngineF32(esd, EsmConfig(**ES)).forward(toks)
+    soft = MlpEngineF32(proj)(z)
+    e_pool, e_soft = rel_err(z[0].cpu(), g["pooled"]), rel_err(soft[0].cpu(), g["soft_token"])
+    lm = LlamaEngineF32(lsd, LlamaConfig(**LL, max_pos=4096))
+    cache = lm.new_cache(1, T + N)
+    logits, _ = lm.prefill(lm.embed_tokens(ids, soft, smap), None, "last", cache=cache)
+    out, errs = [], []
+    for s in range(N):
+        errs.append(rel_err(logits[0, cols].cpu(), g["logits"][s]))
+        tok = int(logits[0].argmax())
+        out.append(tok)
+        if s + 1 < N:
+            logits = lm.decode(cache, torch.tensor([tok]), T + s)
+    record_parity("split/config0_fp32_family", err_pooled=e_pool, err_soft_token=e_soft, err_logits_max=max(errs), tokens_equal=out == g["tokens"].tolist())
+    assert e_pool < 1e-4 and e_soft < 1e-4 and max(errs) < 1e-4, (e_pool, e_soft, max(errs))
+    assert out == g["tokens"].tolist()
+    del lm, cache
+    torch.cuda.empty_cache()
+    # ---- (b) bf16 engine
+    bf = lambda sd: {k: v.to(BF) for k, v in sd.items()}
+    zb = EsmEngine(bf(esd), EsmConfig(**ES)).forward(toks)
+    softb = MlpEngine([(w.to(BF).cuda(), b.to(BF).cuda()) for w, b in proj])(zb)
+    eb_pool, eb_soft = rel_err(zb[0].float().cpu(), g["pooled"]), rel_err(softb[0].float().cpu(), g["soft_token"])
+    eng = LlamaEngine(bf(lsd), LlamaConfig(**LL, max_pos=4096), free_source=True)
+    tokb, _, lgb, _ = eng.generate_greedy(eng.embed_tokens(ids, softb, smap), torch.ones(1, T), N, keep_logits=True)
+    tokb, lgb = tokb.cpu().view(-1).tolist(), lgb.cpu().float()[0]
+    first = next((s for s in range(N) if tokb[s] != int(g["tokens"][s])), N)
+    e_first = rel_err(lgb[0, cols], g["logits"][0])
+    record_parity("split/config0_bf16_engine", err_pooled=eb_pool, err_soft_token=eb_soft, err_first_logits=e_first, tokens_equal_until=first, steps=N)
+    assert eb_pool < 2e-2 and eb_soft < 2e-2 and e_first < 0.15, (eb_pool, eb_soft, e_first)
+    if first < N:
+        margin = float(g["top_vals"][first, 0] - g["top_vals"][first, 1])
+        noise = float((lgb[first, cols] - g["logits"][first]).abs().max())
+        assert margin <= 4 * noise, f"bf16 greedy token differs at step {first} outside the noise (margin {margin:.3e}, noise {noise:.3e})"

@@ -7,11 +7,12 @@ from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 kw = dict(vocab=128263, d=4096, n_layers=32, n_heads=32, n_kv_heads=8, ffn=14336)
 eng = LlamaEngine(synth.llama_state_dict(**kw, device="cuda"), LlamaConfig(**kw, max_pos=4096), free_source=True)
 T, N = 512, 32
-emb = (torch.randn(1, T, 4096, device="cuda") * 0.02).bfloat16()
-cache = eng.new_cache(1, T + N)
-st = GenState(1, kw["vocab"], N, "cuda")
+B = int(os.environ.get("ROWS", 1))     # ROWS=4: the small-batch step (decode_step_nb_kernel)
+emb = (torch.randn(B, T, 4096, device="cuda") * 0.02).bfloat16()
+cache = eng.new_cache(B, T + N)
+st = GenState(B, kw["vocab"], N, "cuda")
 logits, _ = eng.prefill(emb, None, cache, "last")
 st.logits.copy_(logits); st.pos.fill_(T)
-eng.pick(cache, st, 1, advance_pos=False)
-eng.greedy_steps(cache, st, 1, 24, use_graph=False)
+eng.pick(cache, st, B, advance_pos=False)
+eng.greedy_steps(cache, st, B, 24, use_graph=False)
 Context.get().sync()
