@@ -350,10 +350,11 @@ def main():
             configs["config4_fp8_accuracy_damped_model"]["residual_branch_scale"] = 0.25
 
     if rank == 0:
-        out = {"metric": "phenotype-gen tokens/sec (ProCyon-Full greedy generation, end to end)", "value": round(value, 2),
+        out = {"metric": f"phenotype-gen tokens/sec ({'ProCyon-Split' if a.geometry == 'split' else 'ProCyon-Full'} greedy generation, end to end)", "value": round(value, 2),
                "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"configs[1]: ProCyon-Full (ESM2-650M + Llama-3-8B geometry={a.geometry}) bf16 batch=1, "
+               "config": {"workload": (f"configs[1]: ProCyon-Full (ESM2-650M + Llama-3-8B geometry={a.geometry}) bf16 batch=1, " if a.geometry != "split" else
+                                       "configs[0] shape on the GPU: ProCyon-Split (ESM2-150M + Llama-2-7B geometry) bf16 batch=1, ") +
                                       f"{a.residues}-residue protein, {a.prompt}-token prompt, {a.tokens}-token greedy generation",
                           "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
                "phases": {k: round(v, 3) for k, v in phases.items()}, "roofline": roofline, "retrieval": retrieval}
