@@ -277,12 +277,14 @@ def main():
     rb = model.protein_seq_encoder.engine.preferred_batch(plen + 2)
     tok_fn = lambda idx: synth.protein_tokens([plen] * len(idx), seed=1000 + (idx[0] if len(idx) else 0))
     embed_sharded(model, tok_fn, rb * world, batch_size=rb)   # untimed: workspace growth, first-launch effects
-    rt = None
-    for _ in range(2):   # two passes, the faster one is reported (a shared box now and then loses a third of a pass: 40 -> 55 ms per batch)
-        barrier(); t0 = time.perf_counter()
-        allz = embed_sharded(model, tok_fn, nprot, batch_size=rb)
-        barrier(); dt_r = time.perf_counter() - t0
-        rt = dt_r if rt is None else min(rt, dt_r)
+    # ONE timed pass (review, round 4: no best-of-2); a second, untimed-for-the-record pass is reported beside it so that a box that lost part
+    # of the first one shows (`second_pass_proteins_per_s`)
+    barrier(); t0 = time.perf_counter()
+    allz = embed_sharded(model, tok_fn, nprot, batch_size=rb)
+    barrier(); rt = time.perf_counter() - t0
+    barrier(); t0 = time.perf_counter()
+    embed_sharded(model, tok_fn, nprot, batch_size=rb)
+    barrier(); rt2 = time.perf_counter() - t0
     assert allz.shape[0] == nprot
     # the same leg with the exact-rounding two-pass attention (PCY_ESM_ATTN=exact: the reference's bf16 rounding points op for op;
     # the default is the single-pass kernel, held to the fp32 evaluation instead -- DESIGN.md section 4)
@@ -290,11 +292,9 @@ def main():
     if os.environ.get("PCY_ESM_ATTN", "fast")[0] != "e":
         os.environ["PCY_ESM_ATTN"] = "exact"
         embed_sharded(model, tok_fn, rb * world, batch_size=rb)
-        for _ in range(2):
-            barrier(); t0 = time.perf_counter()
-            embed_sharded(model, tok_fn, nprot, batch_size=rb)
-            barrier(); dt_r = time.perf_counter() - t0
-            rt_exact = dt_r if rt_exact is None else min(rt_exact, dt_r)
+        barrier(); t0 = time.perf_counter()
+        embed_sharded(model, tok_fn, nprot, batch_size=rb)
+        barrier(); rt_exact = time.perf_counter() - t0
         os.environ["PCY_ESM_ATTN"] = "fast"
     # the gathered [N_total, D] matrix against single-rank embeddings of a sample of its rows (first / middle / last protein:
     # the last one lives on the last rank): a protein's embedding does not depend on its batch mates, so the rows must be EQUAL
@@ -313,7 +313,7 @@ def main():
     for _ in range(4):
         esm_eng.forward(btoks)
     enc_b_ms = ctx.timer_stop() / 4
-    retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": rb, "timing": "best of 2 passes",
+    retrieval = {"proteins_per_s": round(nprot / rt, 2), "n_proteins": nprot, "residues": plen, "batch": rb, "timing": "single pass", "second_pass_proteins_per_s": round(nprot / rt2, 2),
                  "mfma_frac_of_2500TF": round(nprot / rt * (2 * 648806400 * (plen + 2) + 168960 * (plen + 2) ** 2) / 2.5e15, 4) if a.geometry == "full" else None,
                  "encoder_ms_per_batch": round(enc_b_ms, 3), "encoder_proteins_per_s": round(rb / enc_b_ms * 1e3, 1),
                  "encoder_mfma_frac_of_2500TF": round(rb / enc_b_ms * 1e3 * (2 * 648806400 * (plen + 2) + 168960 * (plen + 2) ** 2) / 2.5e15, 4) if a.geometry == "full" else None,
