@@ -5,6 +5,13 @@
 #include "pcy_common.h"
 #include "pcy_internal.h"
 
+#ifndef PCY_ATTN_DEC_NP
+#define PCY_ATTN_DEC_NP(DS) ((DS) == 16 ? 4 : 2)
+#endif
+#ifndef PCY_ATTN_DEC_VPF
+#define PCY_ATTN_DEC_VPF 0
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -180,7 +187,7 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
     };
     // the key tiles of the first NP passes (NP x 256 keys) are all requested up front: each pass that fetched its own
     // tiles paid a full memory round trip inside the dependent chain rope -> scores -> softmax -> P.V
-    constexpr int NP = DS == 16 ? 4 : 2;
+    constexpr int NP = PCY_ATTN_DEC_NP(DS);
     bf16x8 kt[NP][2][KB];
     auto load_group = [&](int j0) {
 #pragma unroll
@@ -340,6 +347,9 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  // (PCY_ATTN_DEC_VPF: the V rows of pass p + 1 are requested before pass p is consumed -- one workgroup per CU (the fused decode steps)
+  // otherwise pays a memory round trip per pass of 256 / 512 keys; same rows, same order of the sums)
+  uint4 vnx[UV];
   for (int j0 = 0; j0 < nk; j0 += UV * NGV) {
     uint4 vv[UV];
 #pragma unroll
@@ -349,9 +359,18 @@ __device__ __forceinline__ void attn_dec_body(const PcyDecAttnArgs& a, char* sme
         if (grp + u * NGV == t) vv[u] = *reinterpret_cast<const uint4*>(vnew);
         continue;
       }
+      if (PCY_ATTN_DEC_VPF) { vv[u] = vnx[u]; continue; }
       const int j = j0 + grp + u * NGV;
       const bf16_t* src = (j < t) ? vsl + (size_t)j * DH : vnew;   // slot t comes straight from the projection
       vv[u] = *reinterpret_cast<const uint4*>(src);
+    }
+    if (PCY_ATTN_DEC_VPF && j0 + UV * NGV < nk) {
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int j = j0 + UV * NGV + grp + u * NGV;
+        const bf16_t* src = (j < t) ? vsl + (size_t)j * DH : vnew;
+        vnx[u] = *reinterpret_cast<const uint4*>(src);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UV; ++u) {

@@ -22,6 +22,11 @@
 #include "pcy_internal.h"
 #include "pcy_handover.h"
 #include "pcy_mlp_chain.h"
+// one workgroup per CU here: the attention body requests the key tiles of four passes up front and the V rows of pass p + 1 before pass p is
+// consumed (stand-alone launches with several workgroups per CU measured no gain from either; same rows, same order of the sums: same bits).
+// 3 / 4 rows: 3.135 / 3.343 -> 3.086 / 3.272 ms per step
+#define PCY_ATTN_DEC_VPF 1
+#define PCY_ATTN_DEC_NP(DS) 4
 #include "pcy_attn_dec.h"
 
 namespace {

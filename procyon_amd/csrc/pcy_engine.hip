@@ -205,6 +205,12 @@ bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
   return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
          c->n_cu >= 256 && m->n_layers <= 128;
 }
+// ... for the small-batch step: the exchange costs more there than the K reads it saves until much longer caches (t ~ 800: 2 / 4 rows
+// 2.935 / 3.385 ms per step with the split, 2.868 / 3.287 without; t ~ 1540: 3.158 / 3.653 with, 3.180 / 3.632 without)
+int decode_xmin_nb(int B) {
+  const char* xe = getenv("PCY_AO_XMIN");
+  return xe ? atoi(xe) : (B == 2 ? 1536 : 4096);
+}
 int decode_xmin() {   // cached keys from which the decode attention splits its keys across the slice workgroups (read per call: tests compare)
   const char* xe = getenv("PCY_AO_XMIN");
   return xe ? atoi(xe) : 768;
@@ -350,7 +356,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
       if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
       bp.trace = g_mc_trace + (size_t)128 * 256 * 16;
     }
-    step_done = pcy_launch_decode_step_nb(s, c->device, t, bp, mc, sa, c->n_cu, c->ao_sync, B, decode_xmin());
+    step_done = pcy_launch_decode_step_nb(s, c->device, t, bp, mc, sa, c->n_cu, c->ao_sync, B, decode_xmin_nb(B));
   }
   if (try_layer && decode_step_enabled() && c->dev_layers) {   // all layers in one launch
     PcyDecAttnArgs t{};
