@@ -34,8 +34,9 @@ namespace {
 constexpr int NBD = 4096, NBF = 14336, NBWIN = NBF / 4, NBNQ = 6144;
 
 template <int NB> struct NbGeom {
-  static constexpr int DS = NB <= 1 ? 16 : NB == 2 ? 32 : NB <= 4 ? 64 : 128;
+  static constexpr int DS = NB <= 1 ? 16 : NB == 2 ? 32 : 64;
   static constexpr int SLICES = 128 / DS;
+  static constexpr int UNITS = SLICES * 8 * NB;   // attention units (row, kv head, column slice): <= 64 on the attention workgroups, the rest on the qkv-only ones
   static constexpr int XS = ((NB * 16 + 31) / 32) * 32;   // words of one workgroup's share of the residual stream between two layers
   static constexpr int P2 = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
 };
@@ -182,6 +183,8 @@ template <int NB, typename AfterIssue>
 __device__ __forceinline__ void nb_fetch_vectors(const NbBuf& nbuf, const uint32_t* src, size_t sstride, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code,
                                                  AfterIssue after_issue) {
   const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  // watch_wave < 0: no watching wave -- the caller knows the vector is about to be complete (the workgroups that have just stored their own part
+  // of it), and a watch poll would only add a round trip in front of the fetch
   if (wave == watch_wave) {
     unsigned spins = 0;
     for (;;) {
@@ -310,7 +313,7 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #define NB_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
   // prime_second (workgroup-uniform): the second gate/up batch of the wave's first unit is requested here, behind the loads that fetch x
-  nb_fetch_vectors<NB>(nbuf, xo_tag, d, 7, tag, rb, a.err, 13u, [&]() __attribute__((always_inline)) {
+  nb_fetch_vectors<NB>(nbuf, xo_tag, d, (prime_second && NB <= 3) ? -1 : 7, tag, rb, a.err, 13u, [&]() __attribute__((always_inline)) {
     if (prime_second && wave < 7) nb_prime_gate_up<UB>(a, lane, wg * 7 + wave, wa, wb, 2);
   });
   NB_T(8)
@@ -499,7 +502,7 @@ template <int DH, int G, int NB, int UB>
 __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, unsigned long long* part, int n_attn,
                                               unsigned xepoch, int vthr_qkv, size_t stage_off, int vthr_gu, char* smem, const uint32_t* x_in_lines,
                                               uint32_t* x_out_lines, unsigned long long* tr_base) {
-  constexpr int DS = NbGeom<NB>::DS, SLICES = NbGeom<NB>::SLICES, P2 = NbGeom<NB>::P2;
+  constexpr int DS = NbGeom<NB>::DS, SLICES = NbGeom<NB>::SLICES, P2 = NbGeom<NB>::P2, UNITS = NbGeom<NB>::UNITS;
   constexpr int d = NBD, K = NBD;
   const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t tag = *p.epoch & 0xffffu;
@@ -507,48 +510,8 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
 #define NB_T(i) if (tr && tid == 0) tr[i] = wall_clock64();
   NB_T(0)
   const int wg = (int)blockIdx.x;
-  if (wg < n_attn) {
-    // ---- attention of one (row, kv head, column slice); units beyond SLICES x Hkv x NB (NB = 3, 5, 6, 7) have none ----
-    uint4 wa[8 * UB], wb[8 * UB];
-    const int unit = wg;
-    const int kvh = unit % a.Hkv, bx = (unit / a.Hkv) % SLICES, b = unit / (a.Hkv * SLICES);   // kv head in the low digits: the slices of a head share an XCD's L2
-    if (b < NB) {
-      bf16_t* stage = reinterpret_cast<bf16_t*>(smem + stage_off);   // [G + 2][DH]
-      a.xepoch = xepoch;
-      a.xerr = p.err;
-      if constexpr (SLICES == 1) a.xflags = nullptr;   // one workgroup per (row, kv head): no key split, and its code is not compiled
-      a.staged = stage; a.o_tag = p.ao_tag; a.tag = tag;
-      const uint32_t* qt = p.qkv_tag + (size_t)b * NBNQ;
-      const int H = a.H, Hkv = a.Hkv;
-      unsigned* err = p.err;
-      auto hook = [=]() __attribute__((always_inline)) {
-        constexpr int NV4 = (G + 2) * DH / 4;          // one uint4 of tagged words per thread
-        const int seg = tid / (DH / 4), e4 = tid % (DH / 4);
-        const int w0 = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
-        const bool mine = tid < NV4;
-        if (wave * 64 < NV4) {
-          uint4 v = make_uint4(0, 0, 0, 0);
-          unsigned spins = 0;
-          for (;;) {
-            if (mine) v = nb_ld16(nbuf, qt + w0);
-            const bool ok = !mine || ((v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag);
-            if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
-            if (pcy_wait_give_up(spins, 1u << 19, err, 9u, lane)) break;
-            __builtin_amdgcn_s_sleep(8);
-          }
-          if (mine) *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
-        }
-        lds_barrier();
-        if (tr && tid == 0) tr[1] = wall_clock64();
-      };
-      attn_dec_body<DH, G, DS>(a, smem, bx, kvh, b, hook);
-    }
-    NB_T(2)
-    if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 3);   // two batches per wave while x is on its way
-    __syncthreads();                                   // the attention's LDS is dead
-    nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, false);
-    return;
-  }
+  int unit = wg;
+  if (wg >= n_attn) {
   // ---- projection workgroups (192): 4 qkv rows per wave; the first d / 32 of them also 4 o rows per wave ----
   bf16_t* ra = reinterpret_cast<bf16_t*>(smem);             // [NB][d]  RMSNorm(x) * ln1, then the attention output
   bf16_t* rb = ra + NB * d;                                 // [NB][d]  the layer's input
@@ -604,10 +567,11 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
   if (wave < NB && lane < 32)
     __hip_atomic_store(p.qkv_tag + (size_t)wave * NBNQ + (r0 & ~31) + lane, line[wave * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NB_T(1)
-  uint4 wa[8 * UB], wb[8 * UB];
-  // the first gate/up batch of the MLP while the attention runs
-  if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 1);
   if (active) {
+    uint4 wa[8 * UB], wb[8 * UB];
+    // the first gate/up batch of the MLP while the attention runs
+    if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 1);
+    {
     uint4 w[32];   // o rows [r0, r0 + 4) wait in registers while the attention runs
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -666,10 +630,58 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
     if (wave < NB && lane < 32)
       __hip_atomic_store(p.xo_tag + (size_t)wave * d + (r0 & ~31) + lane, line[wave * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     NB_T(4)
+    }
+    __syncthreads();                                     // every wave is done with this phase's LDS
+    // (the second batch of this wave's gate/up rows is requested inside, behind the fetch of the residual stream)
+    nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, true);
+    return;
   }
-  __syncthreads();                                     // every wave is done with this phase's LDS
-  // (the second batch of this wave's gate/up rows is requested inside, behind the fetch of the residual stream)
-  nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, true);
+    // qkv rows only: an attention unit of the second set (NB >= 5), or none
+    unit = UNITS > 64 ? 64 + (wg - n_attn - d / 32) : -1;
+    __syncthreads();                                   // the stores above have read `line`; the attention's LDS starts at 0
+  }
+  {
+    // ---- attention of one (row, kv head, column slice): units [0, 64) on the attention workgroups, units [64, 128) (NB >= 5) on the
+    // projection workgroups that have qkv rows only, behind their rows; a workgroup without a unit goes straight to the MLP ----
+    uint4 wa[8 * UB], wb[8 * UB];
+    const int kvh = unit % a.Hkv, bx = (unit / a.Hkv) % SLICES, b = unit / (a.Hkv * SLICES);   // kv head in the low digits: the slices of a head share an XCD's L2
+    if (unit >= 0 && b < NB) {
+      bf16_t* stage = reinterpret_cast<bf16_t*>(smem + stage_off);   // [G + 2][DH]
+      a.xepoch = xepoch;
+      a.xerr = p.err;
+      if constexpr (SLICES == 1) a.xflags = nullptr;   // one workgroup per (row, kv head): no key split, and its code is not compiled
+      a.staged = stage; a.o_tag = p.ao_tag; a.tag = tag;
+      const uint32_t* qt = p.qkv_tag + (size_t)b * NBNQ;
+      const int H = a.H, Hkv = a.Hkv;
+      unsigned* err = p.err;
+      auto hook = [=]() __attribute__((always_inline)) {
+        constexpr int NV4 = (G + 2) * DH / 4;          // one uint4 of tagged words per thread
+        const int seg = tid / (DH / 4), e4 = tid % (DH / 4);
+        const int w0 = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
+        const bool mine = tid < NV4;
+        if (wave * 64 < NV4) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          unsigned spins = 0;
+          for (;;) {
+            if (mine) v = nb_ld16(nbuf, qt + w0);
+            const bool ok = !mine || ((v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag);
+            if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+            if (pcy_wait_give_up(spins, 1u << 19, err, 9u, lane)) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+          if (mine) *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2((v.x & 0xffffu) | (v.y << 16), (v.z & 0xffffu) | (v.w << 16));
+        }
+        lds_barrier();
+        if (tr && tid == 0) tr[1] = wall_clock64();
+      };
+      attn_dec_body<DH, G, DS>(a, smem, bx, kvh, b, hook);
+    }
+    NB_T(2)
+    if (wave < 7) nb_prime_gate_up<UB>(mc, lane, wg * 7 + wave, wa, wb, 3);   // two batches per wave while x is on its way
+    __syncthreads();                                   // the attention's LDS is dead
+    nb_mlp_body<NB, UB>(nbuf, mc, p.xo_tag, part, smem, vthr_gu, tag, wg, wa, wb, tr, x_out_lines, false);
+    return;
+  }
 #undef NB_T
 }
 
@@ -705,7 +717,7 @@ bool launch_nb_ub(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBloc
                const unsigned* step_epoch, int n_cu, int xmin) {
   constexpr int DH = 128, G = 4, DS = NbGeom<NB>::DS, SLICES = NbGeom<NB>::SLICES;
   constexpr int n_attn = 64;   // (units beyond SLICES x Hkv x NB idle through the attention phase)
-  static_assert(SLICES * 8 * NB <= 64, "attention units");
+  static_assert(SLICES * 8 * NB <= 128, "attention units");
   a.o_sc1 = 0;
   a.xflags = (xmin > 0 && a.scratch && SLICES > 1) ? a.xflags : nullptr;
   a.xmin = xmin;
@@ -748,7 +760,7 @@ bool launch_nb(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBlockAr
 // Words of tagged hand-over slots per layer / of the residual stream between two layers for an NB-row step
 size_t pcy_decode_nb_tag_words(int NB) { return (size_t)NB * (NBF + NBNQ + NBD + NBD) + (size_t)NBD * 4 * NB * 2; }
 size_t pcy_decode_nb_line_words(int NB) { return (size_t)256 * (((size_t)NB * 16 + 31) / 32 * 32); }
-int pcy_decode_nb_ds(int B) { return B <= 1 ? 16 : B == 2 ? 32 : B <= 4 ? 64 : 128; }
+int pcy_decode_nb_ds(int B) { return B <= 1 ? 16 : B == 2 ? 32 : 64; }
 
 // All decoder layers of a decode step for 2 <= B <= 8 rows in one launch.  Geometry: Llama-3-8B (d = 4096, ffn = 14336, 32 / 8 heads of
 // 128), 256 CUs.  false = not covered, nothing launched.  st.tags / st.tag_stride / st.x_lines follow pcy_decode_nb_tag_words /

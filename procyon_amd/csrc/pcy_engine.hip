@@ -200,10 +200,11 @@ int decode_mode() {
   return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
          (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0);
 }
+constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 // geometry of the small-batch step: Llama-3-8B, 256 CUs
 bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
   return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
-         c->n_cu >= 256 && m->n_layers <= 128;
+         c->n_cu >= 256 && m->n_layers <= AO_MAX_LAYERS / 2;   // (score-exchange flags: 2 x AO_FLAGS words per layer)
 }
 // ... for the small-batch step: the exchange costs more there than the K reads it saves until much longer caches (t ~ 800: 2 / 4 rows
 // 2.935 / 3.385 ms per step with the split, 2.868 / 3.287 without; t ~ 1540: 3.158 / 3.653 with, 3.180 / 3.632 without)
@@ -215,7 +216,6 @@ int decode_xmin() {   // cached keys from which the decode attention splits its 
   const char* xe = getenv("PCY_AO_XMIN");
   return xe ? atoi(xe) : 768;
 }
-constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
 size_t tag_words_per_layer(const pcy_llama_desc* m) {
@@ -350,7 +350,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     mc.x = x; mc.x_out = x; mc.d = d; mc.F = F; mc.rms_eps = m->rms_eps; mc.rms_cast = m->rms_cast; mc.epoch = c->nb_sync + B; mc.err = c->xwg_err;
     PcyDecodeStepArgs sa{};
     sa.layers = c->dev_layers; sa.n_layers = m->n_layers; sa.kv_layer_stride = layer_stride;
-    sa.tags = c->nb_tags[B]; sa.tag_stride = pcy_decode_nb_tag_words(B); sa.xflags_stride = AO_FLAGS;
+    sa.tags = c->nb_tags[B]; sa.tag_stride = pcy_decode_nb_tag_words(B); sa.xflags_stride = 2 * AO_FLAGS;   // up to 128 attention units per layer
     sa.x_lines = c->nb_tags[B] + (size_t)m->n_layers * sa.tag_stride; sa.x_lines_stride = pcy_decode_nb_line_words(B);
     if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode_nb.py): in-kernel time stamps, [layer][workgroup][16]
       if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
