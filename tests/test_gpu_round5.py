@@ -19,13 +19,15 @@ def eng2():
 
 
 @pytest.mark.parametrize("B,T,N,xmin", [(2, 300, 9, 0), (3, 100, 7, 0), (4, 300, 9, 0), (5, 64, 7, 0), (6, 40, 5, 0), (7, 90, 5, 0), (8, 300, 7, 0),
-                                        (4, 800, 6, 0), (2, 1100, 5, 0), (4, 420, 6, 384), (2, 500, 6, 384)])
+                                        (4, 800, 6, 0), (2, 1100, 5, 0), (4, 420, 6, 384), (2, 500, 6, 384), (5, 420, 6, 384), (8, 450, 5, 384),
+                                        (2, 1600, 4, 0)])
 def test_decode_nb_step_bit_identical(eng2, monkeypatch, B, T, N, xmin):
     """decode_step_nb_kernel (all layers of a B-row step in one launch: NB dot products per weight row, tagged hand-overs, four-way K split
     of the down projection with {tag, fp32} partial sums) against its launch-per-stage twin (PCY_DISABLE=decode_nb_step: gemv_stream_kernel
     + attn_dec_kernel with the same column slices + gemv_kwin4_kernel): logits of every step, tokens and the appended K / V rows must be
-    BIT-identical, eager and under hipGraph replay (the second replayed run starts at the tag / flag state the first one left); T = 800 /
-    1100 and PCY_AO_XMIN = 384 put the attention's key split + score exchange on (2 / 4 column slices); no watchdog (Context.sync raises)."""
+    BIT-identical, eager and under hipGraph replay (the second replayed run starts at the tag / flag state the first one left); PCY_AO_XMIN =
+    384 and T = 1600 at 2 rows (default threshold 1536) put the attention's key split + score exchange on (2 / 4 column slices; 5 and 8 rows:
+    the units on the projection workgroups too); no watchdog (Context.sync raises)."""
     from procyon_amd.engine import Context, GenState
     if xmin:
         monkeypatch.setenv("PCY_AO_XMIN", str(xmin))
