@@ -29,6 +29,16 @@
 #define PCY_ATTN_DEC_NP(DS) 4
 #include "pcy_attn_dec.h"
 
+#ifndef PCY_NB_ACT_SLEEP
+#define PCY_NB_ACT_SLEEP 16
+#endif
+#ifndef PCY_NB_WQKV_FRONT
+#define PCY_NB_WQKV_FRONT 1
+#endif
+#ifndef PCY_NB_LATE
+#define PCY_NB_LATE 4
+#endif
+
 namespace {
 
 constexpr int NBD = 4096, NBF = 14336, NBWIN = NBF / 4, NBNQ = 6144;
@@ -55,7 +65,7 @@ __device__ __forceinline__ void nb_fetch_issue(const NbBuf& nb, const uint32_t* 
 #pragma unroll
   for (int j = 0; j < NV; ++j) pre[j] = nb_ld16(nb, src + w0 + (j * 64 + lane) * 4);
 }
-template <int NV>
+template <int NV, int SLEEP = 16>
 __device__ __forceinline__ void nb_fetch_finish(const NbBuf& nb, const uint32_t* src, int w0, int lane, uint32_t tag, bf16_t* dst, uint4 (&pre)[NV], unsigned* err,
                                                 unsigned code) {
   unsigned spins = 0;
@@ -66,7 +76,7 @@ __device__ __forceinline__ void nb_fetch_finish(const NbBuf& nb, const uint32_t*
       ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
     if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
     if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
-    __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_s_sleep(SLEEP);
     nb_fetch_issue<NV>(nb, src, w0, lane, pre);
   }
 #pragma unroll
@@ -401,14 +411,18 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   // slowest workgroup has finished gate/up, a request that finds a stale word costs a second trip through the loaded queue (~10 us), and
   // behind 32 KB of weights the request is served ~10 us later anyway (window in LDS 23 -> ? us after the end of gate/up at 4 rows).
   uint4 tq[NB][2];
-  const bool late_block = kg + 4 * wave >= 14;
+  const bool late_block = PCY_NB_LATE != 0 && kg + 4 * wave >= 14;
   if (wave < 7 && !late_block) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
   }
-  issue_down(0, wa);
-  issue_down(1, wb);
-  if (wave < 7 && late_block) {
+  if (PCY_NB_LATE != 4) issue_down(0, wa);
+  if (PCY_NB_LATE == 1 && wave < 7 && late_block) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
+  }
+  if (PCY_NB_LATE < 3) issue_down(1, wb);
+  if (PCY_NB_LATE >= 2 && wave < 7 && late_block) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
   }
@@ -416,9 +430,11 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   if (wave < 7) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-      nb_fetch_finish<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tag, rb + b * NBWIN + wave * 512, tq[b], a.err, 20u);
+      nb_fetch_finish<2, PCY_NB_ACT_SLEEP>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tag, rb + b * NBWIN + wave * 512, tq[b], a.err, 20u);
     NB_T(6)
   }
+  if (PCY_NB_LATE == 4) issue_down(0, wa);
+  if (PCY_NB_LATE >= 3) issue_down(1, wb);
   lds_barrier();   // this group's act values are in rb
   NB_T(10)
   {
@@ -529,10 +545,10 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
 #pragma unroll
         for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(r0 + i) * d + (it * 64 + lane) * 8);
     };
-    load_rows(0);
+    if (PCY_NB_WQKV_FRONT || !x_in_lines) load_rows(0);
     if (x_in_lines) {
       // (all 32 KB in front: B = 4 / 8 at 3.41 / 4.18 ms per step; all behind: 3.36 / 4.11; half and half: 3.32 / 4.16)
-      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u, [&]() __attribute__((always_inline)) { load_rows(2); });
+      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u, [&]() __attribute__((always_inline)) { if (!PCY_NB_WQKV_FRONT) load_rows(0); load_rows(2); });
     } else {
       load_rows(2);
 #pragma unroll
