@@ -29,15 +29,6 @@
 #define PCY_ATTN_DEC_NP(DS) 4
 #include "pcy_attn_dec.h"
 
-#ifndef PCY_NB_ACT_SLEEP
-#define PCY_NB_ACT_SLEEP 16
-#endif
-#ifndef PCY_NB_WQKV_FRONT
-#define PCY_NB_WQKV_FRONT 1
-#endif
-#ifndef PCY_NB_LATE
-#define PCY_NB_LATE 4
-#endif
 
 namespace {
 
@@ -65,7 +56,7 @@ __device__ __forceinline__ void nb_fetch_issue(const NbBuf& nb, const uint32_t* 
 #pragma unroll
   for (int j = 0; j < NV; ++j) pre[j] = nb_ld16(nb, src + w0 + (j * 64 + lane) * 4);
 }
-template <int NV, int SLEEP = 16>
+template <int NV>
 __device__ __forceinline__ void nb_fetch_finish(const NbBuf& nb, const uint32_t* src, int w0, int lane, uint32_t tag, bf16_t* dst, uint4 (&pre)[NV], unsigned* err,
                                                 unsigned code) {
   unsigned spins = 0;
@@ -76,7 +67,7 @@ __device__ __forceinline__ void nb_fetch_finish(const NbBuf& nb, const uint32_t*
       ok = ok && (pre[j].x >> 16) == tag && (pre[j].y >> 16) == tag && (pre[j].z >> 16) == tag && (pre[j].w >> 16) == tag;
     if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
     if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
-    __builtin_amdgcn_s_sleep(SLEEP);
+    __builtin_amdgcn_s_sleep(16);
     nb_fetch_issue<NV>(nb, src, w0, lane, pre);
   }
 #pragma unroll
@@ -328,9 +319,9 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   });
   NB_T(8)
   if (tid < NB * 16) xres[tid] = rb[(tid >> 4) * d + wg * 16 + (tid & 15)];
+  const int kg = (wg & 7) >> 1, kq = (wg >> 3) * 2 + (wg & 1);       // group (an XCD pair), index in the group
   nb_rms_stage<NB>(rb, a.ln2, vthr_gu, a.rms_eps, a.rms_cast, ra, red);
   // down: this workgroup's K blocks and this wave's 8 rows
-  const int kg = (wg & 7) >> 1, kq = (wg >> 3) * 2 + (wg & 1);       // group (an XCD pair), index in the group
   const int dr0 = (kq * 8 + wave) * 8;
   auto issue_down = [&](int t, uint4 (&w)[8 * UB]) __attribute__((always_inline)) {   // batch t = k-iterations [t UB, t UB + UB) of the 7
 #pragma unroll
@@ -406,23 +397,15 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   // ---- down ----
   // (one piece of code for all eight waves: requests inside the branch above and in an else-branch for wave 7 met in 32 four-register
   // copies and the allocator spilled both batches)
-  // Wave j takes block kg + 4 j of act, all rows.  A block of the first half of act (its units were finished half way through gate/up) is
-  // requested in FRONT of the weight rows (a CU's loads return in order); a block of the second half BEHIND them: it is complete only when the
-  // slowest workgroup has finished gate/up, a request that finds a stale word costs a second trip through the loaded queue (~10 us), and
-  // behind 32 KB of weights the request is served ~10 us later anyway (window in LDS 23 -> ? us after the end of gate/up at 4 rows).
+  // Wave j takes block kg + 4 j of act, all rows -- and NO down row is requested before the window has arrived.  A hand-over load is
+  // served behind whatever the chip has in flight (in-kernel stamps at 4 rows: a block that had been complete for 10 us took 11 us to
+  // fetch while the slower workgroups' last gate/up batches and the faster ones' first down batches were in the queues, and the
+  // producers' tagged stores wait in the same queues), so the 32 KB per wave that used to be requested first cost more in the hop than
+  // they saved behind it: both batches in front 3.24 / 4.10 ms per step at 4 / 8 rows, one 3.19 / 4.02, none 3.18 / 3.99.  (Where the
+  // second-half blocks were requested -- in front of, between or behind the weight batches -- made no difference; longer sleeps between
+  // the polls cost 0.5 ... 15 %; touching the blocks' pages ahead changed nothing.)
   uint4 tq[NB][2];
-  const bool late_block = PCY_NB_LATE != 0 && kg + 4 * wave >= 14;
-  if (wave < 7 && !late_block) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
-  }
-  if (PCY_NB_LATE != 4) issue_down(0, wa);
-  if (PCY_NB_LATE == 1 && wave < 7 && late_block) {
-#pragma unroll
-    for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
-  }
-  if (PCY_NB_LATE < 3) issue_down(1, wb);
-  if (PCY_NB_LATE >= 2 && wave < 7 && late_block) {
+  if (wave < 7) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) nb_fetch_issue<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tq[b]);
   }
@@ -430,11 +413,12 @@ __device__ __forceinline__ void nb_mlp_body(const NbBuf& nbuf, const PcyMlpChain
   if (wave < 7) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-      nb_fetch_finish<2, PCY_NB_ACT_SLEEP>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tag, rb + b * NBWIN + wave * 512, tq[b], a.err, 20u);
+      nb_fetch_finish<2>(nbuf, a.act_tag + (size_t)b * F + (kg + 4 * wave) * 512, 0, lane, tag, rb + b * NBWIN + wave * 512, tq[b], a.err, 20u);
     NB_T(6)
+    if (tr && wave == 6 && lane == 0) tr[7] = wall_clock64();
   }
-  if (PCY_NB_LATE == 4) issue_down(0, wa);
-  if (PCY_NB_LATE >= 3) issue_down(1, wb);
+  issue_down(0, wa);
+  issue_down(1, wb);
   lds_barrier();   // this group's act values are in rb
   NB_T(10)
   {
@@ -545,10 +529,11 @@ __device__ __forceinline__ void nb_layer_body(const NbBuf& nbuf, PcyDecAttnArgs 
 #pragma unroll
         for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(r0 + i) * d + (it * 64 + lane) * 8);
     };
-    if (PCY_NB_WQKV_FRONT || !x_in_lines) load_rows(0);
+    load_rows(0);
     if (x_in_lines) {
-      // (all 32 KB in front: B = 4 / 8 at 3.41 / 4.18 ms per step; all behind: 3.36 / 4.11; half and half: 3.32 / 4.16)
-      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u, [&]() __attribute__((always_inline)) { if (!PCY_NB_WQKV_FRONT) load_rows(0); load_rows(2); });
+      // (all 32 KB in front: B = 4 / 8 at 3.41 / 4.18 ms per step; all behind: 3.36 / 4.11; half and half: 3.32 / 4.16 -- and again
+      // after the down stage's change: half and half 3.18 / 3.99, all behind 3.23 / 4.07)
+      nb_fetch_lines<NB>(nbuf, x_in_lines, 7, tag, rb, p.err, 14u, [&]() __attribute__((always_inline)) { load_rows(2); });
     } else {
       load_rows(2);
 #pragma unroll

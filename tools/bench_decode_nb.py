@@ -91,7 +91,7 @@ def timing():
                 lay = tr[5]
                 t0 = lay[:, 0].min()
                 names = {0: "start", 13: "x in LDS", 14: "RMSNorm done", 15: "qkv rows computed", 1: "qkv stored / q,k,v staged", 2: "attention done / ao seen", 3: "ao in LDS", 4: "o stored", 8: "xo in LDS",
-                         9: "gate/up done", 5: "down rows requested", 6: "window 0 tags ok (wave 0)", 10: "window 0 in LDS", 11: "down rows done", 12: "end (rows published)"}
+                         9: "gate/up done", 5: "down rows requested", 6: "window 0 tags ok (wave 0)", 7: "window tags ok (wave 6: a late block)", 10: "window 0 in LDS", 11: "down rows done", 12: "end (rows published)"}
                 for grp, sl in (("attn wgs", slice(0, 64)), ("proj wgs", slice(64, 192)), ("qkv-only wgs", slice(192, 256))):
                     print(f"  -- {grp}")
                     for i, nm in names.items():
