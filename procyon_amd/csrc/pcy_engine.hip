@@ -915,7 +915,7 @@ static uint64_t esm_weights_fingerprint(const pcy_esm_desc* m) {
 }
 // tokens at or below which pcy_esm_encode replays a captured launch chain (PCY_DISABLE=esm_graph: always launch by launch; read per call)
 static int esm_graph_max_tokens() {
-  return pcy_off("esm_graph") ? 0 : 4200;
+  return pcy_off("esm_graph") ? 0 : 40000;   // (round 5: bulk batches too -- see EsmEngine.GRAPH_MAX_TOKENS)
 }
 int pcy_esm_encode(pcy_ctx* c, const pcy_esm_desc* m, const int32_t* tokens, const int32_t* pos, const int32_t* cu,
                    const int32_t* vt_cu, int ntok, int nseq, int max_len, int vt_total, int mask_pads, void* hidden_out) {

@@ -732,7 +732,12 @@ class EsmEngine:
                               1 if cfg.rope_math == "fp32_once" else 0, self.embed.data_ptr(), self.fw.data_ptr(),
                               self.fb.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr(), C.cast(arr, C.POINTER(L.EsmLayer)))
 
-    GRAPH_MAX_TOKENS = 4200     # = the engine's own bound (pcy_esm_encode; PCY_DISABLE=esm_graph switches the replay off)
+    # = the engine's own bound (pcy_esm_encode; PCY_DISABLE=esm_graph switches the replay off).  Round 5: raised from 4200 (one long protein) to
+    # 40 000 tokens (the retrieval batch: 25 x 1026).  A bulk batch is ~230 launches of 25-300 us; on an idle host they are enqueued in 2.4 ms,
+    # far ahead of the GPU, but a GPU box whose host cores were busy (other tenants) took ~50 ms per batch for them and the retrieval leg
+    # dropped from 634 to 434 proteins/s with the encoder's own time unchanged (profiles/r05_bench.json history in DESIGN.md): one graph
+    # launch per batch takes the host out of the loop.
+    GRAPH_MAX_TOKENS = 40000
 
     def preferred_batch(self, tokens_per_protein, lo=16, hi=40, n_cu=256):
         """Proteins per engine call for retrieval-style bulk encoding ("batch size chosen by the engine", BASELINE configs[2]).
@@ -772,7 +777,9 @@ class EsmEngine:
         return dict(tokens=tokens.to(torch.int32), pos=pos.to(torch.int32), cu=cu.to(torch.int32), vt_cu=vt_cu.to(torch.int32),
                     lens=lens, real=real, ntok=int(cu[-1]), nseq=Bp, max_len=int(lens.max()), vt_total=int(vt_cu[-1]))
 
-    def encode_packed(self, pk, mask_pads=True):
+    def encode_packed(self, pk, mask_pads=True, borrow=False):
+        """borrow=True: the caller consumes the result before the next call of this shape is enqueued (stream order) -- the persistent output
+        buffer of a replayed launch chain is returned as it is instead of a copy."""
         dev = self.device
         if pk["max_len"] > self.cfg.max_len:
             raise ValueError(f"sequence of {pk['max_len']} tokens exceeds the rotary table ({self.cfg.max_len})")
@@ -794,7 +801,7 @@ class EsmEngine:
         L.check(self.ctx.lib.pcy_esm_encode(self.ctx.h, C.byref(self.desc), _p(t["tokens"]), _p(t["pos"]), _p(t["cu"]), _p(t["vt_cu"]),
                                             pk["ntok"], pk["nseq"], pk["max_len"], pk["vt_total"], int(mask_pads), _p(hidden)),
                 "pcy_esm_encode")
-        return hidden if slot is None else hidden.clone()    # (the persistent buffer is rewritten by the next call of this shape)
+        return hidden if (slot is None or borrow) else hidden.clone()    # (the persistent buffer is rewritten by the next call of this shape)
 
     def hidden_states(self, rows, mask_pads=True):
         """rows int64 [B',S] -> padded [B',S,d] representations (pad slots zero-filled; test helper)."""
@@ -837,7 +844,7 @@ class EsmEngine:
         """`ESM_PLM.forward(tokens, aggregate=True)`: split long proteins, encode, pool per original protein."""
         rows, keys = batched_split_long_seq(tokens.cpu().long(), max_protein_len=max_protein_len)
         pk = self.pack(rows, mask_pads)
-        h = self.encode_packed(pk, mask_pads)
+        h = self.encode_packed(pk, mask_pads, borrow=True)   # pooled below, on the same stream, before anything can overwrite it
         nprot = int(keys.max()) + 1
         seg = [0]
         rng = []
