@@ -560,22 +560,14 @@ void launch_dec_ds(hipStream_t s, const PcyDecAttnArgs& a) {
   if (a.qkv_partials) {
     const int stage_off = (int)((attn_dec_smem_bytes(G, DS, DH, a.Tmax) + 15) & ~(size_t)15);
     const size_t smem = (size_t)stage_off + (size_t)(G + 2) * DH * 2;
-    static size_t configured = 0;
-    if (smem > 65536 && smem > configured) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_splitk_kernel<DH, G, DS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      configured = smem;
-    }
+    static PcyLdsAttr lds;
+    lds.ensure(&attn_dec_splitk_kernel<DH, G, DS>, smem);
     hipLaunchKernelGGL((attn_dec_splitk_kernel<DH, G, DS>), dim3(DH / DS, a.Hkv, a.B), dim3(512), smem, s, a, stage_off);
     return;
   }
   const size_t smem = attn_dec_smem_bytes(G, DS, DH, a.Tmax);
-  static size_t configured = 0;
-  if (smem > 65536 && smem > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_kernel<DH, G, DS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured = smem;
-  }
+  static PcyLdsAttr lds;
+  lds.ensure(&attn_dec_kernel<DH, G, DS>, smem);
   hipLaunchKernelGGL((attn_dec_kernel<DH, G, DS>), dim3(DH / DS, a.Hkv, a.B), dim3(512), smem, s, a);
 }
 
@@ -725,17 +717,10 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   const dim3 grid(n_attn + (o.N + rw * 8 - 1) / (rw * 8)), block(512);
 #define PCY_AO_LAUNCH(RWV)                                                                                          \
   do {                                                                                                              \
-    static size_t configured = 0;                                                                                   \
-    if (smem > 65536 && smem > configured) {                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_o_kernel<DH, G, RWV>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                            \
-      configured = smem;                                                                                            \
-    }                                                                                                               \
-    static int resident = -1; static size_t resident_smem = 0;                                                      \
-    if (resident < 0 || resident_smem != smem) {                                                                    \
-      resident = pcy_all_resident(attn_o_kernel<DH, G, RWV>, 512, smem, (int)grid.x, n_cu) ? 1 : 0; resident_smem = smem; \
-    }                                                                                                               \
-    if (!resident) return false;                                                                                    \
+    static PcyLdsAttr lds;                                                                                          \
+    lds.ensure(&attn_o_kernel<DH, G, RWV>, smem);                                                                   \
+    static PcyResidentCache res;                                                                                    \
+    if (!res.check(smem, [&] { return pcy_all_resident(attn_o_kernel<DH, G, RWV>, 512, smem, (int)grid.x, n_cu); })) return false; \
     hipLaunchKernelGGL((attn_o_kernel<DH, G, RWV>), grid, block, smem, s, a, o, n_attn, epoch, flags, err, dbg, delay); \
   } while (0)
   switch (rw) {
@@ -1036,21 +1021,15 @@ bool launch_decode_layer(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs
   size_t pf_off = ((smem_o > smem_mlp ? smem_o : smem_mlp) + 1023) & ~(size_t)1023;
   if (pcy_off("lds_prefetch") || pf_off + 7 * 16384 > 160 * 1024) pf_off = 0;
   if (pf_off && pf_off + 7 * 16384 > smem) smem = pf_off + 7 * 16384;
-  static size_t configured[2] = {0, 0};
-  if (smem > 65536 && smem > configured[st ? 1 : 0]) {
-    if (st) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_step_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_layer_kernel<DH, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured[st ? 1 : 0] = smem;
-  }
-  // every workgroup waits for words the others write: all 256 must be resident at once (occupancy query, cached per kernel / LDS size)
-  static int resident[2] = {-1, -1}; static size_t resident_smem[2] = {0, 0};
-  const int ri = st ? 1 : 0;
-  if (resident[ri] < 0 || resident_smem[ri] != smem) {
-    resident[ri] = (st ? pcy_all_resident(decode_step_kernel<DH, G>, 512, smem, 256, n_cu)
-                       : pcy_all_resident(decode_layer_kernel<DH, G>, 512, smem, 256, n_cu)) ? 1 : 0;
-    resident_smem[ri] = smem;
-  }
-  if (!resident[ri]) return false;
+  static PcyLdsAttr lds[2];
+  if (st) lds[1].ensure(&decode_step_kernel<DH, G>, smem);
+  else lds[0].ensure(&decode_layer_kernel<DH, G>, smem);
+  // every workgroup waits for words the others write: all 256 must be resident at once (occupancy query, cached per kernel / device / LDS size)
+  static PcyResidentCache res[2];
+  if (!res[st ? 1 : 0].check(smem, [&] {
+        return st ? pcy_all_resident(decode_step_kernel<DH, G>, 512, smem, 256, n_cu) : pcy_all_resident(decode_layer_kernel<DH, G>, 512, smem, 256, n_cu);
+      }))
+    return false;
   if (st)
     hipLaunchKernelGGL((decode_step_kernel<DH, G>), dim3(256), dim3(512), smem, s, a, p, mc, *st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
                        stage_off, pcy_gemv_rms_threads(mc.F), (int)pf_off);

@@ -166,6 +166,41 @@ __device__ __forceinline__ uint4 ld16_agent(const void* p) {
 }
 __device__ __forceinline__ void st_bf16_agent(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Launch-time caches are PER DEVICE (a process may drive several: hipFuncSetAttribute and the occupancy answers belong to the device that
+// is current when they are made).  Host code only.
+constexpr int PCY_MAX_DEV = 16;
+inline int pcy_cur_dev() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < PCY_MAX_DEV) ? d : 0;
+}
+struct PcyLdsAttr {   // the largest dynamic-LDS size a kernel has been configured for on each device
+  size_t configured[PCY_MAX_DEV] = {};
+  template <typename K>
+  bool ensure(K kernel, size_t smem, size_t above = 65536) {   // false: the device refused the size
+    const int d = pcy_cur_dev();
+    if (smem > above && smem > configured[d]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      configured[d] = smem;
+    }
+    return true;
+  }
+};
+struct PcyResidentCache {   // "all workgroups of this launch are resident at once" per device and LDS size
+  int ok[PCY_MAX_DEV];
+  size_t smem[PCY_MAX_DEV];
+  PcyResidentCache() { for (int i = 0; i < PCY_MAX_DEV; ++i) { ok[i] = -1; smem[i] = 0; } }
+  template <typename Q>
+  bool check(size_t s, Q query) {
+    const int d = pcy_cur_dev();
+    if (ok[d] < 0 || smem[d] != s) { ok[d] = query() ? 1 : 0; smem[d] = s; }
+    return ok[d] == 1;
+  }
+};
+
 // Watchdog of the in-launch cross-workgroup waits (hand-overs, flags): give up after `limit` polls and record `code` in the
 // context's sticky error word -- and give up at once when ANY wait of the launch has already done so (otherwise a launch whose
 // workgroups are not all resident, e.g. beside a competing kernel, would sit out the full limit at every one of its ~200

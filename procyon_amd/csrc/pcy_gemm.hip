@@ -1083,29 +1083,20 @@ void launch_fp8(hipStream_t s, const PcyGemmArgs& a) {
   b.gn = (int)(gnb > tn ? tn : gnb);
   ++g_pcy_dispatch[PCY_DISPATCH_GEMM_FP8];
   if (gemm_noperm(EPI, true)) {
-    static bool configured_n = false;
-    if (!configured_n) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      configured_n = true;
-    }
+    static PcyLdsAttr lds_n;
+    lds_n.ensure(&gemm_kernel_big<EPI, true, true, 1>, smem, 0);
     hipLaunchKernelGGL((gemm_kernel_big<EPI, true, true, 1>), dim3(tiles_big), dim3(512), smem, s, b);
     return;
   }
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    configured = true;
-  }
+  static PcyLdsAttr lds;
+  lds.ensure(&gemm_kernel_big<EPI, true, false, 1>, smem, 0);
   hipLaunchKernelGGL((gemm_kernel_big<EPI, true, false, 1>), dim3(tiles_big), dim3(512), smem, s, b);
 }
 
 template <int EPI, bool NOPERM>
 void launch_big_variant(hipStream_t s, const PcyGemmArgs& b, dim3 grid, int smem) {
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_big<EPI, false, NOPERM, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    configured = true;
-  }
+  static PcyLdsAttr lds;
+  lds.ensure(&gemm_kernel_big<EPI, false, NOPERM, 2>, smem, 0);
   hipLaunchKernelGGL((gemm_kernel_big<EPI, false, NOPERM, 2>), grid, dim3(512), smem, s, b);
 }
 

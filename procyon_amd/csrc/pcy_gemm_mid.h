@@ -169,12 +169,8 @@ template <int EPI, int TM, int TN, int WM, int WN, int S>
 void launch_mid_cfg(hipStream_t s, const PcyGemmArgs& a0) {
   constexpr int smem = S * (TM + TN) * 128;
   static_assert(smem <= 160 * 1024, "LDS");
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_mid<EPI, TM, TN, WM, WN, S>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    configured = true;
-  }
+  static PcyLdsAttr lds;
+  lds.ensure(&gemm_kernel_mid<EPI, TM, TN, WM, WN, S>, smem, 0);
   PcyGemmArgs a = a0;
   const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
   // rasterisation: an XCD runs a contiguous range of the tile order; groups of `gn` column tiles, all row tiles inside (tile_origin).

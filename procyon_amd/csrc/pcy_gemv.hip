@@ -927,11 +927,8 @@ template <int EPI, int BT, int S>
 bool launch_mfma4_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
   constexpr size_t smem = (size_t)4 * S * RT * 4096 + (size_t)S * BT * 4096;
-  static int configured = 0;   // 1 ok, -1 the device refused the LDS size
-  if (!configured)
-    configured = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma4_kernel<EPI, BT, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem) == hipSuccess ? 1 : -1;
-  if (configured < 0) { (void)hipGetLastError(); return false; }
+  static PcyLdsAttr lds;
+  if (!lds.ensure(&gemv_mfma4_kernel<EPI, BT, S>, smem, 0)) return false;   // (the device refused the LDS size)
   hipLaunchKernelGGL((gemv_mfma4_kernel<EPI, BT, S>), dim3(bx, ksplit), dim3(256), smem, s, a, ksplit);
   return true;
 }
@@ -948,11 +945,8 @@ template <int EPI, int BT, int S>
 void launch_mfma3_s(hipStream_t s, const PcyGemvArgs& a, int bx, int ksplit) {
   constexpr int RT = (EPI == EPI_SWIGLU) ? 2 : 1;
   constexpr size_t smem = (size_t)4 * S * RT * 4096 + 2 * BT * 16 * (256 * 2 + 16);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_mfma3_kernel<EPI, BT, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    configured = true;
-  }
+  static PcyLdsAttr lds;
+  lds.ensure(&gemv_mfma3_kernel<EPI, BT, S>, smem, 0);
   hipLaunchKernelGGL((gemv_mfma3_kernel<EPI, BT, S>), dim3(bx, ksplit), dim3(256), smem, s, a, ksplit);
 }
 // Ring depth S (super-steps of 128 k kept in flight per wave = S - 1): the SwiGLU kernel streams two row tiles per wave (S = 3: 96 KB
@@ -1092,9 +1086,8 @@ bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu) {
   if (n_cu < GEMV_CUS || a.d != 2 * NW || a.d != MC_WV * 512 || a.F != 2 * 7 * 1024 || a.F % (2 * 512 * MC_UNB_D)) return false;
   const size_t smem = (size_t)(2 * a.d + a.F) * 2 + 128;
   if (smem > 64 * 1024) return false;
-  static int resident = -1; static size_t resident_smem = 0;
-  if (resident < 0 || resident_smem != smem) { resident = pcy_all_resident(mlp_chain_kernel, MC_NT, smem, GEMV_CUS, n_cu) ? 1 : 0; resident_smem = smem; }
-  if (!resident) return false;
+  static PcyResidentCache res;
+  if (!res.check(smem, [&] { return pcy_all_resident(mlp_chain_kernel, MC_NT, smem, GEMV_CUS, n_cu); })) return false;
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(GEMV_CUS), dim3(MC_NT), smem, s, a, pcy_gemv_rms_threads(a.F));
   return true;
 }
