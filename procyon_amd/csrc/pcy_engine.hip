@@ -53,7 +53,7 @@ struct pcy_ctx {
   const void* graph_key[GRAPH_KEY_N] = {};
   int graph_B = 0;
   int graph_mode = 0;
-  int graph_kind = 0;                 // 0: decode + greedy pick (pcy_llama_greedy), 1: decode only (pcy_llama_decode_graph)
+  int graph_kind = 0;                 // 0: decode + greedy pick (pcy_llama_greedy), 1: decode only (pcy_llama_decode_graph), 2: a beam-search step (pcy_llama_beam_steps)
   int n_cu = 0;
   // sticky error word: a cross-workgroup hand-over inside a launch hit its watchdog.  PINNED HOST memory (device-visible): the
   // kernels store it with system scope, every ABI entry looks at it without touching the stream (take_sticky_error below)
@@ -532,20 +532,25 @@ int ensure_sample_state(pcy_ctx* c, int B, int V) {
 // launches (gather into a scratch copy, copy back): grid (B, Hkv, 2L).  Rows that keep their place (rows[b] == b: most rows
 // once the beams of a group have settled) are skipped in both passes.  The per-layer version took 4 launches per layer
 // (128 launches, ~1 ms of a 8.8 ms beam step at beam 10).
+// t_dev != nullptr (the replayed beam step): the number of slots is read from the device (the position counter the beam step has just
+// advanced) and the scratch rows are Tmax slots apart -- nothing in the launch depends on the step.
 __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, bf16_t* __restrict__ tmp,
-                                 const int32_t* __restrict__ rows, int B, int Bcache, int Hkv, int Tmax, int t, int dh, int to_tmp) {
+                                 const int32_t* __restrict__ rows, int B, int Bcache, int Hkv, int Tmax, int t, int dh, int to_tmp,
+                                 const int32_t* __restrict__ t_dev) {
   const int b = blockIdx.x, h = blockIdx.y, lw = blockIdx.z, l = lw >> 1;
   const int src_b = rows[b];
   if (src_b == b) return;
+  int ts = t;                 // slots between two scratch rows
+  if (t_dev) { t = *t_dev; t = t < Tmax ? t : Tmax; ts = Tmax; }
   bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh;
-  bf16_t* scratch = tmp + (size_t)lw * B * Hkv * t * dh;
+  bf16_t* scratch = tmp + (size_t)lw * B * Hkv * ts * dh;
   const size_t n8 = (size_t)t * dh / 8;
   const uint4* sp; uint4* dp;
   if (to_tmp) {
     sp = reinterpret_cast<const uint4*>(cache + ((size_t)src_b * Hkv + h) * Tmax * dh);
-    dp = reinterpret_cast<uint4*>(scratch + ((size_t)b * Hkv + h) * t * dh);
+    dp = reinterpret_cast<uint4*>(scratch + ((size_t)b * Hkv + h) * ts * dh);
   } else {
-    sp = reinterpret_cast<const uint4*>(scratch + ((size_t)b * Hkv + h) * t * dh);
+    sp = reinterpret_cast<const uint4*>(scratch + ((size_t)b * Hkv + h) * ts * dh);
     dp = reinterpret_cast<uint4*>(cache + ((size_t)b * Hkv + h) * Tmax * dh);
   }
   for (size_t i = threadIdx.x; i < n8; i += blockDim.x) dp[i] = sp[i];
@@ -1365,10 +1370,81 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
   bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
   const dim3 grid(B, Hkv, 2 * L);
   hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
-                     kv->Tmax, t, dh, 1);
+                     kv->Tmax, t, dh, 1, (const int32_t*)nullptr);
   hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
-                     kv->Tmax, t, dh, 0);
+                     kv->Tmax, t, dh, 0, (const int32_t*)nullptr);
   return check_launch("pcy_kv_reorder");
+}
+
+// Steps 1 .. of the diverse beam search as ONE replayed launch chain per step: decode step (the graph of pcy_llama_decode_graph's launches)
+// -> record of the step's logits (row (step, b) of logits_rec, step read from the device) -> pcy_beam_step -> pcy_kv_reorder over the
+// slots the position counter names.  Same kernels, same order, same bits as the four calls (PCY_DISABLE=beam_graph: the callers keep
+// them); it removes the ~12 launch boundaries of a step (3.43 -> see DESIGN.md ms per step at beam 5).
+int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int beam, int group_size,
+                         float diversity_penalty, const pcy_beam_state* bs, void* logits_rec, int n_steps) {
+  PCY_STICKY(c);
+  const int BB = B * beam;
+  if (B <= 0 || beam <= 0 || beam > 32 || group_size <= 0 || beam % group_size)
+    return fail(1, "pcy_llama_beam_steps: beam=%d (1..32) must be a multiple of group_size=%d", beam, group_size);
+  if (BB > kv->B) return fail(1, "pcy_llama_beam_steps: %d rows exceed cache rows %d", BB, kv->B);
+  if (m->vocab <= 0 || m->vocab > 163840) return fail(1, "pcy_llama_beam_steps: vocab %d unsupported (<= 163840)", m->vocab);
+  if (st->pos != bs->pos || st->next_tok != bs->next_tok) return fail(1, "pcy_llama_beam_steps: the decode state must read the beam state's position and tokens");
+  if ((kv->Tmax * m->head_dim) % 8) return fail(1, "pcy_llama_beam_steps: Tmax * head_dim must be a multiple of 8");
+  if (n_steps <= 0) return 0;
+  // everything the chain allocates, before the capture: decode workspace + the reorder scratch behind it, beam scratch, decode state
+  const int Hkv = m->n_kv_heads, dh = m->head_dim, L = m->n_layers;
+  const size_t tmp_elems = (size_t)2 * L * BB * Hkv * kv->Tmax * dh;
+  if (int r = c->reserve(decode_ws_bytes(m, BB, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
+  if (int r = ensure_decode_state(c, m, BB)) return r;
+  const size_t need = align_up(pcy_beam_ws_bytes(B, beam), 256);
+  if (need > c->beam_ws_bytes) {
+    if (c->beam_ws) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->beam_ws)); c->beam_ws = nullptr; c->beam_ws_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->beam_ws), need * 2));
+    c->beam_ws_bytes = need * 2;
+    c->drop_graph();
+  }
+  uint32_t pen_bits; memcpy(&pen_bits, &diversity_penalty, 4);
+  const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, bs->out, bs->cur,
+                                           st->logits, logits_rec, bs->src, c->ws,
+                                           (const void*)(intptr_t)(((int64_t)beam << 40) ^ ((int64_t)group_size << 32) ^ kv->Tmax),
+                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ pen_bits),
+                                           c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ (uint64_t)(uintptr_t)bs->step ^ ((uint64_t)bs->max_len << 48))};
+  if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != BB || c->graph_mode != decode_mode() || c->graph_kind != 2) {
+    c->drop_graph();
+    PcyBeamState b{};
+    b.out = bs->out; b.max_len = bs->max_len; b.cur = bs->cur; b.cur_new = bs->cur_new; b.next_tok = bs->next_tok; b.src = bs->src;
+    b.anc = bs->anc; b.has_eos = bs->has_eos; b.blk_eos = bs->blk_eos; b.ticket = bs->ticket; b.pos = bs->pos; b.step = bs->step;
+    b.done = bs->done; b.eos_id = bs->eos_id;
+    bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, BB, kv->Tmax), 256));
+    hipGraph_t g = nullptr;
+    hipStream_t user = c->stream;
+    c->stream = c->cap_stream;
+    hipError_t e0 = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e0 == hipSuccess) {
+      hipStream_t s = c->stream;
+      enqueue_decode(c, m, kv, st, BB);
+      if (logits_rec)
+        hipLaunchKernelGGL(store_logits_kernel, dim3(BB >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)logits_rec, bs->step, BB,
+                           m->vocab, m->vocab);
+      pcy_launch_beam_step(s, (const bf16_t*)st->logits, m->vocab, B, beam, group_size, diversity_penalty, b, c->beam_ws);
+      const dim3 grid(BB, Hkv, 2 * L);
+      hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 1,
+                         (const int32_t*)bs->pos);
+      hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 0,
+                         (const int32_t*)bs->pos);
+      e0 = hipStreamEndCapture(c->cap_stream, &g);
+    }
+    c->stream = user;
+    if (e0 != hipSuccess) return fail(2, "beam-step graph capture failed: %s", hipGetErrorString(e0));
+    HIP_TRY(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    memcpy(c->graph_key, key, sizeof(key));
+    c->graph_B = BB;
+    c->graph_mode = decode_mode();
+    c->graph_kind = 2;
+  }
+  for (int i = 0; i < n_steps; ++i) HIP_TRY(hipGraphLaunch(c->graph, c->stream));
+  return 0;
 }
 
 }  // extern "C"

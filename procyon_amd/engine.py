@@ -580,6 +580,12 @@ class LlamaEngine:
         L.check(self.ctx.lib.pcy_beam_step(self.ctx.h, _p(logits), logits.shape[1], bs.B, bs.beam, group_size, float(diversity_penalty),
                                            C.byref(bs.c)), "pcy_beam_step")
 
+    def beam_steps(self, cache: KVCache, st: GenState, bs: "BeamState", group_size, diversity_penalty, logits_rec, n_steps):
+        """n_steps iterations of the beam loop body (decode -> record -> beam step -> KV reorder), each ONE replayed launch chain
+        (pcy_llama_beam_steps); st.pos / st.next_tok are the beam state's arrays."""
+        L.check(self.ctx.lib.pcy_llama_beam_steps(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), bs.B, bs.beam, group_size,
+                                                  float(diversity_penalty), C.byref(bs.c), _p(logits_rec), n_steps), "pcy_llama_beam_steps")
+
     def pick(self, cache: KVCache, st: GenState, B, advance_pos):
         L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, int(advance_pos)),
                 "pcy_greedy_pick")

@@ -13,6 +13,7 @@ from itertools import chain
 from types import SimpleNamespace
 from typing import List, Optional
 
+import os
 import torch
 
 from ..engine import BF16, MlpEngine
@@ -531,17 +532,33 @@ class UnifiedProCyon:
         st.c.pos, st.c.next_tok = bs.pos.data_ptr(), bs.next_tok.data_ptr()
         rec = torch.empty(max_len, BB, V, dtype=emb_rep.dtype, device=dev)
         logits = o.logits[:, -1, :].contiguous()
-        for i in range(max_len):
-            if i > 0:
+        if "beam_graph" in os.environ.get("PCY_DISABLE", "").split(","):   # the four calls per step (same kernels, same bits; tests)
+            for i in range(max_len):
+                if i > 0:
+                    if T + i > cache.Tmax:
+                        raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
+                    eng.decode_graph(cache, st, BB)
+                    logits = st.logits
+                rec[i].copy_(logits)
+                eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
+                eng.kv_reorder(cache, bs.src, T + i)
+                if (i & 7) == 7 and int(bs.done):
+                    break
+        else:
+            # step 0 selects on the prefill's logits; every later step (decode -> record -> beam step -> KV reorder) is ONE replayed launch
+            # chain (pcy_llama_beam_steps), enqueued up to the next multiple of 8 steps, where the host looks at the EOS flag
+            rec[0].copy_(logits)
+            eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
+            eng.kv_reorder(cache, bs.src, T)
+            i = 1
+            while i < max_len:
                 if T + i > cache.Tmax:
                     raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
-                eng.decode_graph(cache, st, BB)
-                logits = st.logits
-            rec[i].copy_(logits)
-            eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
-            eng.kv_reorder(cache, bs.src, T + i)
-            if (i & 7) == 7 and int(bs.done):
-                break
+                n = min(8 - (i & 7), max_len - i, cache.Tmax - T - i + 1)
+                eng.beam_steps(cache, st, bs, beam_group_size, diversity_penalty, rec, n)
+                i += n
+                if (i & 7) == 0 and int(bs.done):
+                    break
         out, steps = bs.tokens()                                   # synchronises
         anc = bs.anc[:steps].long()
         slot = torch.arange(BB, device=dev)

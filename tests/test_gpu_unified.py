@@ -118,6 +118,24 @@ def test_generate_beam_matches_oracle(env):
         assert torch.equal(tokens[..., :first], t_ref[..., :first])
 
 
+@pytest.mark.parametrize("beam,group,max_len", [(4, 2, 6), (5, 1, 19), (6, 3, 9)])
+def test_generate_beam_replayed_chain_equals_the_four_calls(env, monkeypatch, beam, group, max_len):
+    """`_generate_beam_search` with every step >= 1 as ONE replayed launch chain (pcy_llama_beam_steps: decode -> record -> beam step -> KV
+    reorder over the slots the device-side position counter names) against the four calls per step (PCY_DISABLE=beam_graph): tokens,
+    scores and the re-indexed logits record must be EQUAL; max_len 19 crosses two of the EOS-flag checks (every 8 steps)."""
+    m = env["model"]
+    instr = ["w5 w6 <|protein|> w7 [ANSWER]", "w1 <|protein|> and <|protein|> w2 w3 [ANSWER]"]
+    kw = dict(max_len=max_len, method="beam", beam_size=beam, beam_group_size=group, diversity_penalty=0.8)
+    mk = lambda: _inputs(m, env["prot"], instr, [[0], [1, 0]], text_slots=[[], []])
+    tok_a, sc_a, lg_a, _ = m.generate(mk(), **kw)
+    monkeypatch.setenv("PCY_DISABLE", "beam_graph")
+    tok_b, sc_b, lg_b, _ = m.generate(mk(), **kw)
+    monkeypatch.delenv("PCY_DISABLE")
+    tok_c, sc_c, lg_c, _ = m.generate(mk(), **kw)     # a second replayed run (the chain is re-captured for the new cache)
+    assert torch.equal(tok_a, tok_b) and torch.equal(sc_a, sc_b) and torch.equal(lg_a, lg_b)
+    assert torch.equal(tok_a, tok_c) and torch.equal(sc_a, sc_c) and torch.equal(lg_a, lg_c)
+
+
 def test_forward_retrieval_and_qa(env):
     from oracle import llama_ref as LR
     from oracle import procyon_ref as PR
