@@ -1408,11 +1408,17 @@ int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache
     c->drop_graph();
   }
   uint32_t pen_bits; memcpy(&pen_bits, &diversity_penalty, 4);
+  // every array of the beam state is baked into the chain: all of them go into the key (FNV-1a), not only the ones listed by name below
+  uint64_t bsh = 1469598103934665603ull;
+  {
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(bs);
+    for (size_t i = 0; i < sizeof(pcy_beam_state); ++i) bsh = (bsh ^ pb[i]) * 1099511628211ull;
+  }
   const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, bs->out, bs->cur,
                                            st->logits, logits_rec, bs->src, c->ws,
                                            (const void*)(intptr_t)(((int64_t)beam << 40) ^ ((int64_t)group_size << 32) ^ kv->Tmax),
                                            (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ pen_bits),
-                                           c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ (uint64_t)(uintptr_t)bs->step ^ ((uint64_t)bs->max_len << 48))};
+                                           c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ bsh)};
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != BB || c->graph_mode != decode_mode() || c->graph_kind != 2) {
     c->drop_graph();
     PcyBeamState b{};
