@@ -340,6 +340,20 @@ def main():
             # curve of configs[3] projected from single-GPU runs of every rank's chunk (replicas, no traffic inside the loop)
             decode_curve = WL.decode_batch_curve(model)
             configs["config3_projected_scaling"] = WL.config3_projected_scaling(model, new_tokens=512, single_gpu=configs["config3_4a_batch32_mixed_residues_T512"])
+            # the reference's own generation method (model_unified.py:702-842; scripts/caption_bulk.py:121-132 hard-codes it): beam search on the
+            # headline's inputs -- ms per beam step from the slope over max_len (decode of beam rows + record + bookkeeping + KV reorder)
+            binp = SM.caption_inputs(model, prot, n_prompt_words=a.prompt - 2, n_slots=2, seed=0)
+            beams = {}
+            for (bsz, grp) in ((5, 5), (10, 2)):
+                tms = {}
+                model.generate(binp, max_len=4, method="beam", beam_size=bsz, beam_group_size=grp)
+                for n in (24, 88):
+                    torch.cuda.synchronize(); tb = time.perf_counter()
+                    model.generate(binp, max_len=n, method="beam", beam_size=bsz, beam_group_size=grp)
+                    torch.cuda.synchronize(); tms[n] = (time.perf_counter() - tb) * 1e3
+                beams[f"beam{bsz}_group{grp}"] = {"ms_per_step": round((tms[88] - tms[24]) / 64, 3), "ms_generate_88_steps": round(tms[88], 1),
+                                                 "prompt_tokens": a.prompt, "mean_cache_len": a.prompt + 56}
+            configs["beam_search_caption"] = beams
         if not dist:
             # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like
             # regime instead of the chaotic random-init one), LAST because it rewrites the decoder's weights in place

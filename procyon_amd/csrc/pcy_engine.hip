@@ -197,7 +197,7 @@ bool qkv_finish_launch() { return pcy_off("attn_qkv_finish"); }   // the qkv K-s
 bool decode_nb_enabled() { return !pcy_off("decode_nb"); }
 bool decode_nb_step_enabled() { return !pcy_off("decode_nb_step"); }
 int decode_mode() {
-  return (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
+  return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
          (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0);
 }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
@@ -536,6 +536,44 @@ int ensure_sample_state(pcy_ctx* c, int B, int V) {
 // launches (gather into a scratch copy, copy back): grid (B, Hkv, 2L).  Rows that keep their place (rows[b] == b: most rows
 // once the beams of a group have settled) are skipped in both passes.  The per-layer version took 4 launches per layer
 // (128 launches, ~1 ms of a 8.8 ms beam step at beam 10).
+// The same reorder in ONE pass and in place for up to 32 rows: a thread owns one 16-byte piece of every row of a (layer, K | V, head) slab --
+// it loads the piece of ALL rows (through LDS: the source row of a destination is only known at run time), then stores row b's piece from
+// row rows[b]'s.  Every byte is read once and the moved rows written once (the two-launch form reads and writes the moved rows twice and
+// needs a scratch copy); nothing is touched when no row moves.  Vanilla beam search (beam_group_size = beam_size, the reference's default)
+// re-ranks most rows at every step: 3.87 -> see DESIGN.md ms per beam-5 step at a 570-token cache.
+template <int MAXB>
+__global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, const int32_t* __restrict__ rows, int B,
+                                                         int Bcache, int Hkv, int Tmax, int t, int dh, const int32_t* __restrict__ t_dev) {
+  __shared__ uint4 stage[MAXB * 128];
+  const int h = blockIdx.x, lw = blockIdx.y, l = lw >> 1;
+  bool any = false;
+  for (int b = 0; b < B; ++b) any = any || rows[b] != b;
+  if (!any) return;                                        // (uniform)
+  if (t_dev) { t = *t_dev; t = t < Tmax ? t : Tmax; }
+  bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh + (size_t)h * Tmax * dh;
+  const size_t rstride = (size_t)Hkv * Tmax * dh;          // elements between two rows of the slab
+  const size_t n8 = (size_t)t * dh / 8;
+  for (size_t i = (size_t)blockIdx.z * 128 + threadIdx.x; i < n8; i += (size_t)gridDim.z * 128) {
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) stage[b * 128 + threadIdx.x] = *reinterpret_cast<const uint4*>(cache + (size_t)b * rstride + i * 8);
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
+      const int sb = rows[b];
+      if (sb != b) *reinterpret_cast<uint4*>(cache + (size_t)b * rstride + i * 8) = stage[sb * 128 + threadIdx.x];
+    }
+  }
+}
+// enqueue: the one-pass form for <= 32 rows (PCY_DISABLE=kv_permute: the two launches through the scratch copy; same result)
+static bool enqueue_kv_permute(hipStream_t s, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t, const int32_t* t_dev) {
+  if (B > 32 || pcy_off("kv_permute")) return false;
+  const dim3 grid(m->n_kv_heads, 2 * m->n_layers, 4);
+  if (B <= 8)
+    hipLaunchKernelGGL(kv_permute_kernel<8>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev);
+  else
+    hipLaunchKernelGGL(kv_permute_kernel<32>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev);
+  return true;
+}
+
 // t_dev != nullptr (the replayed beam step): the number of slots is read from the device (the position counter the beam step has just
 // advanced) and the scratch rows are Tmax slots apart -- nothing in the launch depends on the step.
 __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, bf16_t* __restrict__ tmp,
@@ -1372,6 +1410,7 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
   const size_t tmp_elems = (size_t)2 * L * B * Hkv * kv->Tmax * dh;
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
   bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
+  if (enqueue_kv_permute(c->stream, m, kv, src_rows, B, t, nullptr)) return check_launch("pcy_kv_reorder");
   const dim3 grid(B, Hkv, 2 * L);
   hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
                      kv->Tmax, t, dh, 1, (const int32_t*)nullptr);
@@ -1437,11 +1476,13 @@ int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache
         hipLaunchKernelGGL(store_logits_kernel, dim3(BB >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)logits_rec, bs->step, BB,
                            m->vocab, m->vocab);
       pcy_launch_beam_step(s, (const bf16_t*)st->logits, m->vocab, B, beam, group_size, diversity_penalty, b, c->beam_ws);
-      const dim3 grid(BB, Hkv, 2 * L);
-      hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 1,
-                         (const int32_t*)bs->pos);
-      hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 0,
-                         (const int32_t*)bs->pos);
+      if (!enqueue_kv_permute(s, m, kv, bs->src, BB, 0, (const int32_t*)bs->pos)) {
+        const dim3 grid(BB, Hkv, 2 * L);
+        hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 1,
+                           (const int32_t*)bs->pos);
+        hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 0,
+                           (const int32_t*)bs->pos);
+      }
       e0 = hipStreamEndCapture(c->cap_stream, &g);
     }
     c->stream = user;

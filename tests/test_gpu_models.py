@@ -209,17 +209,25 @@ def test_llama3_8b_layer_golden(golden):
     assert int(st.logits.float().argmax()) == int(g["fw_dec_logits"].float().argmax())
 
 
-def test_kv_reorder():
+@pytest.mark.parametrize("rows,src,t,disable", [(4, [2, 2, 0, 1], 9, ""), (4, [2, 2, 0, 1], 9, "kv_permute"), (4, [0, 1, 2, 3], 16, ""),
+                                               (8, [7, 0, 0, 3, 3, 5, 1, 2], 13, ""), (12, [1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10], 16, ""),
+                                               (33, list(range(1, 33)) + [0], 5, "")])
+def test_kv_reorder(monkeypatch, rows, src, t, disable):
+    """cache[:, b, :, :t] = cache[:, src[b], :, :t] for every layer, K and V (model_unified.py:830-832): the one-pass in-place permutation
+    (kv_permute_kernel: <= 8 and <= 32 rows), the identity (nothing touched), the two-launch form through the scratch copy
+    (PCY_DISABLE=kv_permute, and > 32 rows); slots from t on keep their contents."""
+    if disable:
+        monkeypatch.setenv("PCY_DISABLE", disable)
     sd, geom, eng = llama_pair(SM_LLAMA)
-    cache = eng.new_cache(4, 16)
+    cache = eng.new_cache(rows, 16)
     cache.k.copy_(torch.randn(cache.k.shape).to(BF))
     cache.v.copy_(torch.randn(cache.v.shape).to(BF))
     k0, v0 = cache.k.clone(), cache.v.clone()
-    src = torch.tensor([2, 2, 0, 1])
-    eng.kv_reorder(cache, src, 9)
-    assert torch.equal(cache.k[:, :, :, :9], k0[:, src.cuda()][:, :, :, :9])
-    assert torch.equal(cache.v[:, :, :, :9], v0[:, src.cuda()][:, :, :, :9])
-    assert torch.equal(cache.k[:, :, :, 9:], k0[:, :, :, 9:])
+    src = torch.tensor(src)
+    eng.kv_reorder(cache, src, t)
+    assert torch.equal(cache.k[:, :, :, :t], k0[:, src.cuda()][:, :, :, :t])
+    assert torch.equal(cache.v[:, :, :, :t], v0[:, src.cuda()][:, :, :, :t])
+    assert torch.equal(cache.k[:, :, :, t:], k0[:, :, :, t:]) and torch.equal(cache.v[:, :, :, t:], v0[:, :, :, t:])
 
 
 @pytest.mark.parametrize("T,N,n_layers", [(300, 24, 3), (600, 10, 2), (1100, 6, 2)])   # 600 / 1100: key split + score exchange on
