@@ -538,24 +538,28 @@ int ensure_sample_state(pcy_ctx* c, int B, int V) {
 // (128 launches, ~1 ms of a 8.8 ms beam step at beam 10).
 // The same reorder in ONE pass and in place for up to 32 rows: a thread owns one 16-byte piece of every row of a (layer, K | V, head) slab --
 // it loads the piece of ALL rows (through LDS: the source row of a destination is only known at run time), then stores row b's piece from
-// row rows[b]'s.  Every byte is read once and the moved rows written once (the two-launch form reads and writes the moved rows twice and
-// needs a scratch copy); nothing is touched when no row moves.  Vanilla beam search (beam_group_size = beam_size, the reference's default)
+// row rows[b]'s.  The rows that are somebody's source are read once and the moved rows written once (the two-launch form reads and writes
+// the moved rows twice and needs a scratch copy); nothing is touched when no row moves.  Vanilla beam search (beam_group_size = beam_size, the reference's default)
 // re-ranks most rows at every step: 3.87 -> see DESIGN.md ms per beam-5 step at a 570-token cache.
 template <int MAXB>
 __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, const int32_t* __restrict__ rows, int B,
                                                          int Bcache, int Hkv, int Tmax, int t, int dh, const int32_t* __restrict__ t_dev) {
   __shared__ uint4 stage[MAXB * 128];
   const int h = blockIdx.x, lw = blockIdx.y, l = lw >> 1;
-  bool any = false;
-  for (int b = 0; b < B; ++b) any = any || rows[b] != b;
-  if (!any) return;                                        // (uniform)
+  unsigned need = 0;                                       // rows some OTHER row takes its contents from (uniform)
+  for (int b = 0; b < B; ++b) {
+    const int sb = rows[b];
+    if (sb != b) need |= 1u << sb;
+  }
+  if (!need) return;                                       // no row moves
   if (t_dev) { t = *t_dev; t = t < Tmax ? t : Tmax; }
   bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh + (size_t)h * Tmax * dh;
   const size_t rstride = (size_t)Hkv * Tmax * dh;          // elements between two rows of the slab
   const size_t n8 = (size_t)t * dh / 8;
   for (size_t i = (size_t)blockIdx.z * 128 + threadIdx.x; i < n8; i += (size_t)gridDim.z * 128) {
 #pragma unroll 4
-    for (int b = 0; b < B; ++b) stage[b * 128 + threadIdx.x] = *reinterpret_cast<const uint4*>(cache + (size_t)b * rstride + i * 8);
+    for (int b = 0; b < B; ++b)
+      if ((need >> b) & 1u) stage[b * 128 + threadIdx.x] = *reinterpret_cast<const uint4*>(cache + (size_t)b * rstride + i * 8);
 #pragma unroll 4
     for (int b = 0; b < B; ++b) {
       const int sb = rows[b];
