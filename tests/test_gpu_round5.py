@@ -251,3 +251,31 @@ def test_split_geometry_config0_full_depth(golden):
         margin = float(g["top_vals"][first, 0] - g["top_vals"][first, 1])
         noise = float((lgb[first, cols] - g["logits"][first]).abs().max())
         assert margin <= 4 * noise, f"bf16 greedy token differs at step {first} outside the noise (margin {margin:.3e}, noise {noise:.3e})"
+
+
+def test_esm_bulk_batch_replays_its_launch_chain_with_the_same_bits(monkeypatch):
+    """Round 5: `pcy_esm_encode` replays the captured launch chain for BULK batches too (up to 40 000 tokens; the retrieval batch is 25 x
+    1026), one graph launch per batch instead of ~230 kernel launches -- /root/reference/procyon/evaluate/framework/procyon.py:294-322 calls the
+    encoder batch after batch.  Seven proteins of 1000 residues at ESM2-650M width (7 014 tokens: above the old 4 200-token bound, the
+    256 x 256 GEMM path): pooled embeddings of the replayed calls (dispatch counter) must EQUAL the launch-by-launch run
+    (PCY_DISABLE=esm_graph), with other tokens under the same shape, and the pooled forward may borrow the chain's persistent output
+    buffer because a later call of the same shape does not disturb an earlier result."""
+    from procyon_amd import _lib as L
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, EsmConfig, EsmEngine
+    ctx = Context.get()
+    kw = dict(d=1280, n_layers=2, n_heads=20, ffn=5120)
+    eng = EsmEngine(synth.esm_state_dict(**kw, device="cuda"), EsmConfig(**kw))
+    cnt = lambda: int(ctx.lib.pcy_debug_dispatch_count(L.DISPATCH_ESM_GRAPH))
+    ta, tb = synth.protein_tokens([1000] * 7, seed=11), synth.protein_tokens([1000] * 7, seed=12)
+    monkeypatch.setenv("PCY_DISABLE", "esm_graph")
+    ref_a, ref_b = eng.forward(ta).clone(), eng.forward(tb).clone()
+    monkeypatch.delenv("PCY_DISABLE")
+    n0 = cnt()
+    o1 = eng.forward(ta)            # first sight of the shape: launch by launch
+    o2 = eng.forward(ta)            # second: captured and replayed
+    o3 = eng.forward(tb)            # replay with other tokens
+    o4 = eng.forward(ta)
+    ctx.sync()
+    assert cnt() - n0 >= 3, cnt() - n0
+    assert torch.equal(o1, ref_a) and torch.equal(o2, ref_a) and torch.equal(o3, ref_b) and torch.equal(o4, ref_a)
