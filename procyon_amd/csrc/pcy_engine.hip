@@ -71,6 +71,11 @@ struct pcy_ctx {
   // own batch size and its counter only advances with those steps, so a word with the current tag can only come from the current step)
   uint32_t* nb_tags[9] = {};
   unsigned* nb_sync = nullptr;        // [16] tag counters, index = batch size
+  // mid-batch decode step (pcy_decode_mb.hip): arrival flags [(layers + 1)][pcy_decode_mb_flag_words()] (a flag holds the epoch of the step that
+  // raised it) and the epoch word, advanced once per step and never reset
+  unsigned* mb_flags = nullptr;
+  size_t mb_flags_words = 0;
+  unsigned* mb_sync = nullptr;
   uint32_t* op_tags = nullptr;        // tagged `act` vector of pcy_decode_mlp ([ffn] words, its own counter)
   size_t op_tags_words = 0;
   unsigned* smp_hist = nullptr;       // [rows][65536] histogram scratch of the nucleus step (kept all-zero between calls)
@@ -196,15 +201,22 @@ bool qkv_finish_launch() { return pcy_off("attn_qkv_finish"); }   // the qkv K-s
 // same column slices) instead of the one launch -- same bits, tests compare the two.
 bool decode_nb_enabled() { return !pcy_off("decode_nb"); }
 bool decode_nb_step_enabled() { return !pcy_off("decode_nb_step"); }
+// PCY_DISABLE=decode_mb_step: batches of 9..32 rows run launch by launch (seven per layer) instead of the mid-batch step (pcy_decode_mb.hip:
+// the same work items as phases of ONE launch) -- same bits, tests compare the two.
+bool decode_mb_step_enabled() { return !pcy_off("decode_mb_step"); }
 int decode_mode() {
   return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
-         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0);
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0);
 }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 // geometry of the small-batch step: Llama-3-8B, 256 CUs
 bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
   return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
          c->n_cu >= 256 && m->n_layers <= AO_MAX_LAYERS / 2;   // (score-exchange flags: 2 x AO_FLAGS words per layer)
+}
+// geometry of the mid-batch step (9..32 rows): the same model and chip
+bool decode_mb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
+  return B >= 9 && B <= 32 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 && c->n_cu >= 256;
 }
 // ... for the small-batch step: the exchange costs more there than the K reads it saves until much longer caches (t ~ 800: 2 / 4 rows
 // 2.935 / 3.385 ms per step with the split, 2.868 / 3.287 without; t ~ 1540: 3.158 / 3.653 with, 3.180 / 3.632 without)
@@ -292,6 +304,23 @@ int ensure_decode_state(pcy_ctx* c, const pcy_llama_desc* m, int B = 1) {
     HIP_TRY(hipMemset(c->nb_tags[B], 0, nbw * 4));
     HIP_TRY(hipMemset(c->nb_sync + B, 0, 4));   // zeroed slots, next tag 1
   }
+  if (decode_mb_covers(c, m, B)) {
+    const size_t fw = (size_t)(m->n_layers + 1) * pcy_decode_mb_flag_words();
+    if (!c->mb_sync) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mb_sync), 64));
+      HIP_TRY(hipMemset(c->mb_sync, 0, 64));
+    }
+    if (c->mb_flags_words < fw) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->drop_graph();
+      if (c->mb_flags) HIP_TRY(hipFree(c->mb_flags));
+      c->mb_flags = nullptr; c->mb_flags_words = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->mb_flags), fw * 4));
+      HIP_TRY(hipMemset(c->mb_flags, 0, fw * 4));   // (the epoch word keeps counting: a zeroed flag never equals a later epoch)
+      c->mb_flags_words = fw;
+    }
+  }
   return 0;
 }
 
@@ -323,6 +352,9 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   // 2..8 rows: the small-batch step (pcy_decode_nb.hip) -- one launch for all layers, or its launch-per-stage twin; lm_head as before
   const bool nb_on = decode_nb_enabled() && decode_nb_covers(c, m, B) && c->nb_tags[B] && c->nb_sync && c->dev_layers && c->ao_sync && c->xwg_err;
   const bool batched = batched_head && !nb_on;
+  // 9..32 rows: the mid-batch step (pcy_decode_mb.hip) -- the batched path's work items as phases of one launch
+  const bool mb_step = batched && decode_mb_step_enabled() && decode_mb_covers(c, m, B) && pcy_decode_mb_fits(B, kv->Tmax) && c->mb_flags && c->mb_sync &&
+                       c->dev_layers && c->xwg_err && (size_t)(m->n_layers + 1) * pcy_decode_mb_flag_words() <= c->mb_flags_words;
   const bool try_ao = attn_o_enabled() && B == 1 && c->ao_sync && c->xwg_err && m->n_layers <= AO_MAX_LAYERS;
   bool try_layer = decode_layer_enabled() && try_ao && c->mc_tags;   // one launch per decoder layer
   const bool nb_step = nb_on && decode_nb_step_enabled();
@@ -330,8 +362,9 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     if (try_ao || nb_step) pcy_launch_bump(s, c->ao_sync);
     if (try_layer) pcy_launch_bump(s, c->ao_sync + 1);
     if (nb_step) pcy_launch_bump(s, c->nb_sync + B);
+    if (mb_step) pcy_launch_bump(s, c->mb_sync);
   } else {
-    pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, (try_ao || nb_step) ? c->ao_sync : nullptr,
+    pcy_launch_embed_tokens_dev(s, (const bf16_t*)m->embed, st->next_tok, x, B, d, (try_ao || nb_step) ? c->ao_sync : (mb_step ? c->mb_sync : nullptr),
                                 try_layer ? c->ao_sync + 1 : (nb_step ? c->nb_sync + B : nullptr));
   }
   const size_t tag_stride = tag_words_per_layer(m);
@@ -380,6 +413,22 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     step_done = pcy_launch_decode_step(s, t, bp, mc, sa, c->n_cu, c->ao_sync);
   }
   int xn_ready = 0;   // batched path: xn = RMSNorm(x) of the NEXT projection already produced by a fused finish kernel
+  if (mb_step) {
+    PcyMbArgs ma{};
+    ma.layers = c->dev_layers; ma.n_layers = m->n_layers; ma.final_norm = (const bf16_t*)m->final_norm;
+    ma.x = x; ma.xn = xn; ma.ao = ao; ma.act = act;
+    ma.qkv_ws = sk_ws; ma.sk_ws = sk_ws + (size_t)2 * B * qkvw;
+    ma.kcache = (bf16_t*)kv->k; ma.vcache = (bf16_t*)kv->v; ma.kv_layer_stride = layer_stride; ma.Bcache = kv->B;
+    ma.pos_dev = st->pos; ma.cos_t = (const bf16_t*)m->rope_cos; ma.sin_t = (const bf16_t*)m->rope_sin; ma.keep = st->keep; ma.ld_keep = kv->Tmax;
+    ma.B = B; ma.Tmax = kv->Tmax; ma.scale = 1.0f / sqrtf((float)dh); ma.rms_eps = m->rms_eps; ma.rms_cast = m->rms_cast;
+    ma.flags = c->mb_flags; ma.epoch = c->mb_sync; ma.err = c->xwg_err;
+    if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode_mb.py): in-kernel time stamps, [layer][workgroup][16]
+      if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
+      ma.trace = g_mc_trace + (size_t)128 * 256 * 16;
+    }
+    pcy_launch_rmsnorm(s, x, (const bf16_t*)m->layers[0].ln1, xn, B, d, m->rms_eps, m->rms_cast);
+    if (pcy_launch_decode_step_mb(s, c->device, ma, c->n_cu)) { step_done = true; xn_ready = 1; }
+  }
   for (int l = 0; l < (step_done ? 0 : m->n_layers); ++l) {
     const pcy_llama_layer& L = m->layers[l];
     PcyGemvArgs g{};
@@ -641,6 +690,8 @@ void pcy_ctx_destroy(pcy_ctx* c) {
   if (c->dev_layers) hipFree(c->dev_layers);
   for (auto& t : c->nb_tags) if (t) hipFree(t);
   if (c->nb_sync) hipFree(c->nb_sync);
+  if (c->mb_flags) hipFree(c->mb_flags);
+  if (c->mb_sync) hipFree(c->mb_sync);
   if (c->op_tags) hipFree(c->op_tags);
   if (c->beam_ws) hipFree(c->beam_ws);
   if (c->smp_hist) hipFree(c->smp_hist);
@@ -1302,7 +1353,7 @@ int replay_decode_graph(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache*
                                            st->logits, st->logits_all, st->keep, c->ws,
                                            (const void*)(intptr_t)(((int64_t)st->logits_all_ld << 32) ^ kv->Tmax),
                                            (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ st->max_steps),
-                                           c->mc_tags, c->dev_layers, (const void*)(uintptr_t)c->layers_fp};
+                                           (const void*)((uintptr_t)c->mc_tags ^ ((uintptr_t)c->mb_flags << 1)), c->dev_layers, (const void*)(uintptr_t)c->layers_fp};
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 ||
       c->graph_B != B || c->graph_mode != decode_mode() || c->graph_kind != kind) {
     c->drop_graph();

@@ -236,6 +236,32 @@ bool pcy_launch_decode_step_nb(hipStream_t s, int device, const PcyDecAttnArgs& 
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
 int pcy_gemv_rms_threads(int N);
 
+// Mid-batch decode step (pcy_decode_mb.hip): every decoder layer of a step for 9..32 rows in ONE launch -- the batched (skinny-MFMA) GEMVs
+// of the launch-per-stage path, its decode attention and its K-split finish + RMSNorm as phases of one persistent kernel, the weight rings
+// running ahead across the phase boundaries.  Geometry: Llama-3-8B (d 4096, ffn 14336, 32 / 8 heads of 128), 256 CUs.
+struct PcyMbArgs {
+  const PcyLayerWeightsDev* layers; int n_layers;   // device table of the layers' weights
+  const bf16_t* final_norm;                         // [d] the norm behind the last layer (its result is what lm_head reads)
+  bf16_t* x;                                        // [B][d] residual stream (in: the embedded tokens; out: the last layer's output)
+  bf16_t* xn;                                       // [B][d] in: RMSNorm(x) * ln1 of layer 0; out: RMSNorm(x_out) * final_norm
+  bf16_t* ao;                                       // [B][d] attention output
+  bf16_t* act;                                      // [B][ffn] SwiGLU output
+  float* qkv_ws;                                    // [2][B][Nq] K-split partial sums of the qkv projection
+  float* sk_ws;                                     // [4][B][d] K-split partial sums of the o / down projections
+  bf16_t* kcache; bf16_t* vcache; size_t kv_layer_stride; int Bcache;
+  const int32_t* pos_dev; const bf16_t* cos_t; const bf16_t* sin_t; const uint8_t* keep; int ld_keep;
+  int B, Tmax; float scale, rms_eps; int rms_cast;
+  unsigned* flags;                                  // [(n_layers + 1)][pcy_decode_mb_flag_words()] arrival flags (value = step epoch)
+  const unsigned* epoch;                            // device word advanced once per step that runs this launch
+  unsigned* err;                                    // watchdog word
+  unsigned long long* trace;                        // measurement aid: [layer][256][16] time stamps (nullptr: none)
+};
+size_t pcy_decode_mb_flag_words();
+int pcy_decode_mb_ds(int B);                        // output columns per attention workgroup of the B-row step (the twin must use the same)
+bool pcy_decode_mb_fits(int B, int Tmax);           // LDS of the attention phase fits beside the weight rings
+// false = not covered, nothing launched
+bool pcy_launch_decode_step_mb(hipStream_t s, int device, const PcyMbArgs& a, int n_cu);
+
 // pooled[i] over token ranges rng[seg[i]..seg[i+1]) = (start,len) pairs; mode 0 mean, 1 mean-corrected, 2 max
 size_t pcy_pool_ws_bytes(int nprot, int d);
 void pcy_launch_pool(hipStream_t s, const bf16_t* h, int d, const int32_t* seg, const int32_t* rng, int nprot,

@@ -496,23 +496,18 @@ class UnifiedProCyon:
         if beam_size % beam_group_size != 0:
             raise ValueError("beam_group_size must evenly divide beam_size, got: "
                              f"{beam_size} % {beam_group_size} != 0")
-        emb_rep = torch.repeat_interleave(input_embeds, repeats=beam_size, dim=0)
-        mask_rep = torch.repeat_interleave(attn_mask, repeats=beam_size, dim=0)
-        dev = self.device
         enc = self.text_encoder
-        eng = enc.engine
         if beam_size > 32:
             raise ValueError("beam_size > 32 is not supported by the device-side beam step")
-        from ..engine import BeamState, GenState
-        T = emb_rep.shape[1]
+        T = input_embeds.shape[1]
         keep_new = enc.max_new_tokens
         enc.max_new_tokens = max(keep_new, max_len)
         try:
-            return self._beam_search_body(emb_rep, mask_rep, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty)
+            return self._beam_search_body(input_embeds, attn_mask, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty)
         finally:
             enc.max_new_tokens = keep_new
 
-    def _beam_search_body(self, emb_rep, mask_rep, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty):
+    def _beam_search_body(self, input_embeds, attn_mask, B, BB, V, T, max_len, beam_size, beam_group_size, diversity_penalty):
         from ..engine import BeamState, GenState
         dev = self.device
         enc = self.text_encoder
@@ -523,15 +518,27 @@ class UnifiedProCyon:
         # re-indexed once at the end along the parent chain (the reference re-indexes the whole history on the host in every
         # group of every step, model_unified.py:827-829).  The EOS stop (:833) is decided on the device; once it has fired the
         # queued steps change nothing, so the host looks at the flag only every few steps.
-        o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
-                logit_positions=torch.full((BB,), T - 1), want_hidden=False)
-        cache = o.past_key_values.cache
+        # The reference replicates every prompt x beam BEFORE the prefill (model_unified.py:751-752): beam x the prefill on identical rows.
+        # Here each prompt is prefilled ONCE into row b of a BB-row cache; its K / V rows are then copied to the rows of its beams (one
+        # pcy_kv_reorder with the constant source map r -> r // beam) and its last-row logits repeated.  PCY_DISABLE=beam_prefill_once: the
+        # reference's replicated prefill (a BB-row batch may take other GEMM tiles than a B-row one: equal to bf16 noise, tests).
+        if beam_size > 1 and "beam_prefill_once" not in os.environ.get("PCY_DISABLE", "").split(","):
+            cache = eng.new_cache(BB, T + enc.max_new_tokens)
+            lg_b, _ = eng.prefill(input_embeds.to(eng.device), attn_mask, cache, "last")
+            eng.kv_reorder(cache, torch.arange(BB, dtype=torch.int32) // beam_size, T)
+            logits = lg_b.repeat_interleave(beam_size, dim=0).contiguous()
+        else:
+            emb_rep = torch.repeat_interleave(input_embeds, repeats=beam_size, dim=0)
+            mask_rep = torch.repeat_interleave(attn_mask, repeats=beam_size, dim=0)
+            o = enc(input_embeds=emb_rep, attn_masks=mask_rep, use_cache=True, past_key_values=None,
+                    logit_positions=torch.full((BB,), T - 1), want_hidden=False)
+            cache = o.past_key_values.cache
+            logits = o.logits[:, -1, :].contiguous()
         bs = BeamState(B, beam_size, max_len, self.tokenizer.eos_token_id, prompt_len=T, device=dev)
         st = GenState(BB, V, 1, dev)
         st.pos, st.next_tok = bs.pos, bs.next_tok                  # the decode graph reads what the beam step writes
         st.c.pos, st.c.next_tok = bs.pos.data_ptr(), bs.next_tok.data_ptr()
-        rec = torch.empty(max_len, BB, V, dtype=emb_rep.dtype, device=dev)
-        logits = o.logits[:, -1, :].contiguous()
+        rec = torch.empty(max_len, BB, V, dtype=logits.dtype, device=dev)
         if "beam_graph" in os.environ.get("PCY_DISABLE", "").split(","):   # the four calls per step (same kernels, same bits; tests)
             for i in range(max_len):
                 if i > 0:
