@@ -7,7 +7,7 @@
 // bytes) never reach the streaming rate at all.  Here the SAME work items run as phases of one persistent kernel:
 //
 //   256 workgroups x 512 threads, one per CU, all resident.  Per layer
-//     Q  workgroups [0, 192): item (64 rows of Wqkv, K half)      -> fp32 partial sums                 (gemv_mfma4_kernel, ksplit 2)
+//     Q  every workgroup: item (48 rows of Wqkv, K half)          -> fp32 partial sums                 (gemv_mfma4_kernel, ksplit 2)
 //     A  workgroups [0, units): decode attention of one (row, kv head, DS columns) unit, q / k / v added up from the partial sums
 //                                                                                                        (attn_dec_splitk_kernel)
 //     O  every workgroup: item (64 rows of Wo, K quarter)         -> fp32 partial sums                 (gemv_mfma4_kernel, ksplit 4)
@@ -19,7 +19,7 @@
 //   the split sums, same rounding points): the launch is BIT-IDENTICAL to the launch-per-stage step (PCY_DISABLE=decode_mb_step; tests).
 //
 //   Waves 0..3 of a workgroup are the GEMV waves: each streams ITS 16 (gate/up: 2 x 16) weight rows as 4 KB tiles [16 rows][256 B] by LDS-DMA
-//   into a private ring of 7 tiles and keeps 5 tiles outstanding AT ALL TIMES -- the tile sequence of a wave runs through the phases and the
+//   into a private ring of 7 tiles that is kept FULL at all times (a step refills the slots it has just read) -- the tile sequence of a wave runs through the phases and the
 //   layers (Q, O, G, D, next layer's Q, ...) and does not stop at a phase boundary: while a workgroup waits for its inputs, publishes its
 //   results or runs the attention, the rings fill with the next items' weights (the finishers F1 / F2 are workgroups WITHOUT an item in the
 //   phase that follows, so nothing of theirs queues in front of the partial sums they fetch).
@@ -32,7 +32,7 @@
 //   (value = the step's epoch: a device counter advanced once per step, so nothing is ever re-zeroed); a consumer polls the flag words of
 //   its producers with ONE 16-byte agent-scope load per lane and then reads the payload with sc1 loads.  Every wait is bounded (watchdog).
 //
-// LDS: 4 x 28 KB weight rings + 48 KB shared (x ring | attention | finisher scratch) = 160 KB.
+// LDS: 4 weight rings of 7 (6) tiles + 48 (64) KB shared (x ring | attention | finisher scratch) = 160 KB at <= 16 (<= 32) rows.
 #include <stdlib.h>
 #include "pcy_internal.h"
 // (one workgroup per CU, as in the small-batch step: key tiles of four passes up front, V rows one pass ahead; same rows, same sums)
@@ -46,21 +46,26 @@ typedef __attribute__((address_space(3))) void* mb_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* mb_gptr_t;
 
 constexpr int MBD = 4096, MBF = 14336, MBNQ = 6144;
-constexpr int MB_RING = 7;                          // tiles of a GEMV wave's ring
-constexpr int MB_DEPTH = 5;                         // tiles outstanding at a step's wait (the step then issues as many as it consumes)
-constexpr int MB_WBYTES = 4 * MB_RING * 4096;       // 112 KB
-constexpr int MB_XBYTES = 48 * 1024;
-constexpr int MB_SMEM = MB_WBYTES + MB_XBYTES;      // 160 KB
+// LDS split by batch tiles.  A CU's loads return in issue order, so the x tile of step s + n must be requested no later than the weight tiles of
+// step s + n: the x ring has to look as many STEPS ahead as the weight rings.  16 rows (BT 1): 7 weight tiles per wave + 8 x steps of 4 KB;
+// 32 rows (BT 2): 6 weight tiles per wave + 8 x steps of 8 KB (with 7 + 6 steps the O / D phases ran at the x loads' pace: 1.2 us per step).
+template <int BT> struct MbCfg {
+  static constexpr int RING = BT == 2 ? 6 : 7;          // tiles of a GEMV wave's ring; kept full (a step refills the slots it has just read)
+  static constexpr int WBYTES = 4 * RING * 4096;        // 96 / 112 KB
+  static constexpr int XBYTES = 160 * 1024 - WBYTES;    // 64 / 48 KB: x ring | attention | finisher scratch
+  static constexpr int SX = 8;                          // x steps in the ring
+};
+constexpr int MB_SMEM = 160 * 1024;
 // arrival flags of one layer (words; every group starts on a 256-byte line)
 constexpr int MBF_XN = 0;      // [32]      F2 of the previous layer: row b's xn is there
-constexpr int MBF_QKV = 64;    // [8][32]   per kv head: the 24 Q items that hold its q / k / v rows
+constexpr int MBF_QKV = 64;    // [256]     Q items
 constexpr int MBF_AO = 320;    // [4][64]   per K quarter of Wo: the attention units of its two kv heads
 constexpr int MBF_O = 576;     // [256]     O items
 constexpr int MBF_XN2 = 832;   // [32]      F1: row b's xn is there
 constexpr int MBF_ACT = 896;   // [4][64]   per K quarter of Wdown: the 56 G items that produce its act columns
 constexpr int MBF_DN = 1152;   // [256]     D items
 constexpr int MBF_STRIDE = 1408;
-constexpr int MB_Q_WGS = 192, MB_G_WGS = 224, MB_F1_WG0 = 224, MB_F2_WG0 = 192;
+constexpr int MB_G_WGS = 224, MB_F1_WG0 = 224, MB_F2_WG0 = 192;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mb_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); }
 __device__ __forceinline__ uint4 mb_ld16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
@@ -94,17 +99,20 @@ __device__ __forceinline__ void mb_raise(unsigned* f, unsigned epoch) { __hip_at
 struct MbStream {
   const PcyLayerWeightsDev* layers;
   int n_layers, wg, wave;
-  char* ring;                 // this wave's MB_RING tiles
+  char* ring;                 // this wave's tiles
   int il, iph, itile, intiles, iK, irt2, islot, idone;
   const bf16_t* ibase;        // first element of the phase's item for this wave: W + r0 * K + kbeg
   int cslot;                  // ring slot of the next tile to be consumed
 };
-__device__ __forceinline__ bool mb_has_item(int wg, int ph) { return ph == 0 ? wg < MB_Q_WGS : ph == 2 ? wg < MB_G_WGS : true; }
+// Q: 384 row tiles x 2 K halves = 768 wave items = 3 per workgroup (waves 0..2: tiles 3 (wg >> 1) + wave of half wg & 1) -- every CU streams in
+// every phase but G (896 gate/up pairs = 3.5 per workgroup: 224 workgroups of 4).  A CU draws ~25 GB/s from HBM whatever it has in flight, so a
+// phase is as long as its fullest CU.
+__device__ __forceinline__ bool mb_has_item(int wg, int wave, int ph) { return ph == 0 ? wave < 3 : ph == 2 ? wg < MB_G_WGS : true; }
 __device__ __forceinline__ void mb_stream_setup(MbStream& s) {
   const PcyLayerWeightsDev lw = s.layers[s.il];
   const int wg = s.wg, wave = s.wave;
   s.itile = 0;
-  if (s.iph == 0) { s.ibase = lw.wqkv + (size_t)((wg >> 1) * 64 + wave * 16) * MBD + (wg & 1) * 2048; s.intiles = 16; s.iK = MBD; s.irt2 = 0; }
+  if (s.iph == 0) { s.ibase = lw.wqkv + (size_t)((wg >> 1) * 48 + wave * 16) * MBD + (wg & 1) * 2048; s.intiles = 16; s.iK = MBD; s.irt2 = 0; }
   else if (s.iph == 1) { s.ibase = lw.wo + (size_t)((wg >> 2) * 64 + wave * 16) * MBD + (wg & 3) * 1024; s.intiles = 8; s.iK = MBD; s.irt2 = 0; }
   else if (s.iph == 2) { s.ibase = lw.wgu + (size_t)((wg * 4 + wave) * 32) * MBD; s.intiles = 64; s.iK = MBD; s.irt2 = 1; }
   else { s.ibase = lw.wdown + (size_t)((wg >> 2) * 64 + wave * 16) * MBF + (wg & 3) * 3584; s.intiles = 28; s.iK = MBF; s.irt2 = 0; }
@@ -113,12 +121,13 @@ __device__ __forceinline__ void mb_stream_advance(MbStream& s) {   // the phase'
   for (;;) {
     if (++s.iph == 4) { s.iph = 0; ++s.il; }
     if (s.il >= s.n_layers) { s.idone = 1; s.itile = s.intiles - 1; return; }   // behind the last layer: the last tile again (the counts stay uniform)
-    if (mb_has_item(s.wg, s.iph)) break;
+    if (mb_has_item(s.wg, s.wave, s.iph)) break;
   }
   mb_stream_setup(s);
 }
 // one tile [16 rows][256 B] -> the ring; voff = this lane's element offset inside a tile for K = 4096 / 14336 (4 x 4 rows of 256 B, the 16-byte
 // pieces of a row XOR-swizzled by the row on the source side: gemv_mfma4_kernel's layout)
+template <int RING>
 __device__ __forceinline__ void mb_stream_issue(MbStream& s, const int (&voff4)[4], const int (&voff14)[4]) {
   const bf16_t* p = s.ibase + (s.irt2 ? (size_t)(s.itile & 1) * 16 * s.iK + (size_t)(s.itile >> 1) * 128 : (size_t)s.itile * 128);
   char* dst = s.ring + s.islot * 4096;
@@ -126,7 +135,7 @@ __device__ __forceinline__ void mb_stream_issue(MbStream& s, const int (&voff4)[
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     __builtin_amdgcn_global_load_lds((mb_gptr_t)(p + (k4 ? voff4[q] : voff14[q])), (mb_lds_ptr_t)(dst + q * 1024), 16, 0, 2 /* nt */);
-  s.islot = s.islot + 1 == MB_RING ? 0 : s.islot + 1;
+  s.islot = s.islot + 1 == RING ? 0 : s.islot + 1;
   if (!s.idone && ++s.itile == s.intiles) mb_stream_advance(s);
 }
 
@@ -151,11 +160,13 @@ struct MbCtx {
 //   wait_f / wait_n: flags of the producers of x (nullptr: x was written before the launch); done_f: this item's flag
 template <int RT, int BT, int EPI>
 __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const int (&voff4)[4], const int (&voff14)[4], int nsteps, const bf16_t* x, int ldx,
-                                              const unsigned* wait_f, int wait_n, unsigned wait_code, float* ws_out, int N, int n0, unsigned* done_f, int t_ready) {
-  constexpr int SX = BT == 2 ? 6 : 8;               // x ring: steps of BT tiles (48 KB / 32 KB)
+                                              const unsigned* wait_f, int wait_n, unsigned wait_code, float* ws_out, int N, int n0, unsigned* done_f, int t_ready,
+                                              int nact = 4 /* GEMV waves that have an item */) {
+  constexpr int SX = MbCfg<BT>::SX, RING = MbCfg<BT>::RING;
   constexpr int NX = BT * 4;                        // copies per step
   MB_IDS
   const int B = c.a->B;
+  const int abl = c.a->abl;   // timing ablations (tools only; wrong results): 1 x copies without sc1, 2 no MFMAs, 4 no x copies, 8 no attention, 16 no waits, 32 no finish arithmetic
   const int fr = lane & 15, fq = lane >> 4;
   char* xring = c.xreg;
   f32x4 acc[RT][BT];
@@ -172,28 +183,28 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
       int b = bt * 16 + row;
       b = b < B ? b : B - 1;
       const bf16_t* src = x + (size_t)b * ldx + ss * 128 + ((lane & 15) ^ row) * 8;
-      __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + bt * 4096 + q * 1024), 16, 0, 16 /* sc1 */);
+      if (abl & 4) continue;
+      if (abl & 1) __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + bt * 4096 + q * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + bt * 4096 + q * 1024), 16, 0, 16 /* sc1 */);
     }
   };
   if (wave == 4) {
-    if (wait_f) mb_wait_flags(wait_f, wait_n, c.epoch, c.a->err, wait_code, lane);
+    if (wait_f && !(abl & 16)) mb_wait_flags(wait_f, wait_n, c.epoch, c.a->err, wait_code, lane);
     if (c.tr && lane == 0) c.tr[t_ready] = wall_clock64();
     for (int i = 0; i < SX - 1 && i < nsteps; ++i) issue_x(i);
   }
   for (int ss = 0; ss < nsteps; ++ss) {
-    if (wave < 4) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((MB_DEPTH - RT) * 4) : "memory");     // this step's tile(s) have landed
+    if (wave < nact) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - RT) * 4) : "memory");     // this step's tile(s) have landed
     } else if (wave == 4) {
       if (ss + SX - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * NX) : "memory");   // x(ss) has landed
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // x(ss) is there for everybody; slot (ss - 1) % SX is free
-    if (wave < 4) {
+    if (wave < nact) {
       const char* wb0 = s.ring + s.cslot * 4096;
-      const int cs1 = s.cslot + 1 == MB_RING ? 0 : s.cslot + 1;
+      const int cs1 = s.cslot + 1 == RING ? 0 : s.cslot + 1;
       const char* wb1 = s.ring + cs1 * 4096;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) mb_stream_issue(s, voff4, voff14);
       const char* xb = xring + (ss % SX) * (BT * 4096);
       bf16x8 wf[RT][4];
 #pragma unroll
@@ -208,10 +219,14 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[j], acc[rt][bt], 0, 0, 0);
+          for (int j = 0; j < 4; ++j)
+            if (!(abl & 2)) acc[rt][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][j], xf[j], acc[rt][bt], 0, 0, 0);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      s.cslot = RT == 2 ? (cs1 + 1 == MB_RING ? 0 : cs1 + 1) : cs1;
+      // the tiles just read are refilled at once (the ring is wave-private: nobody else to wait for)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) mb_stream_issue<RING>(s, voff4, voff14);
+      s.cslot = RT == 2 ? (cs1 + 1 == RING ? 0 : cs1 + 1) : cs1;
     } else if (wave == 4) {
       if (ss + SX - 1 < nsteps) issue_x(ss + SX - 1);
     }
@@ -219,7 +234,7 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
   // ---- epilogue: GEMV wave w -> LDS -> wave w + 4 stores (written through), drains and the item's flag goes up ----
   lds_barrier();                                    // everybody is done with the x ring
   uint4* stage = reinterpret_cast<uint4*>(xring);   // [4][BT][64]
-  if (wave < 4) {
+  if (wave < nact) {
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) {
       uint4 v;
@@ -237,7 +252,8 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
   lds_barrier();
   if (wave >= 4) {
     const int gw = wave - 4;
-    if (EPI == 0) {
+    if (gw >= nact) {
+    } else if (EPI == 0) {
       const __amdgpu_buffer_rsrc_t rs = mb_rsrc(ws_out);
 #pragma unroll
       for (int bt = 0; bt < BT; ++bt) {
@@ -268,11 +284,11 @@ __device__ __forceinline__ void mb_finish_row(const MbCtx& c, const float* ws, c
   MB_IDS
   const int B = a.B;
   float* red = reinterpret_cast<float*>(c.xreg);
-  if (wave == 4) mb_wait_flags(wait_f, 256, c.epoch, a.err, wait_code, lane);
+  if (wave == 4 && !(a.abl & 16)) mb_wait_flags(wait_f, 256, c.epoch, a.err, wait_code, lane);
   __builtin_amdgcn_s_barrier();
   float xv[2][8];
   float ss = 0.f;
-  if (tid < 256) {
+  if (tid < 256 && !(a.abl & 32)) {
     const __amdgpu_buffer_rsrc_t rws = mb_rsrc(ws), rx = mb_rsrc(a.x);
     uint4 p[2][2][4], rr[2];
 #pragma unroll
@@ -316,7 +332,7 @@ __device__ __forceinline__ void mb_finish_row(const MbCtx& c, const float* ws, c
   lds_barrier();
   if (tid < 256 && lane == 0) red[wave] = ss;
   lds_barrier();
-  if (tid < 256) {
+  if (tid < 256 && !(a.abl & 32)) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) t += red[i];
@@ -357,15 +373,26 @@ __device__ __forceinline__ void mb_attention(const MbCtx& c, int layer, int unit
   t.o = a.ao; t.ldo = MBD; t.pos_dev = a.pos_dev; t.cos_t = a.cos_t; t.sin_t = a.sin_t; t.keep = a.keep; t.ld_keep = a.ld_keep;
   t.B = a.B; t.H = 32; t.Hkv = 8; t.dh = DH; t.Tmax = a.Tmax; t.scale = a.scale;
   t.o_sc1 = 1; t.staged = stage;
-  const unsigned* qf = c.lflags + MBF_QKV + kvh * 32;
+  // the Q items that hold this kv head's rows: row tiles [32 kvh, +32) (q), [256 + 8 kvh, +8) (k), [320 + 8 kvh, +8) (v); tile t belongs to the
+  // workgroups 2 (t / 3) and 2 (t / 3) + 1 (the two K halves).  Three contiguous flag ranges, widened to 16-byte granules.
+  const unsigned* qf = c.lflags + MBF_QKV;
+  const int tq = 32 * kvh, tk = 256 + 8 * kvh, tv = 320 + 8 * kvh;
+  const int q_lo = (2 * (tq / 3)) & ~3, q_n = 2 * ((tq + 31) / 3) + 2 - q_lo;
+  const int k_lo = (2 * (tk / 3)) & ~3, k_n = 2 * ((tk + 7) / 3) + 2 - k_lo;
+  const int v_lo = (2 * (tv / 3)) & ~3, v_n = 2 * ((tv + 7) / 3) + 2 - v_lo;
   const float* ws = a.qkv_ws;
   MB_IDS
   const int B = a.B;
   const unsigned epoch = c.epoch;
   unsigned* err = a.err;
   unsigned long long* tr = c.tr;
+  const int abl = a.abl;
   auto hook = [=]() __attribute__((always_inline)) {
-    if (wave == 4) mb_wait_flags(qf, 24, epoch, err, 31u, lane);
+    if (wave == 4 && !(abl & 16)) {
+      mb_wait_flags(qf + q_lo, q_n, epoch, err, 31u, lane);
+      mb_wait_flags(qf + k_lo, k_n, epoch, err, 37u, lane);
+      mb_wait_flags(qf + v_lo, v_n, epoch, err, 38u, lane);
+    }
     __builtin_amdgcn_s_barrier();
     if (tr && tid == 0) tr[2] = wall_clock64();
     constexpr int NV4 = (G + 2) * DH / 4;
@@ -380,7 +407,7 @@ __device__ __forceinline__ void mb_attention(const MbCtx& c, int layer, int unit
     }
     lds_barrier();
   };
-  attn_dec_body<DH, G, DS>(t, c.xreg, bx, kvh, b, hook);
+  if (!(abl & 8)) attn_dec_body<DH, G, DS>(t, c.xreg, bx, kvh, b, hook);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its written-through stores of the output have left
   __builtin_amdgcn_s_barrier();
   if (tid == 0) mb_raise(c.lflags + MBF_AO + (kvh >> 1) * 64 + (b * SL + bx) * 2 + (kvh & 1), epoch);
@@ -390,7 +417,7 @@ template <int BT, int DS>
 __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   MbCtx c;
-  c.a = &a; c.smem = smem; c.xreg = smem + MB_WBYTES;
+  c.a = &a; c.smem = smem; c.xreg = smem + MbCfg<BT>::WBYTES;
   c.wg = (int)blockIdx.x;
   c.epoch = *a.epoch;
   MB_IDS
@@ -406,12 +433,12 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
   }
   MbStream s;
   s.layers = a.layers; s.n_layers = a.n_layers; s.wg = wg; s.wave = wave < 4 ? wave : 0;
-  s.ring = smem + (wave < 4 ? wave : 0) * (MB_RING * 4096);
-  s.il = 0; s.iph = mb_has_item(wg, 0) ? 0 : 1; s.islot = 0; s.cslot = 0; s.idone = 0;
+  s.ring = smem + (wave < 4 ? wave : 0) * (MbCfg<BT>::RING * 4096);
+  s.il = 0; s.iph = mb_has_item(wg, s.wave, 0) ? 0 : 1; s.islot = 0; s.cslot = 0; s.idone = 0;
   mb_stream_setup(s);
   if (wave < 4) {
 #pragma unroll 1
-    for (int i = 0; i < MB_DEPTH; ++i) mb_stream_issue(s, voff4, voff14);
+    for (int i = 0; i < MbCfg<BT>::RING; ++i) mb_stream_issue<MbCfg<BT>::RING>(s, voff4, voff14);
   }
   for (int l = 0; l < a.n_layers; ++l) {
     const PcyLayerWeightsDev lw = a.layers[l];
@@ -420,12 +447,10 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
     c.tr = a.trace ? a.trace + ((size_t)l * 256 + wg) * 16 : nullptr;
     MB_T(0)
     // ---- Q ----
-    if (wg < MB_Q_WGS) {
-      const int rq = wg >> 1, kh = wg & 1;
-      const int grp = rq < 64 ? rq >> 3 : rq < 80 ? (rq - 64) >> 1 : (rq - 80) >> 1;
-      const int idx = rq < 64 ? (rq & 7) * 2 + kh : rq < 80 ? 16 + (rq & 1) * 2 + kh : 20 + (rq & 1) * 2 + kh;
+    {
+      const int kh = wg & 1;
       mb_gemv_phase<1, BT, 0>(c, s, voff4, voff14, 16, a.xn + kh * 2048, MBD, l ? c.lflags + MBF_XN : nullptr, B, 30u,
-                              a.qkv_ws + (size_t)kh * B * MBNQ, MBNQ, rq * 64, c.lflags + MBF_QKV + grp * 32 + idx, 13);
+                              a.qkv_ws + (size_t)kh * B * MBNQ, MBNQ, (wg >> 1) * 48, c.lflags + MBF_QKV + wg, 13, 3);
     }
     MB_T(1)
     // ---- A ----
@@ -499,7 +524,7 @@ int pcy_decode_mb_ds(int B) { return B >= 16 ? 128 : 64; }
 bool pcy_decode_mb_fits(int B, int Tmax) {
   const int ds = pcy_decode_mb_ds(B);
   const size_t need = ((attn_dec_smem_bytes(4, ds, 128, Tmax) + 15) & ~(size_t)15) + (size_t)(4 + 2) * 128 * 2;
-  return B >= 9 && B <= 32 && need <= (size_t)MB_XBYTES;
+  return B >= 9 && B <= 32 && need <= (size_t)(B <= 16 ? MbCfg<1>::XBYTES : MbCfg<2>::XBYTES);
 }
 
 bool pcy_launch_decode_step_mb(hipStream_t s, int device, const PcyMbArgs& a, int n_cu) {

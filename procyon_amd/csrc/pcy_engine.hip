@@ -422,6 +422,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     ma.pos_dev = st->pos; ma.cos_t = (const bf16_t*)m->rope_cos; ma.sin_t = (const bf16_t*)m->rope_sin; ma.keep = st->keep; ma.ld_keep = kv->Tmax;
     ma.B = B; ma.Tmax = kv->Tmax; ma.scale = 1.0f / sqrtf((float)dh); ma.rms_eps = m->rms_eps; ma.rms_cast = m->rms_cast;
     ma.flags = c->mb_flags; ma.epoch = c->mb_sync; ma.err = c->xwg_err;
+    { const char* e = getenv("PCY_MB_ABL"); ma.abl = e ? atoi(e) : 0; }
     if (getenv("PCY_MC_TRACE")) {   // measurement aid (tools/bench_decode_mb.py): in-kernel time stamps, [layer][workgroup][16]
       if (!g_mc_trace) { hipMalloc(&g_mc_trace, 2 * 128 * 256 * 16 * 8); hipMemset(g_mc_trace, 0, 2 * 128 * 256 * 16 * 8); }
       ma.trace = g_mc_trace + (size_t)128 * 256 * 16;

@@ -255,6 +255,7 @@ struct PcyMbArgs {
   const unsigned* epoch;                            // device word advanced once per step that runs this launch
   unsigned* err;                                    // watchdog word
   unsigned long long* trace;                        // measurement aid: [layer][256][16] time stamps (nullptr: none)
+  int abl;                                          // timing ablations (PCY_MB_ABL, tools only: the results are wrong)
 };
 size_t pcy_decode_mb_flag_words();
 int pcy_decode_mb_ds(int B);                        // output columns per attention workgroup of the B-row step (the twin must use the same)

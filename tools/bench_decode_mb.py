@@ -74,6 +74,22 @@ def timing():
     for B in [int(x) for x in os.environ.get("BATCHES", "10,16,20,32").split(",")]:
         emb = (torch.randn(B, T, 4096, device="cuda") * 0.02).bfloat16()
         row = []
+        abls = [int(v) for v in os.environ.get("ABLS", "").split(",") if v]
+        for abl in abls:       # timing ablations of the fused step (PCY_MB_ABL; eager launches: the value is a kernel argument)
+            os.environ["PCY_MB_ABL"] = str(abl)
+            set_disable("")
+            cache = eng.new_cache(B, T + N)
+            st = GenState(B, kw["vocab"], N, "cuda")
+            logits, _ = eng.prefill(emb, None, cache, "last")
+            st.logits.copy_(logits); st.pos.fill_(T)
+            eng.pick(cache, st, B, advance_pos=False)
+            eng.greedy_steps(cache, st, B, 4, use_graph=False)
+            ctx.timer_start(); eng.greedy_steps(cache, st, B, 32, use_graph=False); ms = ctx.timer_stop() / 32
+            ctx.sync()
+            print(f"B={B:2d} ABL={abl:3d}: {ms:.3f} ms/step (eager)", flush=True)
+        os.environ.pop("PCY_MB_ABL", None)
+        if abls:
+            continue
         for mode in ("new", "old"):
             set_disable("" if mode == "new" else "decode_mb_step")
             cache = eng.new_cache(B, T + N)
@@ -82,8 +98,9 @@ def timing():
             st.logits.copy_(logits); st.pos.fill_(T)
             eng.pick(cache, st, B, advance_pos=False)
             if os.environ.get("PCY_MC_TRACE"): eng.greedy_steps(cache, st, B, 1, use_graph=False)
-            eng.greedy_steps(cache, st, B, 4)
-            ctx.timer_start(); eng.greedy_steps(cache, st, B, 64); ms = ctx.timer_stop() / 64
+            ug = os.environ.get("EAGER", "0") == "0"
+            eng.greedy_steps(cache, st, B, 4, use_graph=ug)
+            ctx.timer_start(); eng.greedy_steps(cache, st, B, 64, use_graph=ug); ms = ctx.timer_stop() / 64
             ctx.sync()
             row.append(ms)
             if mode == "new" and os.environ.get("PCY_MC_TRACE"):
