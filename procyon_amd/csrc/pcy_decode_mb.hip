@@ -56,6 +56,9 @@ template <int BT> struct MbCfg {
   static constexpr int SX = 8;                          // x steps in the ring
 };
 constexpr int MB_SMEM = 160 * 1024;
+#ifndef MB_NLW
+#define MB_NLW 1   // x loader waves (1: wave 4 alone; 4 measured slower: 4.1 -> 4.6 ms per 10-row step, 5.1 -> 5.8 at 32 rows)
+#endif
 // arrival flags of one layer (words; every group starts on a 256-byte line)
 constexpr int MBF_XN = 0;      // [32]      F2 of the previous layer: row b's xn is there
 constexpr int MBF_QKV = 64;    // [256]     Q items
@@ -103,6 +106,7 @@ struct MbStream {
   int il, iph, itile, intiles, iK, irt2, islot, idone;
   const bf16_t* ibase;        // first element of the phase's item for this wave: W + r0 * K + kbeg
   int cslot;                  // ring slot of the next tile to be consumed
+  int wdef;                   // timing ablation: weight copies with the default cache policy instead of nt
 };
 // Q: 384 row tiles x 2 K halves = 768 wave items = 3 per workgroup (waves 0..2: tiles 3 (wg >> 1) + wave of half wg & 1) -- every CU streams in
 // every phase but G (896 gate/up pairs = 3.5 per workgroup: 224 workgroups of 4).  A CU draws ~25 GB/s from HBM whatever it has in flight, so a
@@ -134,7 +138,8 @@ __device__ __forceinline__ void mb_stream_issue(MbStream& s, const int (&voff4)[
   const bool k4 = s.iK == MBD;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((mb_gptr_t)(p + (k4 ? voff4[q] : voff14[q])), (mb_lds_ptr_t)(dst + q * 1024), 16, 0, 2 /* nt */);
+    if (s.wdef) __builtin_amdgcn_global_load_lds((mb_gptr_t)(p + (k4 ? voff4[q] : voff14[q])), (mb_lds_ptr_t)(dst + q * 1024), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((mb_gptr_t)(p + (k4 ? voff4[q] : voff14[q])), (mb_lds_ptr_t)(dst + q * 1024), 16, 0, 2 /* nt */);
   s.islot = s.islot + 1 == RING ? 0 : s.islot + 1;
   if (!s.idone && ++s.itile == s.intiles) mb_stream_advance(s);
 }
@@ -174,31 +179,52 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // x loaders: waves 4 .. 4 + NLW - 1; loader lw copies the row groups g = lw, lw + NLW, ... (rows 4 g .. 4 g + 3; batch tile g / 4) of every
+  // step.  Row groups beyond the batch are not copied at all (their MFMA columns are never stored).
+  constexpr int NLW = MB_NLW;
+  const int lw = wave - 4;
+  int nlw = 0;                                       // copies per step of this loader wave
+#pragma unroll
+  for (int g = 0; g < NX; ++g) nlw += (lw >= 0 && lw < NLW && g % NLW == lw && g * 4 < B) ? 1 : 0;
   auto issue_x = [&](int ss) __attribute__((always_inline)) {
     char* xb = xring + (ss % SX) * (BT * 4096);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int bt = i >> 2, q = i & 3;
-      const int row = q * 4 + (lane >> 4);
-      int b = bt * 16 + row;
+    for (int g = 0; g < NX; ++g) {
+      if (g % NLW != lw || g * 4 >= B) continue;
+      const int row = (g & 3) * 4 + (lane >> 4);
+      int b = (g >> 2) * 16 + row;
       b = b < B ? b : B - 1;
       const bf16_t* src = x + (size_t)b * ldx + ss * 128 + ((lane & 15) ^ row) * 8;
       if (abl & 4) continue;
-      if (abl & 1) __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + bt * 4096 + q * 1024), 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + bt * 4096 + q * 1024), 16, 0, 16 /* sc1 */);
+      if (abl & 1) __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + g * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + g * 1024), 16, 0, 16 /* sc1 */);
     }
   };
   if (wave == 4) {
     if (wait_f && !(abl & 16)) mb_wait_flags(wait_f, wait_n, c.epoch, c.a->err, wait_code, lane);
     if (c.tr && lane == 0) c.tr[t_ready] = wall_clock64();
+  }
+  if (NLW > 1) __builtin_amdgcn_s_barrier();   // the inputs are there: every loader wave may start
+  if (lw >= 0 && lw < NLW) {
     for (int i = 0; i < SX - 1 && i < nsteps; ++i) issue_x(i);
   }
   for (int ss = 0; ss < nsteps; ++ss) {
     if (wave < nact) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - RT) * 4) : "memory");     // this step's tile(s) have landed
-    } else if (wave == 4) {
-      if (ss + SX - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * NX) : "memory");   // x(ss) has landed
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (lw >= 0 && lw < NLW) {
+      if (ss + SX - 1 <= nsteps && !(abl & 4)) {                                  // this wave's copies of x(ss) have landed
+        switch (nlw) {
+          case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 1) : "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 2) : "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 3) : "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 4) : "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 5) : "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 6) : "memory"); break;
+          case 7: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 7) : "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SX - 2) * 8) : "memory"); break;
+          default: break;
+        }
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // x(ss) is there for everybody; slot (ss - 1) % SX is free
     if (wave < nact) {
@@ -227,7 +253,7 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) mb_stream_issue<RING>(s, voff4, voff14);
       s.cslot = RT == 2 ? (cs1 + 1 == RING ? 0 : cs1 + 1) : cs1;
-    } else if (wave == 4) {
+    } else if (lw >= 0 && lw < NLW) {
       if (ss + SX - 1 < nsteps) issue_x(ss + SX - 1);
     }
   }
@@ -434,7 +460,7 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
   MbStream s;
   s.layers = a.layers; s.n_layers = a.n_layers; s.wg = wg; s.wave = wave < 4 ? wave : 0;
   s.ring = smem + (wave < 4 ? wave : 0) * (MbCfg<BT>::RING * 4096);
-  s.il = 0; s.iph = mb_has_item(wg, s.wave, 0) ? 0 : 1; s.islot = 0; s.cslot = 0; s.idone = 0;
+  s.il = 0; s.iph = mb_has_item(wg, s.wave, 0) ? 0 : 1; s.islot = 0; s.cslot = 0; s.idone = 0; s.wdef = (a.abl & 64) ? 1 : 0;
   mb_stream_setup(s);
   if (wave < 4) {
 #pragma unroll 1

@@ -204,9 +204,16 @@ bool decode_nb_step_enabled() { return !pcy_off("decode_nb_step"); }
 // PCY_DISABLE=decode_mb_step: batches of 9..32 rows run launch by launch (seven per layer) instead of the mid-batch step (pcy_decode_mb.hip:
 // the same work items as phases of ONE launch) -- same bits, tests compare the two.
 bool decode_mb_step_enabled() { return !pcy_off("decode_mb_step"); }
+// (17..32 rows -- two batch tiles -- stay on the launches: there the activations every CU has to fetch per weight byte double, every byte a CU
+// loads goes through the same ~25 GB/s, and the fused step measured 5.0 / 5.3 ms at 20 / 32 rows against 4.4 / 4.6 launch by launch;
+// PCY_MB_MAX=32 runs them fused all the same: tests, tools)
+int decode_mb_max_rows() {
+  const char* e = getenv("PCY_MB_MAX");
+  return e ? atoi(e) : 16;
+}
 int decode_mode() {
   return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
-         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0);
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16);
 }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 // geometry of the small-batch step: Llama-3-8B, 256 CUs
@@ -216,7 +223,7 @@ bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
 }
 // geometry of the mid-batch step (9..32 rows): the same model and chip
 bool decode_mb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
-  return B >= 9 && B <= 32 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 && c->n_cu >= 256;
+  return B >= 9 && B <= 32 && B <= decode_mb_max_rows() && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 && c->n_cu >= 256;
 }
 // ... for the small-batch step: the exchange costs more there than the K reads it saves until much longer caches (t ~ 800: 2 / 4 rows
 // 2.935 / 3.385 ms per step with the split, 2.868 / 3.287 without; t ~ 1540: 3.158 / 3.653 with, 3.180 / 3.632 without)

@@ -22,7 +22,7 @@ Round 4: the same runs on DAMPED weights (`synth.damp_residual_branches`, residu
 f3_llama8b_damped_T64.npz, f4_esm650m_damped_1024.npz -- where the bf16 oracle agrees with the fp32 truth on (nearly) every argmax, so the
 GPU test can assert token agreement between the HIP path and the bf16 ORACLE itself and a bound on err(HIP, oracle_bf16).
 
-    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256] [split]
+    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256] [split] [rows10] [config3]
 """
 from __future__ import annotations
 
@@ -186,6 +186,77 @@ def make_llama_leftpad():
          top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values, top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
 
 
+def make_llama_rows10():
+    """f7 (round 6): TEN ragged left-padded rows (pads 0 .. 27 of 64 slots), 16 teacher-forced cached steps in the reference's compat mode
+    (Q1 / Q2) at FULL depth -- the batch of the reference's beam-10 callers (scripts/caption_bulk.py:193-194, evaluate/framework/procyon.py:72-76),
+    which runs on the mid-batch decode step (pcy_decode_mb.hip); the first 5 / 8 rows as batches of their own hold the small-batch step
+    (pcy_decode_nb.hip) to the same oracle (rows are independent of their batch mates)."""
+    sd = synth.llama_state_dict(**LLAMA)
+    geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
+    B, T, ndec = 10, 64, 16
+    g = torch.Generator().manual_seed(7171)
+    ids = torch.randint(0, 128000, (B, T), generator=g)
+    npad = [0, 21, 3, 0, 11, 27, 8, 0, 16, 5]
+    mask = torch.ones(B, T)
+    for b, n in enumerate(npad):
+        mask[b, :n] = 0
+        ids[b, :n] = 128001
+    t0 = time.time()
+    lb, toks = llama_run_rows(sd, geom, ids, mask, torch.bfloat16, ndec)
+    print(f"  rows10 bf16 oracle {time.time() - t0:.0f}s", flush=True)
+    t0 = time.time()
+    lf, _ = llama_run_rows(sd, geom, ids, mask, torch.float32, ndec, forced=toks)
+    print(f"  rows10 fp32 truth {time.time() - t0:.0f}s", flush=True)
+    V = lb.shape[-1]
+    cols = set(range(0, V, 127))
+    for s in range(ndec + 1):
+        for b in range(B):
+            cols |= set(lf[s, b].topk(8).indices.tolist()) | set(lb[s, b].float().topk(8).indices.tolist())
+    cols = torch.tensor(sorted(cols))
+    top_f, top_b = lf.topk(8, dim=-1), lb.float().topk(8, dim=-1)
+    err_full = torch.tensor([[rel(lb[s, b].float(), lf[s, b]) for b in range(B)] for s in range(ndec + 1)])
+    print(f"  rows10: bf16-vs-fp32 err mean {float(err_full.mean()):.3e} max {float(err_full.max()):.3e}\n   argmax agree {(lb.float().argmax(-1) == lf.argmax(-1)).float().mean():.3f}")
+    save("f7_llama8b_rows10_T64", ids=ids.to(torch.int32), mask=mask.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
+         logits_bf16=lb[..., cols], logits_fp32=lf[..., cols], norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
+         top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values, top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
+
+
+def make_config3_rows():
+    """f8 (round 6): BASELINE configs[3] 4b at full geometry -- 32 ragged rows (T uniform in [128, 512], seed 7, left-padded to 512), compat mode.
+    The oracle runs THREE sampled rows (0, 13, 31: rows are independent) for 8 teacher-forced steps; the GPU test runs all 32 rows as one batch
+    (prefill + the 32-row decode step) and compares those rows."""
+    sd = synth.llama_state_dict(**LLAMA)
+    geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
+    B, T, ndec = 32, 512, 8
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(128, 513, (B,), generator=g)
+    ids = torch.randint(0, 128000, (B, T), generator=g)
+    mask = torch.ones(B, T)
+    for b in range(B):
+        n = T - int(lens[b])
+        mask[b, :n] = 0
+        ids[b, :n] = 128001
+    rows = torch.tensor([0, 13, 31])
+    t0 = time.time()
+    lb, toks = llama_run_rows(sd, geom, ids[rows], mask[rows], torch.bfloat16, ndec)
+    print(f"  config3 rows bf16 oracle {time.time() - t0:.0f}s", flush=True)
+    t0 = time.time()
+    lf, _ = llama_run_rows(sd, geom, ids[rows], mask[rows], torch.float32, ndec, forced=toks)
+    print(f"  config3 rows fp32 truth {time.time() - t0:.0f}s", flush=True)
+    V = lb.shape[-1]
+    cols = set(range(0, V, 127))
+    for s in range(ndec + 1):
+        for b in range(len(rows)):
+            cols |= set(lf[s, b].topk(8).indices.tolist()) | set(lb[s, b].float().topk(8).indices.tolist())
+    cols = torch.tensor(sorted(cols))
+    top_f, top_b = lf.topk(8, dim=-1), lb.float().topk(8, dim=-1)
+    err_full = torch.tensor([[rel(lb[s, b].float(), lf[s, b]) for b in range(len(rows))] for s in range(ndec + 1)])
+    print(f"  config3 rows: bf16-vs-fp32 err mean {float(err_full.mean()):.3e} max {float(err_full.max()):.3e}")
+    save("f8_config3_rows_T512", ids=ids.to(torch.int32), mask=mask.to(torch.int32), rows=rows.to(torch.int32), tokens=toks.to(torch.int32), cols=cols.to(torch.int32),
+         logits_bf16=lb[..., cols], logits_fp32=lf[..., cols], norm_fp32=lf.double().norm(dim=-1).float(), err_bf16_full=err_full.float(),
+         top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values, top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
+
+
 def make_llama(damped=False, long=False):
     global NDEC
     if long:       # round 5: the headline's generation length (256 tokens) at T = 512 -> f1_llama8b_T512_N256.npz
@@ -306,3 +377,7 @@ if __name__ == "__main__":
         make_llama(long=True)
     if "split" in what:
         make_split()
+    if "rows10" in what:
+        make_llama_rows10()
+    if "config3" in what:
+        make_config3_rows()

@@ -1,0 +1,151 @@
+"""Round 6: the mid-batch decode step (procyon_amd/csrc/pcy_decode_mb.hip) -- every decoder layer of a 9..32-row decode step in ONE launch
+(every caller of the reference generates with beam 10 or 20: /root/reference/scripts/caption_bulk.py:193-194,
+/root/reference/procyon/evaluate/framework/procyon.py:72-76) -- and the beam search's one-prefill-per-prompt
+(/root/reference/procyon/model/model_unified.py:751-768 replicates the prompt x beam BEFORE the prefill)."""
+import pytest
+import torch
+
+from conftest import pcy_disable, rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+KW = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=8, ffn=14336)
+
+
+@pytest.fixture(scope="module")
+def eng2():
+    from procyon_amd import synth
+    from procyon_amd.engine import LlamaConfig, LlamaEngine
+    return LlamaEngine(synth.llama_state_dict(**KW), LlamaConfig(**KW, max_pos=2048))
+
+
+@pytest.mark.parametrize("B,T,N", [(9, 300, 7), (10, 100, 8), (11, 77, 5), (12, 64, 5), (13, 50, 5), (15, 40, 5), (16, 90, 5), (10, 800, 5), (16, 1100, 4),
+                                    (17, 300, 5), (20, 200, 6), (24, 33, 4), (32, 300, 5), (32, 1100, 3)])
+def test_decode_mb_step_bit_identical(eng2, monkeypatch, B, T, N):
+    """decode_step_mb_kernel (all layers of a B-row step in one launch: the batched path's work items -- skinny-MFMA GEMV tiles with their K
+    splits, the decode attention, the K-split finish + RMSNorm -- as phases of one persistent kernel, flag hand-overs, weight rings that run
+    ahead across the phases) against the launch-per-stage step (PCY_DISABLE=decode_mb_step: seven launches per layer): logits of every step,
+    tokens and the appended K / V rows must be BIT-identical, eager and under hipGraph replay (the second replayed run starts at the flag /
+    epoch state the first one left).  9..15 rows: attention units of 64 columns; 16: 128 columns, one batch tile; 17..32 (PCY_MB_MAX=32: by
+    default these stay on the launches, which are faster there): two batch tiles.  No watchdog (Context.sync raises)."""
+    from procyon_amd.engine import Context, GenState
+    monkeypatch.setenv("PCY_MB_MAX", "32")
+    torch.manual_seed(B * 1000 + T)
+    emb = (torch.randn(B, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(step, use_graph):
+        pcy_disable(monkeypatch, "" if step else "decode_mb_step")
+        cache = eng2.new_cache(B, T + N + 2)
+        st = GenState(B, KW["vocab"], N + 2, "cuda")
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng2.pick(cache, st, B, advance_pos=False)
+        out = []
+        for i in range(N):
+            if i % 3 == 2:
+                continue
+            eng2.greedy_steps(cache, st, B, 2 if i % 3 == 1 else 1, use_graph=use_graph)
+            out.append(st.logits.clone())
+        Context.get().sync()
+        return torch.stack(out).cpu(), st.tokens_out[:, :N + 1].cpu(), st.logprob.cpu().clone(), cache.k[:, :, :, T:T + N].cpu(), cache.v[:, :, :, T:T + N].cpu()
+
+    ref = run(False, False)
+    assert torch.isfinite(ref[0].float()).all()
+    for use_graph in (False, True, True):
+        got = run(True, use_graph)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), (B, T, use_graph)
+
+
+def test_decode_mb_default_covers_9_to_16_rows(eng2, monkeypatch):
+    """Without PCY_MB_MAX the fused step takes 9..16 rows and leaves 17..32 to the launches; either way the results are the launches' bits, and
+    a step of another batch size in between (its own epoch / flag state is shared: a flag holds the epoch of the step that raised it) changes
+    nothing."""
+    from procyon_amd.engine import Context, GenState
+    monkeypatch.delenv("PCY_MB_MAX", raising=False)
+    torch.manual_seed(6)
+
+    def run(B, T, step):
+        pcy_disable(monkeypatch, "" if step else "decode_mb_step")
+        emb = (torch.randn(B, T, 4096, generator=torch.Generator().manual_seed(B)) * 0.02).to(BF).cuda()
+        cache = eng2.new_cache(B, T + 6)
+        st = GenState(B, KW["vocab"], 6, "cuda")
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng2.pick(cache, st, B, advance_pos=False)
+        eng2.greedy_steps(cache, st, B, 3)
+        Context.get().sync()
+        return st.logits.cpu().clone()
+
+    ref10, ref20, ref12 = run(10, 90, False), run(20, 60, False), run(12, 70, False)
+    for _ in range(2):
+        assert torch.equal(run(10, 90, True), ref10)
+        assert torch.equal(run(20, 60, True), ref20)
+        assert torch.equal(run(12, 70, True), ref12)
+
+
+def test_decode_mb_beam10_loop_bit_identical(eng2, monkeypatch):
+    """The reference's production call: diverse beam search, beam 10 in groups of 2 (scripts/caption_bulk.py:193-194, :130) = a 10-row
+    decode step + pcy_beam_step + the K/V reorder of every step, as the replayed chain (pcy_llama_beam_steps).  One launch per step vs the
+    seven launches per layer: tokens, running scores, the parent chain and the logits record equal."""
+    from procyon_amd.engine import BeamState, Context, GenState
+    torch.manual_seed(10)
+    T, steps, beam, group = 120, 14, 10, 2
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda().repeat(beam, 1, 1).contiguous()
+
+    def run(step):
+        pcy_disable(monkeypatch, "" if step else "decode_mb_step")
+        cache = eng2.new_cache(beam, T + steps + 2)
+        logits, _ = eng2.prefill(emb, None, cache, "last")
+        bs = BeamState(1, beam, steps, 2, prompt_len=T, device="cuda")
+        st = GenState(beam, KW["vocab"], 1, "cuda")
+        st.pos, st.next_tok = bs.pos, bs.next_tok
+        st.c.pos, st.c.next_tok = bs.pos.data_ptr(), bs.next_tok.data_ptr()
+        rec = torch.zeros(steps, beam, KW["vocab"], dtype=BF, device="cuda")
+        rec[0].copy_(logits)
+        eng2.beam_step(logits.contiguous(), bs, group, 0.8)
+        eng2.kv_reorder(cache, bs.src, T)
+        eng2.beam_steps(cache, st, bs, group, 0.8, rec, steps - 1)
+        out, n = bs.tokens()
+        Context.get().sync()
+        return out.cpu(), bs.cur.cpu().clone(), bs.anc[:n].cpu().clone(), rec[:n].cpu()
+
+    ref, got = run(False), run(True)
+    for x, y in zip(got, ref):
+        assert torch.equal(x, y)
+
+
+def test_beam_search_prefills_each_prompt_once(monkeypatch):
+    """`_generate_beam_search` (model_unified.py:740-842) replicates every prompt x beam before the prefill (:751-752).  The mirror prefills
+    each prompt once into row b of the B x beam-row cache, copies its K / V rows to the rows of its beams (pcy_kv_reorder with the source map
+    r -> r // beam) and repeats its last-row logits.  Against the replicated prefill (PCY_DISABLE=beam_prefill_once), through the public
+    `generate(method="beam")` on a two-prompt batch (ragged: the shorter prompt is left-padded): the step-0 logits of a beam are those of its
+    prompt -- bit for bit when both prefills take the same GEMM kernels, to bf16 noise otherwise (a beam x larger token count may select other
+    tiles) -- and then the whole search is the same search (tokens, scores, logits record)."""
+    from procyon_amd import synth
+    from procyon_amd import synthetic_model as SM
+    from procyon_amd.engine import Context
+    model = SM.build("small", device="cuda", max_new_tokens=32)
+    prot = synth.protein_tokens([90, 41], seed=3)
+    instr = ["w5 w6 <|protein|> w7 [ANSWER]", "w1 w2 <|protein|> and w3 w4 w8 w9 w2 w3 [ANSWER]"]
+    inputs = lambda: {"data": {"seq": prot, "seq_idx": torch.arange(2), "text": [], "drug": None},
+                      "input": {"seq": [[0], [1]], "text": [[], []], "drug": None},
+                      "target": {"seq": None, "text": None, "drug": None}, "instructions": list(instr)}
+    kw = dict(max_len=10, method="beam", beam_size=6, beam_group_size=2, diversity_penalty=0.8)
+
+    def run(once):
+        pcy_disable(monkeypatch, "" if once else "beam_prefill_once")
+        tokens, scores, logits, _ = model.generate(inputs(), **kw)
+        Context.get().sync()
+        return tokens, scores, logits
+
+    o1, c1, l1 = run(True)
+    o0, c0, l0 = run(False)
+    assert o1.shape == o0.shape and l1.shape == l0.shape and o1.shape[:2] == (2, 6)
+    e0 = rel_err(l1[:, :, 0].float(), l0[:, :, 0].float())
+    assert e0 < 2e-2, e0
+    if torch.equal(l1[:, :, 0], l0[:, :, 0]):           # same prefill bits -> the same search
+        assert torch.equal(o1, o0) and torch.equal(c1, c0) and torch.equal(l1, l0)
+    else:                                               # other GEMM tiles in the beam x larger prefill: the same search up to ties inside the noise
+        assert (o1[:, :, 0] == o0[:, :, 0]).all()
+        assert rel_err(c1.float(), c0.float()) < 5e-2
