@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 8
+#define PCY_ABI_VERSION 9
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -115,6 +115,14 @@ int pcy_retrieval_topk(pcy_ctx*, const void* query, int Q, const void* targets, 
 int pcy_retrieval_scores_f32(pcy_ctx*, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, float* sims_out);
 int pcy_retrieval_topk_f32(pcy_ctx*, const float* query, int Q, const void* targets, int targets_bf16, int N, int D, int k, int32_t* idx_out,
                            float* score_out);
+
+/* QA read-out (reference: procyon/data/inference_utils.py:582-604, procyon/training/train_utils.py:1048-1070: `preds = logits.softmax(dim=-1)`
+ * at the answer row, then the yes / no columns or the argmax).  logits [rows, V] bf16 (is_f32 = 0: fp32 statistics, ONE rounding of
+ * exp(x - max) / sum, torch.softmax on a bf16 tensor) or fp32 (is_f32 = 1).  Optional outputs (NULL = not wanted): probs_out [rows, V] in
+ * the logits' dtype; yes_no_out [rows, 2] fp32 = the stored probabilities of yes_id / no_id; argmax_out [rows] int32 = argmax of the stored
+ * probabilities, lowest index on ties. */
+int pcy_qa_probs(pcy_ctx*, const void* logits, int is_f32, int rows, int V, int yes_id, int no_id, void* probs_out, float* yes_no_out,
+                 int32_t* argmax_out);
 
 /* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path"; the reference has no fp8 counterpart) ----
  * Per-row symmetric OCP e4m3 quantisation of a bf16 matrix x[rows,K] (ldx elements between rows, K % 8 == 0):

@@ -258,8 +258,8 @@ def create_batched_input_retrieval(input_descriptions: List[str], data_args, tas
 # ---------------------------------------------------------------------------------------------- QA read-out
 def get_qa_logits_inference(model_out, padding_token=None, answer_token=None):
     """Vocabulary distribution at the answer position and the label token there (inference_utils.py:582-604).  The answer
-    position is (index after the last [ANSWER]) - 1, the causal shift; the engine's `forward` already returns the logits of
-    exactly that row ([B,1,V], `answer_positions`), a full [B,T,V] tensor is indexed the reference's way."""
+    position is (index after the last [ANSWER]) - 1, the causal shift; the engine's `forward` has computed the logits of exactly
+    that row (`outputs.answer_logits` [B,1,V], `answer_positions`), a full [B,T,V] tensor is indexed the reference's way."""
     toks = model_out["text_toks"].detach().clone().cpu()
     if padding_token is not None:
         inds = get_final_tokens(toks, padding_token=padding_token)
@@ -269,11 +269,14 @@ def get_qa_logits_inference(model_out, padding_token=None, answer_token=None):
         raise ValueError("One of padding_token or answer_token for get_qa_metrics must not be None")
     rows = torch.arange(toks.shape[0])
     y_toks = toks[rows, inds]
-    preds = model_out["outputs"].logits.softmax(dim=-1).detach().clone().cpu()
-    if preds.shape[1] == 1:
-        assert torch.equal(model_out["answer_positions"].cpu(), inds - 1), "logits row is not the answer position"
-        pred_toks = preds[:, 0]
+    outputs = model_out["outputs"]
+    ans = getattr(outputs, "answer_logits", None)
+    if ans is not None and torch.equal(model_out["answer_positions"].cpu(), inds - 1):
+        # the engine computed exactly the rows the reader wants: softmax over the vocabulary on the device (pcy_qa_probs)
+        from procyon_amd.engine import Context
+        pred_toks = Context.get().qa_probs(ans[:, 0])[0].cpu()
     else:
+        preds = outputs.logits.softmax(dim=-1).detach().clone().cpu()
         pred_toks = preds[rows, inds - 1]
     return pred_toks.detach().clone().cpu(), y_toks.detach().clone().cpu()
 

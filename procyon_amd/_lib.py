@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
-ABI_VERSION = 8
+ABI_VERSION = 9
 # pcy_debug_dispatch_count kinds
 DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8, DISPATCH_ATTN_FAST, _DISPATCH_UNUSED_7, DISPATCH_GEMM_MID, DISPATCH_ESM_GRAPH = range(10)
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "pcy_retrieval_topk": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp]),
     "pcy_retrieval_scores_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, vp]),
     "pcy_retrieval_topk_f32": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp]),
+    "pcy_qa_probs": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     # fp32 operator family (include/pcy.h: callers that never call .bfloat16())
     "pcy_f32_linear": (ci, [vp, vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci]),
     "pcy_f32_layernorm": (ci, [vp, vp, vp, vp, vp, ci, ci, C.c_float]),

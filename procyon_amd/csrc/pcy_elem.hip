@@ -1336,6 +1336,58 @@ void pcy_launch_embed_gather(hipStream_t s, const bf16_t* table, const int32_t* 
                              const int32_t* soft_map, bf16_t* out, int rows, int d) {
   if (rows > 0) hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(NT), 0, s, table, ids, soft, soft_map, out, d, (unsigned*)nullptr, (unsigned*)nullptr);
 }
+// QA read-out (reference: data/inference_utils.py:582-604, training/train_utils.py:1048-1070): probabilities over the vocabulary at the answer
+// row, `preds = logits.softmax(dim=-1)` on a tensor of the model dtype -- bf16: fp32 statistics, ONE rounding of exp(x - max) / sum (what
+// torch.softmax does on a bf16 tensor); fp32: the same in fp32.  One workgroup per row; optional outputs: the whole vector, the yes / no
+// columns (fp32 values of the stored probabilities), the argmax of the STORED probabilities (lowest index on ties, torch.argmax).
+constexpr int QA_NT = 1024;
+template <bool F32>
+__global__ __launch_bounds__(QA_NT) void qa_probs_kernel(const void* __restrict__ logits, int V, int yes_id, int no_id, void* __restrict__ probs_out,
+                                                         float* __restrict__ yes_no_out, int32_t* __restrict__ argmax_out) {
+  __shared__ float red[QA_NT / 64];
+  __shared__ int redi[QA_NT / 64];
+  const int b = blockIdx.x;
+  const bf16_t* lb = reinterpret_cast<const bf16_t*>(logits) + (size_t)b * V;
+  const float* lf = reinterpret_cast<const float*>(logits) + (size_t)b * V;
+  auto ld = [&](int i) { return F32 ? lf[i] : bf2f(lb[i]); };
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += QA_NT) m = fmaxf(m, ld(i));
+  m = block_max<QA_NT>(m, red);
+  float l = 0.f;
+  for (int i = threadIdx.x; i < V; i += QA_NT) l += expf(ld(i) - m);
+  l = block_sum<QA_NT>(l, red);
+  float best = -1.f; int besti = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += QA_NT) {
+    float p = expf(ld(i) - m) / l;
+    if (!F32) p = rbf(p);
+    if (probs_out) {
+      if (F32) reinterpret_cast<float*>(probs_out)[(size_t)b * V + i] = p;
+      else reinterpret_cast<bf16_t*>(probs_out)[(size_t)b * V + i] = f2bf(p);
+    }
+    if (yes_no_out && i == yes_id) yes_no_out[b * 2] = p;
+    if (yes_no_out && i == no_id) yes_no_out[b * 2 + 1] = p;
+    if (p > best) { best = p; besti = i; }       // (ascending i per thread: the first maximum)
+  }
+  // block arg-max, lowest index on ties
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; redi[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0 && argmax_out) {
+    for (int w = 1; w < QA_NT / 64; ++w)
+      if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+    argmax_out[b] = besti;
+  }
+}
+void pcy_launch_qa_probs(hipStream_t s, const void* logits, int is_f32, int rows, int V, int yes_id, int no_id, void* probs_out, float* yes_no_out,
+                         int32_t* argmax_out) {
+  if (rows <= 0) return;
+  if (is_f32) hipLaunchKernelGGL(qa_probs_kernel<true>, dim3(rows), dim3(QA_NT), 0, s, logits, V, yes_id, no_id, probs_out, yes_no_out, argmax_out);
+  else hipLaunchKernelGGL(qa_probs_kernel<false>, dim3(rows), dim3(QA_NT), 0, s, logits, V, yes_id, no_id, probs_out, yes_no_out, argmax_out);
+}
 __global__ void bump_word_kernel(unsigned* w) { *w += 1; }
 void pcy_launch_bump(hipStream_t s, unsigned* word) { hipLaunchKernelGGL(bump_word_kernel, dim3(1), dim3(1), 0, s, word); }
 

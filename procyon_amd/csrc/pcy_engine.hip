@@ -983,6 +983,15 @@ int pcy_retrieval_topk_f32(pcy_ctx* c, const float* query, int Q, const void* ta
   return check_launch("pcy_retrieval_topk_f32");
 }
 
+int pcy_qa_probs(pcy_ctx* c, const void* logits, int is_f32, int rows, int V, int yes_id, int no_id, void* probs_out, float* yes_no_out,
+                 int32_t* argmax_out) {
+  PCY_STICKY(c);
+  if (!logits || rows < 0 || V <= 0) return fail(1, "pcy_qa_probs: logits NULL or bad shape (rows %d, V %d)", rows, V);
+  if (yes_no_out && (yes_id < 0 || yes_id >= V || no_id < 0 || no_id >= V)) return fail(1, "pcy_qa_probs: yes / no token outside the vocabulary");
+  pcy_launch_qa_probs(c->stream, logits, is_f32, rows, V, yes_id, no_id, probs_out, yes_no_out, argmax_out);
+  return check_launch("pcy_qa_probs");
+}
+
 int pcy_mlp_forward(pcy_ctx* c, const pcy_mlp_desc* m, const void* x, int M, void* out) {
   PCY_STICKY(c);
   if (m->n_layers < 1 || m->n_layers > 8) return fail(1, "pcy_mlp_forward: n_layers %d", m->n_layers);

@@ -65,6 +65,8 @@ struct PcyMlpChainArgs {
   unsigned* err;                           // watchdog word
   unsigned long long* trace;               // measurement aid: [grid][16] time stamps (nullptr: none)
 };
+void pcy_launch_qa_probs(hipStream_t s, const void* logits, int is_f32, int rows, int V, int yes_id, int no_id, void* probs_out, float* yes_no_out,
+                         int32_t* argmax_out);   // softmax over the vocabulary at the QA answer row (+ yes / no columns, argmax)
 void pcy_launch_bump(hipStream_t s, unsigned* word);   // *word += 1 (tag counters, pcy_handover.h)
 // false = geometry not covered (nothing launched)
 bool pcy_launch_mlp_chain(hipStream_t s, const PcyMlpChainArgs& a, int n_cu);

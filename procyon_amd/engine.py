@@ -181,6 +181,21 @@ class Context:
         L.check(self.lib.pcy_retrieval_topk(self.h, _p(query), Q, _p(targets), N, D, k, _p(idx), _p(sc)), "pcy_retrieval_topk")
         return idx.long(), sc
 
+    def qa_probs(self, logits, yes_id=None, no_id=None, want_probs=True, want_argmax=False):
+        """The QA read-out on the device (pcy_qa_probs): `logits.softmax(dim=-1)` over the vocabulary for answer rows [rows, V] in the rows'
+        dtype (bf16: fp32 statistics, one rounding; fp32), optionally the yes / no columns [rows, 2] (fp32 values of the stored
+        probabilities) and the argmax of the stored probabilities -- data/inference_utils.py:582-604, training/train_utils.py:1048-1070.
+        -> (probs | None, yes_no | None, argmax int64 | None)"""
+        x = logits.to(self.device).contiguous()
+        assert x.dim() == 2 and x.dtype in (BF16, torch.float32), (x.shape, x.dtype)
+        rows, V = x.shape
+        probs = torch.empty_like(x) if want_probs else None
+        yn = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if yes_id is not None else None
+        am = torch.empty(rows, dtype=torch.int32, device=x.device) if want_argmax else None
+        L.check(self.lib.pcy_qa_probs(self.h, _p(x), int(x.dtype == torch.float32), rows, V, int(yes_id or 0), int(no_id or 0), _p(probs), _p(yn),
+                                      _p(am)), "pcy_qa_probs")
+        return probs, yn, None if am is None else am.long()
+
     def _ret_f32_args(self, query, targets):
         q = query.to(self.device, torch.float32).contiguous()
         t = targets.to(self.device)

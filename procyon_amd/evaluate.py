@@ -104,8 +104,8 @@ def get_final_tokens(text_toks, padding_token):
 
 def get_qa_scores(model_out, padding_token=None, answer_token=None):
     """`procyon/training/train_utils.py:1048-1070`: predicted token at the position before the label (causal shift) and
-    the label token.  The engine's `forward` returns the logits of exactly that row (`[B,1,V]`, position
-    `answer_positions` = label index - 1) instead of `[B,T,V]`; full-width logits are read the reference's way."""
+    the label token.  The engine's `forward` has computed the logits of exactly that row (`outputs.answer_logits` [B,1,V], position
+    `answer_positions` = label index - 1); full-width logits are read the reference's way."""
     y_tok_total = model_out["text_toks"].detach().clone().cpu()
     if padding_token is not None:
         y_inds = get_final_tokens(y_tok_total, padding_token=padding_token)
@@ -115,16 +115,18 @@ def get_qa_scores(model_out, padding_token=None, answer_token=None):
         raise ValueError("One of padding_token or answer_token for get_qa_metrics must not be None")
     rows = torch.arange(y_tok_total.shape[0])
     y_toks = y_tok_total[rows, y_inds]
-    logits = model_out["outputs"].logits
-    preds = logits.softmax(dim=-1).detach().clone().cpu()
-    pred_total = preds.argmax(dim=-1)
-    if pred_total.shape[1] == 1:
+    outputs = model_out["outputs"]
+    ans = getattr(outputs, "answer_logits", None)
+    if ans is not None:
         pos = model_out["answer_positions"].cpu()
         if not torch.equal(pos, y_inds - 1):
             raise ValueError("the engine returned logits at rows other than the label positions - 1")
-        pred_toks = pred_total[:, 0]
+        # softmax over the vocabulary + argmax of the stored probabilities on the device (pcy_qa_probs)
+        from .engine import Context
+        pred_toks = Context.get().qa_probs(ans[:, 0], want_probs=False, want_argmax=True)[2].cpu()
     else:
-        pred_toks = pred_total[rows, y_inds - 1]
+        preds = outputs.logits.softmax(dim=-1).detach().clone().cpu()
+        pred_toks = preds.argmax(dim=-1)[rows, y_inds - 1]
     return pred_toks.detach().clone().cpu(), y_toks.detach().clone().cpu()
 
 

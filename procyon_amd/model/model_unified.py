@@ -89,6 +89,76 @@ def special_token_ids(tokenizer, text_encoder_fname):
     return ids
 
 
+class _LazyLogits:
+    """`outputs.logits` of `UnifiedProCyon.forward` on the QA branch: behaves like the reference's [B, T, V] tensor
+    (model_unified.py:548-554) for a caller that indexes it -- `logits[torch.arange(B), pos]`, `logits[:, pos]`, `logits.softmax(-1)`, any
+    torch function -- but only the answer rows exist until something else is asked for: indexing exactly the answer positions returns them
+    (the QA readers' access, data/inference_utils.py:582-604), anything else runs the prefill once more with every row's logits and caches
+    the [B, T_real, V] tensor (columns beyond the last real token of the longest row are never computed; the reference pads to
+    max_text_len).  `outputs.answer_logits` [B, 1, V] is the engine's own fast handle on the same rows."""
+
+    def __init__(self, answer_rows, answer_pos, T, materialise):
+        self._rows, self._pos, self._T, self._mk, self._full_t = answer_rows, answer_pos.long().cpu(), T, materialise, None
+
+    def _full(self):
+        if self._full_t is None:
+            self._full_t = self._mk()
+        return self._full_t
+
+    @property
+    def shape(self):
+        return torch.Size((self._rows.shape[0], self._T, self._rows.shape[-1]))
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def dim(self):
+        return 3
+
+    @property
+    def dtype(self):
+        return self._rows.dtype
+
+    @property
+    def device(self):
+        return self._rows.device
+
+    def _is_answer_index(self, idx):
+        if not (isinstance(idx, tuple) and len(idx) == 2):
+            return False
+        r, p = idx
+        B = self._rows.shape[0]
+        if isinstance(r, slice):
+            if r != slice(None):
+                return False
+        else:
+            r = torch.as_tensor(r).cpu()
+            if r.dtype == torch.bool or r.shape != (B,) or not torch.equal(r.long(), torch.arange(B)):
+                return False
+        if isinstance(p, (int, slice)):
+            return False
+        p = torch.as_tensor(p).cpu()
+        return p.dtype != torch.bool and p.shape == (B,) and torch.equal(p.long(), self._pos) and not isinstance(idx[0], slice)
+
+    def __getitem__(self, idx):
+        if self._full_t is None and self._is_answer_index(idx):
+            return self._rows
+        return self._full()[idx]
+
+    def __getattr__(self, name):      # anything a tensor has (softmax, float, cpu, argmax, ...): on the materialised tensor
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._full(), name)
+
+    def __len__(self):
+        return self._rows.shape[0]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a._full() if isinstance(a, _LazyLogits) else a
+        return func(*[un(a) for a in args], **{k: un(v) for k, v in (kwargs or {}).items()})
+
+
 class UnifiedProCyon:
     def __init__(self, config: ProCyonConfig, text_encoder, tokenizer, protein_seq_encoder=None, token_projectors=None,
                  aaseq_shared_projector: Optional[MlpEngine] = None, aaseq_lm_projector: Optional[MlpEngine] = None,
@@ -124,8 +194,7 @@ class UnifiedProCyon:
     # examples/paper_analyses/protpep_qa_scores.py:55-58, scripts/qa_filter_captions.py:17-18 and scripts/caption_bulk.py:72-73, which
     # run fp32.  The model tracks the dtype its caller has asked for and computes in it: bf16 on the bf16 engine; fp32 -- as long as the
     # fp32 weights of the checkpoint are still held, i.e. `.bfloat16()` was never called -- on the fp32 operator family
-    # (procyon_amd/engine_f32.py) for `forward` (QA, retrieval) and `forward_sequences`; generation needs bf16 (`_require_bf16`).
-    # Never silently different arithmetic.
+    # (procyon_amd/engine_f32.py: forward, forward_sequences AND generation, `_generate_*_f32`).  Never silently different arithmetic.
     def eval(self):
         self.training = False
         return self
@@ -181,14 +250,6 @@ class UnifiedProCyon:
                     raise RuntimeError(f"the engine's weights live on {mine}; cannot move the model to {dev} "
                                        "(build it with device=... instead)")
         return self
-
-    def _require_bf16(self, what):
-        if self.dtype != BF16:
-            raise RuntimeError(
-                f"UnifiedProCyon.{what}: the model is in {self.dtype} (as constructed / loaded); KV-cached generation computes in bfloat16 "
-                "only on the MI355X engine -- call model.bfloat16() first, as the reference's entry points do "
-                "(evaluate/framework/procyon.py:64-65, inference/retrieval_utils.py:90-101).  fp32 arithmetic is available for `forward` "
-                "(QA scoring, retrieval) and `forward_sequences`.")
 
     def _require_bf16_or_fp32(self, what):
         if self.dtype not in (BF16, torch.float32):
@@ -350,12 +411,12 @@ class UnifiedProCyon:
     @torch.no_grad()
     def forward(self, inputs, return_mlm=False, retrieval=False, get_full_labels=False, aaseq_type='protein',
                 exclude_protein_structure=False, crop_off=False, output_attentions=False, full_logits=False):
-        """`forward` (model_unified.py:483-581), inference branches.  QA: logits only at the position the QA readers
-        use (last [ANSWER] index, data/inference_utils.py:582-604) -> outputs.logits [B,1,V] and
-        out["answer_positions"]; retrieval: contrastive_out["positive"]["text"] [B,D].
-        full_logits=True (opt-in, not in the reference's signature): outputs.logits [B, T_real, V] for EVERY position like the
-        reference's `outputs.logits` (:548-554; the reference pads every row to max_text_len and materialises [B, 2048, V] -- the
-        trailing all-pad columns are not computed here), for callers that index `logits[:, pos]` themselves."""
+        """`forward` (model_unified.py:483-581), inference branches.  QA: `outputs.logits` reads like the reference's [B, T, V] tensor
+        (:548-554) -- index it at the answer positions (`logits[torch.arange(B), pos]`, data/inference_utils.py:582-604) and the rows that
+        were computed come back; any other access materialises every position once (_LazyLogits).  `outputs.answer_logits` [B, 1, V] and
+        out["answer_positions"] are the engine's own handle on the answer rows.  Retrieval: contrastive_out["positive"]["text"] [B, D].
+        full_logits=True (not in the reference's signature): outputs.logits is a plain [B, T_real, V] tensor from the start (the reference pads
+        every row to max_text_len and materialises [B, 2048, V]; the trailing all-pad columns are not computed here)."""
         if return_mlm:
             raise NotImplementedError("return_mlm is a training path (model_unified.py:505-509)")
         self._require_bf16_or_fp32("forward")
@@ -386,6 +447,12 @@ class UnifiedProCyon:
         outputs = self.text_encoder(input_embeds=emb, attn_masks=attn_masks[:, :real], full_labels=full_labels,
                                     logit_positions=None if full_logits else (answer_pos if not retrieval else torch.zeros(B, dtype=torch.long)),
                                     want_hidden=retrieval and not sum_all, hidden_sum_positions=ret_rows, lazy_hidden=True)
+        if not retrieval and not full_logits:
+            # the reference's `outputs.logits` is [B, T, V]; here the answer rows are computed and the rest on first access (_LazyLogits)
+            enc, am = self.text_encoder, attn_masks[:, :real]
+            outputs.answer_logits = outputs.logits                       # [B, 1, V]
+            outputs.logits = _LazyLogits(outputs.answer_logits[:, 0], answer_pos, real,
+                                         lambda: enc(input_embeds=emb, attn_masks=am, logit_positions=None, want_hidden=False, lazy_hidden=True).logits)
         out = {'outputs': outputs, 'text_toks': input_ids, 'full_labels': full_labels if get_full_labels else None,
                'contrastive_out': None, 'contrastive_loss': None, 'answer_positions': answer_pos}
         if retrieval:

@@ -192,10 +192,11 @@ def score_pairs(model, pairs=256, chunk=64, first=0, count=None):
     count = pairs if count is None else count
     ys, ls = [], []
     for lo in range(first, first + count, chunk):
-        lg = model.forward(make(lo, min(chunk, first + count - lo)), retrieval=False)["outputs"].logits[:, 0].float()
-        p = lg.softmax(-1)
-        ys.append(torch.stack([p[:, model.yes_token], p[:, model.no_token]], 1))
-        ls.append(lg[:, ::61].clone())
+        lg = model.forward(make(lo, min(chunk, first + count - lo)), retrieval=False)["outputs"].answer_logits[:, 0]
+        # the reference's read-out (data/inference_utils.py:582-604): softmax over the vocabulary in the model dtype, then the yes / no columns
+        from .engine import Context
+        ys.append(Context.get().qa_probs(lg, model.yes_token, model.no_token, want_probs=False)[1])
+        ls.append(lg.float()[:, ::61].clone())
     return torch.cat(ys), torch.cat(ls)
 
 

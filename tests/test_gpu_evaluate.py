@@ -63,7 +63,7 @@ def test_qa_eval_get_predictions(model):
     out = model(b, retrieval=False, get_full_labels=True, crop_off=True)
     pred, _ = get_qa_scores(out, answer_token=model.answer_idx)
     assert torch.equal(res["pred"], torch.cat([pred, pred]))
-    assert torch.equal(pred, out["outputs"].logits[:, 0].float().argmax(-1).cpu())
+    assert torch.equal(pred, out["outputs"].answer_logits[:, 0].float().argmax(-1).cpu())
 
 
 def test_retrieval_eval_get_predictions(model):

@@ -177,7 +177,7 @@ def test_fp32_model_runs_as_the_unchanged_fp32_callers_drive_it():
     r = LR.llama_forward(w["llama"], lgeom, inputs_embeds=emb[:, :real], attn_mask=mask[:, :real])
     yes_ref, no_ref, _ = PR.qa_yes_no_probs(r["logits"], ids[:, :real], m.answer_idx, m.yes_token, m.no_token)
     o = m.forward(mk(instr, prot, slots, text_slots=[[], []]), retrieval=False)
-    lg = o["outputs"].logits[:, 0]
+    lg = o["outputs"].answer_logits[:, 0]
     assert lg.dtype == F32
     probs = lg.softmax(-1).cpu()
     pos = o["answer_positions"]

@@ -146,9 +146,9 @@ def test_pair_scoring_fp8_agrees_with_bf16():
     inp = lambda: {"data": {"seq": prot, "seq_idx": torch.arange(prot.shape[0]), "text": [], "drug": None},
                    "input": {"seq": slots, "text": [[] for _ in range(n)], "drug": None},
                    "target": {"seq": None, "text": None, "drug": None}, "instructions": [tmpl] * n}
-    p16 = model.forward(inp(), retrieval=False)["outputs"].logits[:, 0].float().softmax(-1).cpu()
+    p16 = model.forward(inp(), retrieval=False)["outputs"].answer_logits[:, 0].float().softmax(-1).cpu()
     model.text_encoder.engine.quantize_fp8()
-    p8 = model.forward(inp(), retrieval=False)["outputs"].logits[:, 0].float().softmax(-1).cpu()
+    p8 = model.forward(inp(), retrieval=False)["outputs"].answer_logits[:, 0].float().softmax(-1).cpu()
     model.text_encoder.engine.set_fp8(False)
     y16, n16, y8, n8 = p16[:, model.yes_token], p16[:, model.no_token], p8[:, model.yes_token], p8[:, model.no_token]
     print("abs dP(yes)", (y8 - y16).abs().max().item(), "P(yes) bf16", y16[:3].tolist())

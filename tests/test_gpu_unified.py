@@ -170,7 +170,7 @@ def test_forward_retrieval_and_qa(env):
     r = LR.llama_forward(w["llama"], env["lgeom"], inputs_embeds=emb[:, :real], attn_mask=mask[:, :real])
     yes_ref, no_ref, _ = PR.qa_yes_no_probs(r["logits"], ids[:, :real], m.answer_idx, m.yes_token, m.no_token)
     out = m.forward(_inputs(m, env["prot"], instr, [[0, 1], [1]], text_slots=[[], []]), retrieval=False)
-    probs = out["outputs"].logits[:, 0].softmax(-1).cpu()
+    probs = out["outputs"].answer_logits[:, 0].softmax(-1).cpu()
     assert out["text_toks"].shape[1] == m.config.max_text_len
     assert torch.equal(out["answer_positions"], PR.get_after_answer_tokens(ids, m.answer_idx) - 1)
     assert torch.allclose(probs[:, m.yes_token].float(), yes_ref.float(), rtol=0.05, atol=1e-6)
@@ -181,9 +181,26 @@ def test_forward_retrieval_and_qa(env):
     fl = full["outputs"].logits
     assert fl.shape[:2] == (2, real) and fl.shape[2] == out["outputs"].logits.shape[2]
     picked = fl[torch.arange(2), out["answer_positions"].to(fl.device)]
-    assert rel_err(picked.cpu(), out["outputs"].logits[:, 0].cpu()) < 2e-2
+    assert rel_err(picked.cpu(), out["outputs"].answer_logits[:, 0].cpu()) < 2e-2
     valid = mask[:, :real].bool()
     assert rel_err(fl.cpu()[valid], r["logits"][valid]) < 2e-2
+    # the DEFAULT `outputs.logits` reads like the reference's [B, T, V] tensor (model_unified.py:548-554): the QA readers' index returns the
+    # rows that were computed, without a second pass; any other access materialises every position once (the same bits as full_logits=True)
+    lz, pos = out["outputs"].logits, out["answer_positions"]
+    assert tuple(lz.shape) == (2, real, fl.shape[2]) and lz._full_t is None
+    assert torch.equal(lz[torch.arange(2), pos], out["outputs"].answer_logits[:, 0]) and lz._full_t is None
+    assert torch.equal(lz[:, 3], fl[:, 3]) and lz._full_t is not None
+    assert torch.equal(torch.softmax(lz, dim=-1), fl.softmax(-1)) and torch.equal(lz.argmax(-1), fl.argmax(-1))
+    # the read-out itself on the device (pcy_qa_probs): softmax over the vocabulary in the model dtype, yes / no columns, argmax
+    from procyon_amd.engine import Context
+    ans = out["outputs"].answer_logits[:, 0]
+    p_dev, yn, am = Context.get().qa_probs(ans, m.yes_token, m.no_token, want_argmax=True)
+    p_ref = ans.float().softmax(-1)
+    assert p_dev.dtype == ans.dtype and float((p_dev.float() - p_ref).abs().max()) <= 2.0 ** -8 * float(p_ref.max()) + 1e-9
+    assert torch.equal(yn[:, 0], p_dev[:, m.yes_token].float()) and torch.equal(yn[:, 1], p_dev[:, m.no_token].float())
+    assert torch.equal(am, p_dev.float().argmax(-1))
+    p32 = Context.get().qa_probs(ans.float())[0]
+    assert p32.dtype == torch.float32 and torch.allclose(p32, p_ref, rtol=1e-5, atol=1e-9)
 
 
 def test_sampling_probability_vector_and_nucleus_mask(env):
@@ -339,7 +356,7 @@ def test_config5_shape_pair_scoring_with_in_context_examples(env):
     r = LR.llama_forward(w["llama"], env["lgeom"], inputs_embeds=emb[:, :real], attn_mask=mask[:, :real])
     yes_ref, no_ref, _ = PR.qa_yes_no_probs(r["logits"], ids[:, :real], m.answer_idx, m.yes_token, m.no_token)
     out = m.forward(inp, retrieval=False)
-    probs = out["outputs"].logits[:, 0].softmax(-1).cpu()
+    probs = out["outputs"].answer_logits[:, 0].softmax(-1).cpu()
     assert torch.allclose(probs[:, m.yes_token].float(), yes_ref.float(), rtol=0.05, atol=1e-6)
     assert torch.allclose(probs[:, m.no_token].float(), no_ref.float(), rtol=0.05, atol=1e-6)
     # rows 0 and 1 differ only in the last slot -> different scores; the engine must not have mixed up the slot order
