@@ -741,6 +741,7 @@ bool launch_nb_ub(hipStream_t s, int device, PcyDecAttnArgs a, const PcyAttnBloc
     lc.resident_smem = smem;
   }
   if (!lc.resident) return false;
+  if (st.n_layers == 0) return true;   // (launchability query: pcy_decode_nb_launchable)
   hipLaunchKernelGGL((decode_step_nb_kernel<DH, G, NB, UB>), dim3(256), dim3(512), smem, s, a, p, mc, st, n_attn, step_epoch, pcy_gemv_rms_threads(p.Nq),
                      stage_off, pcy_gemv_rms_threads(mc.F));
   return true;
@@ -768,7 +769,7 @@ int pcy_decode_nb_ds(int B) { return B <= 1 ? 16 : B == 2 ? 32 : 64; }
 // pcy_decode_nb_line_words of B rows; p.epoch = the tag counter of THIS batch size's slots.
 bool pcy_launch_decode_step_nb(hipStream_t s, int device, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc,
                                const PcyDecodeStepArgs& st, int n_cu, const unsigned* step_epoch, int B, int xmin) {
-  if (B < 1 || B > 8 || a.B != B || a.dh != 128 || a.H != 32 || a.Hkv != 8 || a.dbg || n_cu < 256 || st.n_layers < 1) return false;
+  if (B < 1 || B > 8 || a.B != B || a.dh != 128 || a.H != 32 || a.Hkv != 8 || a.dbg || n_cu < 256 || st.n_layers < 0) return false;
   if (p.d != NBD || p.Nq != NBNQ || mc.d != NBD || mc.F != NBF) return false;
 #ifdef PCY_NB_ONLY   // (experiments: one instantiation)
   return B == PCY_NB_ONLY ? launch_nb<PCY_NB_ONLY>(s, device, a, p, mc, st, step_epoch, n_cu, xmin) : false;
@@ -784,4 +785,19 @@ bool pcy_launch_decode_step_nb(hipStream_t s, int device, const PcyDecAttnArgs& 
     default: return launch_nb<8>(s, device, a, p, mc, st, step_epoch, n_cu, xmin);
   }
 #endif
+}
+
+// Would pcy_launch_decode_step_nb launch for this batch size and cache capacity on this device?  (LDS of the attention phase grows with Tmax;
+// every workgroup must be resident.)  The engine asks BEFORE it commits a step to the small-batch arithmetic: an uncovered shape takes the
+// round-4 launches (MFMA GEMVs), not the twin's forced streaming kernels, and no hand-over counter is advanced for a step that never runs.
+bool pcy_decode_nb_launchable(int device, int B, int Tmax, int n_cu) {
+  PcyDecAttnArgs a{};
+  a.B = B; a.dh = 128; a.H = 32; a.Hkv = 8; a.Tmax = Tmax;
+  PcyAttnBlockArgs p{};
+  p.d = NBD; p.Nq = NBNQ;
+  PcyMlpChainArgs mc{};
+  mc.d = NBD; mc.F = NBF;
+  PcyDecodeStepArgs st{};
+  st.n_layers = 0;
+  return pcy_launch_decode_step_nb(nullptr, device, a, p, mc, st, n_cu, nullptr, B, 0);
 }

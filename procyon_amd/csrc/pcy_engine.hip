@@ -204,27 +204,6 @@ bool decode_nb_step_enabled() { return !pcy_off("decode_nb_step"); }
 // PCY_DISABLE=decode_mb_step: batches of 9..32 rows run launch by launch (seven per layer) instead of the mid-batch step (pcy_decode_mb.hip:
 // the same work items as phases of ONE launch) -- same bits, tests compare the two.
 bool decode_mb_step_enabled() { return !pcy_off("decode_mb_step"); }
-// (17..32 rows -- two batch tiles -- stay on the launches: there the activations every CU has to fetch per weight byte double, every byte a CU
-// loads goes through the same ~25 GB/s, and the fused step measured 5.0 / 5.3 ms at 20 / 32 rows against 4.4 / 4.6 launch by launch;
-// PCY_MB_MAX=32 runs them fused all the same: tests, tools)
-int decode_mb_max_rows() {
-  const char* e = getenv("PCY_MB_MAX");
-  return e ? atoi(e) : 16;
-}
-int decode_mode() {
-  return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
-         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16);
-}
-constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
-// geometry of the small-batch step: Llama-3-8B, 256 CUs
-bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
-  return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
-         c->n_cu >= 256 && m->n_layers <= AO_MAX_LAYERS / 2;   // (score-exchange flags: 2 x AO_FLAGS words per layer)
-}
-// geometry of the mid-batch step (9..32 rows): the same model and chip
-bool decode_mb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
-  return B >= 9 && B <= 32 && B <= decode_mb_max_rows() && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 && c->n_cu >= 256;
-}
 // ... for the small-batch step: the exchange costs more there than the K reads it saves until much longer caches (t ~ 800: 2 / 4 rows
 // 2.935 / 3.385 ms per step with the split, 2.868 / 3.287 without; t ~ 1540: 3.158 / 3.653 with, 3.180 / 3.632 without)
 int decode_xmin_nb(int B) {
@@ -236,6 +215,28 @@ int decode_xmin() {   // cached keys from which the decode attention splits its 
   return xe ? atoi(xe) : 768;
 }
 
+// (17..32 rows -- two batch tiles -- stay on the launches: there the activations every CU has to fetch per weight byte double, every byte a CU
+// loads goes through the same ~25 GB/s, and the fused step measured 5.0 / 5.3 ms at 20 / 32 rows against 4.4 / 4.6 launch by launch;
+// PCY_MB_MAX=32 runs them fused all the same: tests, tools)
+int decode_mb_max_rows() {
+  const char* e = getenv("PCY_MB_MAX");
+  return e ? atoi(e) : 16;
+}
+int decode_mode() {
+  return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16) |
+         (int)((((unsigned)decode_xmin() * 2654435761u) ^ ((unsigned)decode_xmin_nb(2) * 40503u) ^ ((unsigned)decode_xmin_nb(4) * 69069u)) & 0x3fu) << 22;
+}
+constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
+// geometry of the small-batch step: Llama-3-8B, 256 CUs
+bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
+  return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
+         c->n_cu >= 256 && m->n_layers <= AO_MAX_LAYERS / 2;   // (score-exchange flags: 2 x AO_FLAGS words per layer)
+}
+// geometry of the mid-batch step (9..32 rows): the same model and chip
+bool decode_mb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
+  return B >= 9 && B <= 32 && B <= decode_mb_max_rows() && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 && c->n_cu >= 256;
+}
 // tagged vectors of one layer: act [ffn], qkv [(H + 2 Hkv) dh], attention output [H dh], x after o [d]
 size_t tag_words_per_layer(const pcy_llama_desc* m) {
   return (size_t)m->ffn + (size_t)m->d + (size_t)(m->n_heads + 2 * m->n_kv_heads) * m->head_dim + (size_t)m->n_heads * m->head_dim;
@@ -357,7 +358,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
   const bool batched_head = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
   // 2..8 rows: the small-batch step (pcy_decode_nb.hip) -- one launch for all layers, or its launch-per-stage twin; lm_head as before
-  const bool nb_on = decode_nb_enabled() && decode_nb_covers(c, m, B) && c->nb_tags[B] && c->nb_sync && c->dev_layers && c->ao_sync && c->xwg_err;
+  const bool nb_on = decode_nb_enabled() && decode_nb_covers(c, m, B) && c->nb_tags[B] && c->nb_sync && c->dev_layers && c->ao_sync && c->xwg_err &&
+                     pcy_decode_nb_launchable(c->device, B, kv->Tmax, c->n_cu);
   const bool batched = batched_head && !nb_on;
   // 9..32 rows: the mid-batch step (pcy_decode_mb.hip) -- the batched path's work items as phases of one launch
   const bool mb_step = batched && decode_mb_step_enabled() && decode_mb_covers(c, m, B) && pcy_decode_mb_fits(B, kv->Tmax) && c->mb_flags && c->mb_sync &&
@@ -604,11 +606,12 @@ __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kb
   __shared__ uint4 stage[MAXB * 128];
   const int h = blockIdx.x, lw = blockIdx.y, l = lw >> 1;
   unsigned need = 0;                                       // rows some OTHER row takes its contents from (uniform)
+  bool moves = false;
   for (int b = 0; b < B; ++b) {
     const int sb = rows[b];
-    if (sb != b) need |= 1u << sb;
+    if (sb != b) { moves = true; if (sb >= 0 && sb < B) need |= 1u << sb; }
   }
-  if (!need) return;                                       // no row moves
+  if (!moves) return;                                      // no row moves
   if (t_dev) { t = *t_dev; t = t < Tmax ? t : Tmax; }
   bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh + (size_t)h * Tmax * dh;
   const size_t rstride = (size_t)Hkv * Tmax * dh;          // elements between two rows of the slab
@@ -620,7 +623,10 @@ __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kb
 #pragma unroll 4
     for (int b = 0; b < B; ++b) {
       const int sb = rows[b];
-      if (sb != b) *reinterpret_cast<uint4*>(cache + (size_t)b * rstride + i * 8) = stage[sb * 128 + threadIdx.x];
+      if (sb == b) continue;
+      // (a source beyond the permuted rows -- pcy_kv_reorder accepts any cache row -- is not staged, and is nobody's destination: straight from memory)
+      const uint4 v = (sb >= 0 && sb < B) ? stage[sb * 128 + threadIdx.x] : *reinterpret_cast<const uint4*>(cache + (size_t)sb * rstride + i * 8);
+      *reinterpret_cast<uint4*>(cache + (size_t)b * rstride + i * 8) = v;
     }
   }
 }
@@ -1525,11 +1531,16 @@ int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(bs);
     for (size_t i = 0; i < sizeof(pcy_beam_state); ++i) bsh = (bsh ^ pb[i]) * 1099511628211ull;
   }
+  // ... and what enqueue_decode bakes into the step besides: the key-keep mask, the hand-over slots / flags of the fused steps
+  uint64_t fold = 1469598103934665603ull;
+  for (const void* q : {(const void*)st->keep, (const void*)c->mc_tags, (const void*)c->dev_layers, (const void*)c->mb_flags,
+                        (const void*)(BB <= 8 ? c->nb_tags[BB] : nullptr)})
+    fold = (fold ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
   const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, bs->out, bs->cur,
                                            st->logits, logits_rec, bs->src, c->ws,
                                            (const void*)(intptr_t)(((int64_t)beam << 40) ^ ((int64_t)group_size << 32) ^ kv->Tmax),
                                            (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ pen_bits),
-                                           c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ bsh)};
+                                           c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ bsh ^ fold)};
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != BB || c->graph_mode != decode_mode() || c->graph_kind != 2) {
     c->drop_graph();
     PcyBeamState b{};

@@ -412,7 +412,8 @@ int pcy_f32_attention(pcy_ctx* c, const float* q, int ldq, int qcol0, const floa
   const size_t smem = (size_t)(dh + max_len) * sizeof(float);
   if (smem > 160 * 1024 - 1024) { pcy_set_error("pcy_f32_attention: %d keys exceed the LDS score buffer", max_len); return 1; }
   if (nseq > 0 && max_len > 0) {
-    if (smem > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static PcyLdsAttr lds_attn_f32_kernel;   // (configured once per device and size, refused sizes fail the call)
+    if (!lds_attn_f32_kernel.ensure(&attn_f32_kernel, smem)) { pcy_set_error("pcy_f32_attention: the device refused %zu bytes of LDS", smem); return 1; }
     hipLaunchKernelGGL(attn_f32_kernel, dim3(max_len, H, nseq), dim3(64), smem, pcy_ctx_stream(c), q, ldq, qcol0, k, ldk, kcol0, v, ldv, vcol0, o, ldo,
                        cu, keep, H, Hkv, dh, causal, scale);
   }
@@ -426,7 +427,8 @@ int pcy_f32_attn_decode(pcy_ctx* c, const float* q, int ldq, const float* kcache
   const size_t smem = (size_t)(dh + nkeys) * sizeof(float);
   if (smem > 160 * 1024 - 1024) { pcy_set_error("pcy_f32_attn_decode: %d keys exceed the LDS score buffer", nkeys); return 1; }
   if (B > 0) {
-    if (smem > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dec_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static PcyLdsAttr lds_attn_dec_f32_kernel;   // (configured once per device and size, refused sizes fail the call)
+    if (!lds_attn_dec_f32_kernel.ensure(&attn_dec_f32_kernel, smem)) { pcy_set_error("pcy_f32_attn_decode: the device refused %zu bytes of LDS", smem); return 1; }
     hipLaunchKernelGGL(attn_dec_f32_kernel, dim3(H, B), dim3(64), smem, pcy_ctx_stream(c), q, ldq, kcache, vcache, ldkv, Tmax, o, ldo, H, Hkv, dh, nkeys, scale);
   }
   return launch_ok("pcy_f32_attn_decode");

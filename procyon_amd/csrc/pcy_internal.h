@@ -235,6 +235,7 @@ size_t pcy_decode_nb_line_words(int B);
 int pcy_decode_nb_ds(int B);   // output columns per attention workgroup of the B-row step (what the launch-per-stage twin must use)
 bool pcy_launch_decode_step_nb(hipStream_t s, int device, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc,
                                const PcyDecodeStepArgs& st, int n_cu, const unsigned* step_epoch, int B, int xmin);
+bool pcy_decode_nb_launchable(int device, int B, int Tmax, int n_cu);   // pcy_launch_decode_step_nb would launch (LDS for this Tmax, residency)
 // threads of the stand-alone RMS-fused GEMV launch for N output rows (the summation order of its statistic)
 int pcy_gemv_rms_threads(int N);
 

@@ -730,7 +730,7 @@ class UnifiedProCyon:
                         cur[g0:g1] = top_v
                         rec[g0:g1] = rec[parents.cpu()]
                         src[g0:g1] = src[parents]        # (the K / V rows of every layer follow the parents, :830-832)
-                past.cache.reorder_(src)
+                past.cache.reorder_(src, past.t)
                 if bool((out == self.tokenizer.eos_token_id).any(dim=1).all()):
                     break
         finally:
