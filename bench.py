@@ -248,7 +248,7 @@ def main():
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     traffic_ratio = None
     try:
-        pname = next(n for n in (("r05_pmc_decode_step.json", "r04_pmc_decode_step.json") if all_layers else ("r02_pmc_decode_layer.json",))
+        pname = next(n for n in (("r06_pmc_decode_step.json", "r05_pmc_decode_step.json", "r04_pmc_decode_step.json") if all_layers else ("r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
         if a.geometry == "full" and one_launch:
@@ -344,15 +344,18 @@ def main():
             # headline's inputs -- ms per beam step from the slope over max_len (decode of beam rows + record + bookkeeping + KV reorder)
             binp = SM.caption_inputs(model, prot, n_prompt_words=a.prompt - 2, n_slots=2, seed=0)
             beams = {}
-            for (bsz, grp) in ((5, 5), (10, 2)):
+            # beam 5 / 5: the signature default (model_unified.py:924-940); beam 10 / 2: scripts/caption_bulk.py:193-194 + :130 and the evaluation
+            # plugin (evaluate/framework/procyon.py:72-76); beam 20 / 2 at max_len 200: examples/phenotype_generation.ipynb cell 14
+            for (bsz, grp, n_hi) in ((5, 5, 88), (10, 2, 88), (20, 2, 200)):
                 tms = {}
                 model.generate(binp, max_len=4, method="beam", beam_size=bsz, beam_group_size=grp)
-                for n in (24, 88):
+                for n in (24, n_hi):
                     torch.cuda.synchronize(); tb = time.perf_counter()
                     model.generate(binp, max_len=n, method="beam", beam_size=bsz, beam_group_size=grp)
                     torch.cuda.synchronize(); tms[n] = (time.perf_counter() - tb) * 1e3
-                beams[f"beam{bsz}_group{grp}"] = {"ms_per_step": round((tms[88] - tms[24]) / 64, 3), "ms_generate_88_steps": round(tms[88], 1),
-                                                 "prompt_tokens": a.prompt, "mean_cache_len": a.prompt + 56}
+                beams[f"beam{bsz}_group{grp}"] = {"ms_per_step": round((tms[n_hi] - tms[24]) / (n_hi - 24), 3), f"ms_generate_{n_hi}_steps": round(tms[n_hi], 1),
+                                                 "prompt_tokens": a.prompt, "mean_cache_len": a.prompt + (24 + n_hi) // 2,
+                                                 "prefill": "one per prompt, K / V rows broadcast to the beams"}
             configs["beam_search_caption"] = beams
         if not dist:
             # fp8 accuracy where it can be judged: the same model with its residual branches damped to a quarter (a trained-like

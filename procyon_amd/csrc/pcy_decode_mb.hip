@@ -104,6 +104,7 @@ struct MbStream {
   int n_layers, wg, wave;
   char* ring;                 // this wave's tiles
   int il, iph, itile, intiles, iK, irt2, islot, idone;
+  int inss, ishift;           // 128-k steps of the phase's K range and the step the workgroup starts at (pcy_gemv_kshift: rotated K order)
   const bf16_t* ibase;        // first element of the phase's item for this wave: W + r0 * K + kbeg
   int cslot;                  // ring slot of the next tile to be consumed
   int wdef;                   // timing ablation: weight copies with the default cache policy instead of nt
@@ -116,10 +117,13 @@ __device__ __forceinline__ void mb_stream_setup(MbStream& s) {
   const PcyLayerWeightsDev lw = s.layers[s.il];
   const int wg = s.wg, wave = s.wave;
   s.itile = 0;
-  if (s.iph == 0) { s.ibase = lw.wqkv + (size_t)((wg >> 1) * 48 + wave * 16) * MBD + (wg & 1) * 2048; s.intiles = 16; s.iK = MBD; s.irt2 = 0; }
-  else if (s.iph == 1) { s.ibase = lw.wo + (size_t)((wg >> 2) * 64 + wave * 16) * MBD + (wg & 3) * 1024; s.intiles = 8; s.iK = MBD; s.irt2 = 0; }
-  else if (s.iph == 2) { s.ibase = lw.wgu + (size_t)((wg * 4 + wave) * 32) * MBD; s.intiles = 64; s.iK = MBD; s.irt2 = 1; }
-  else { s.ibase = lw.wdown + (size_t)((wg >> 2) * 64 + wave * 16) * MBF + (wg & 3) * 3584; s.intiles = 28; s.iK = MBF; s.irt2 = 0; }
+  int r0wg;   // first weight row of the workgroup's item (all of its waves share the x tiles, hence the rotation)
+  if (s.iph == 0) { r0wg = (wg >> 1) * 48; s.ibase = lw.wqkv + (size_t)(r0wg + wave * 16) * MBD + (wg & 1) * 2048; s.intiles = 16; s.iK = MBD; s.irt2 = 0; }
+  else if (s.iph == 1) { r0wg = (wg >> 2) * 64; s.ibase = lw.wo + (size_t)(r0wg + wave * 16) * MBD + (wg & 3) * 1024; s.intiles = 8; s.iK = MBD; s.irt2 = 0; }
+  else if (s.iph == 2) { r0wg = wg * 128; s.ibase = lw.wgu + (size_t)(r0wg + wave * 32) * MBD; s.intiles = 64; s.iK = MBD; s.irt2 = 1; }
+  else { r0wg = (wg >> 2) * 64; s.ibase = lw.wdown + (size_t)(r0wg + wave * 16) * MBF + (wg & 3) * 3584; s.intiles = 28; s.iK = MBF; s.irt2 = 0; }
+  s.inss = s.irt2 ? s.intiles >> 1 : s.intiles;
+  s.ishift = pcy_gemv_kshift(r0wg, s.inss);
 }
 __device__ __forceinline__ void mb_stream_advance(MbStream& s) {   // the phase's last tile has been issued: the next phase that has an item
   for (;;) {
@@ -133,7 +137,9 @@ __device__ __forceinline__ void mb_stream_advance(MbStream& s) {   // the phase'
 // pieces of a row XOR-swizzled by the row on the source side: gemv_mfma4_kernel's layout)
 template <int RING>
 __device__ __forceinline__ void mb_stream_issue(MbStream& s, const int (&voff4)[4], const int (&voff14)[4]) {
-  const bf16_t* p = s.ibase + (s.irt2 ? (size_t)(s.itile & 1) * 16 * s.iK + (size_t)(s.itile >> 1) * 128 : (size_t)s.itile * 128);
+  int ss = (s.irt2 ? s.itile >> 1 : s.itile) + s.ishift;
+  ss = ss >= s.inss ? ss - s.inss : ss;
+  const bf16_t* p = s.ibase + (s.irt2 ? (size_t)(s.itile & 1) * 16 * s.iK : (size_t)0) + (size_t)ss * 128;
   char* dst = s.ring + s.islot * 4096;
   const bool k4 = s.iK == MBD;
 #pragma unroll
@@ -166,7 +172,7 @@ struct MbCtx {
 template <int RT, int BT, int EPI>
 __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const int (&voff4)[4], const int (&voff14)[4], int nsteps, const bf16_t* x, int ldx,
                                               const unsigned* wait_f, int wait_n, unsigned wait_code, float* ws_out, int N, int n0, unsigned* done_f, int t_ready,
-                                              int nact = 4 /* GEMV waves that have an item */) {
+                                              int r0wg /* first weight row of the item: the K rotation */, int nact = 4 /* GEMV waves that have an item */) {
   constexpr int SX = MbCfg<BT>::SX, RING = MbCfg<BT>::RING;
   constexpr int NX = BT * 4;                        // copies per step
   MB_IDS
@@ -186,15 +192,18 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
   int nlw = 0;                                       // copies per step of this loader wave
 #pragma unroll
   for (int g = 0; g < NX; ++g) nlw += (lw >= 0 && lw < NLW && g % NLW == lw && g * 4 < B) ? 1 : 0;
+  const int xshift = pcy_gemv_kshift(r0wg, nsteps);   // the workgroup's rotated K order: the same rule as the weight streams'
   auto issue_x = [&](int ss) __attribute__((always_inline)) {
     char* xb = xring + (ss % SX) * (BT * 4096);
+    int rs = ss + xshift;
+    rs = rs >= nsteps ? rs - nsteps : rs;
 #pragma unroll
     for (int g = 0; g < NX; ++g) {
       if (g % NLW != lw || g * 4 >= B) continue;
       const int row = (g & 3) * 4 + (lane >> 4);
       int b = (g >> 2) * 16 + row;
       b = b < B ? b : B - 1;
-      const bf16_t* src = x + (size_t)b * ldx + ss * 128 + ((lane & 15) ^ row) * 8;
+      const bf16_t* src = x + (size_t)b * ldx + rs * 128 + ((lane & 15) ^ row) * 8;
       if (abl & 4) continue;
       if (abl & 1) __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + g * 1024), 16, 0, 0);
       else __builtin_amdgcn_global_load_lds((mb_gptr_t)src, (mb_lds_ptr_t)(xb + g * 1024), 16, 0, 16 /* sc1 */);
@@ -310,17 +319,23 @@ __device__ __forceinline__ void mb_finish_row(const MbCtx& c, const float* ws, c
   MB_IDS
   const int B = a.B;
   float* red = reinterpret_cast<float*>(c.xreg);
+  // (the row's residual does not depend on the items this finisher waits for: requested in front of the wait)
+  uint4 rr[2];
+  if (tid < 256 && !(a.abl & 32)) {
+    const __amdgpu_buffer_rsrc_t rx0 = mb_rsrc(a.x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) rr[it] = mb_ld16(rx0, (b * MBD + tid * 8 + it * 2048) * 2);
+  }
   if (wave == 4 && !(a.abl & 16)) mb_wait_flags(wait_f, 256, c.epoch, a.err, wait_code, lane);
   __builtin_amdgcn_s_barrier();
   float xv[2][8];
   float ss = 0.f;
   if (tid < 256 && !(a.abl & 32)) {
     const __amdgpu_buffer_rsrc_t rws = mb_rsrc(ws), rx = mb_rsrc(a.x);
-    uint4 p[2][2][4], rr[2];
+    uint4 p[2][2][4];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int k = tid * 8 + it * 2048;
-      rr[it] = mb_ld16(rx, (b * MBD + k) * 2);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
     {
       const int kh = wg & 1;
       mb_gemv_phase<1, BT, 0>(c, s, voff4, voff14, 16, a.xn + kh * 2048, MBD, l ? c.lflags + MBF_XN : nullptr, B, 30u,
-                              a.qkv_ws + (size_t)kh * B * MBNQ, MBNQ, (wg >> 1) * 48, c.lflags + MBF_QKV + wg, 13, 3);
+                              a.qkv_ws + (size_t)kh * B * MBNQ, MBNQ, (wg >> 1) * 48, c.lflags + MBF_QKV + wg, 13, (wg >> 1) * 48, 3);
     }
     MB_T(1)
     // ---- A ----
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
     {
       const int rb = wg >> 2, kq = wg & 3;
       mb_gemv_phase<1, BT, 0>(c, s, voff4, voff14, 8, a.ao + kq * 1024, MBD, c.lflags + MBF_AO + kq * 64, 2 * SL * B, 32u,
-                              a.sk_ws + (size_t)kq * B * MBD, MBD, rb * 64, c.lflags + MBF_O + wg, 4);
+                              a.sk_ws + (size_t)kq * B * MBD, MBD, rb * 64, c.lflags + MBF_O + wg, 4, rb * 64);
     }
     MB_T(5)
     // ---- F1 ----
@@ -501,14 +516,14 @@ __global__ __launch_bounds__(512) void decode_step_mb_kernel(PcyMbArgs a) {
     // ---- G ----
     if (wg < MB_G_WGS) {
       mb_gemv_phase<2, BT, 1>(c, s, voff4, voff14, 32, a.xn, MBD, c.lflags + MBF_XN2, B, 34u, nullptr, 0, 0,
-                              c.lflags + MBF_ACT + (wg / 56) * 64 + wg % 56, 7);
+                              c.lflags + MBF_ACT + (wg / 56) * 64 + wg % 56, 7, wg * 128);
     }
     MB_T(8)
     // ---- D ----
     {
       const int rb = wg >> 2, kq = wg & 3;
       mb_gemv_phase<1, BT, 0>(c, s, voff4, voff14, 28, a.act + kq * 3584, MBF, c.lflags + MBF_ACT + kq * 64, 56, 35u,
-                              a.sk_ws + (size_t)kq * B * MBD, MBD, rb * 64, c.lflags + MBF_DN + wg, 9);
+                              a.sk_ws + (size_t)kq * B * MBD, MBD, rb * 64, c.lflags + MBF_DN + wg, 9, rb * 64);
     }
     MB_T(10)
     // ---- F2 ----

@@ -492,6 +492,7 @@ void launch_epi(hipStream_t s, const PcyGemvArgs& a) {
 typedef __attribute__((address_space(3))) void* gv_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gv_gptr_t;
 
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemv_splitk_finish_kernel(PcyGemvArgs a, int ksplit) {
   const size_t quads = (size_t)a.B * (a.N / 4);
@@ -636,6 +637,8 @@ __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int kspl
   const int ks = K / ksplit;                   // multiple of KC
   const int kbeg = blockIdx.y * ks;
   const int nchunk = ks / KC;
+  const int csh = pcy_gemv_kshift(blockIdx.x * 4 * 16 * RT, ks / 128) >> 2;   // rotated K order, in chunks (pcy_gemv_kshift)
+  auto rk = [&](int k) { int c = (k >> 9) + csh; c = c >= nchunk ? c - nchunk : c; return (c << 9) | (k & 511); };
   const bf16_t* wp[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int kspl
     for (int i = 0; i < BT * 4; ++i) {
       const int row = wave * BT * 4 + i;
       const int b = row < a.B ? row : a.B - 1;
-      const bf16_t* src = a.x + (size_t)b * a.ldx + kbeg + c * KC + lane * 8;
+      const bf16_t* src = a.x + (size_t)b * a.ldx + kbeg + rk(c * KC) + lane * 8;
       __builtin_amdgcn_global_load_lds((gv_gptr_t)src, (gv_lds_ptr_t)(buf + row * XROW), 16, 0, 0);
     }
   };
@@ -659,7 +662,8 @@ __global__ __launch_bounds__(256) void gemv_mfma2_kernel(PcyGemvArgs a, int kspl
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) acc[rt][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto load_w = [&](int k, bf16x8 (&wf)[RT][4]) {   // one 128-k super-step = 4 MFMA k-steps
+  auto load_w = [&](int k0, bf16x8 (&wf)[RT][4]) {   // one 128-k super-step = 4 MFMA k-steps
+    const int k = rk(k0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -738,6 +742,8 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
   const int ks = K / ksplit;                   // multiple of KC
   const int kbeg = blockIdx.y * ks;
   const int nss = ks / 128, nchunk = ks / KC;
+  const int ksh = pcy_gemv_kshift(blockIdx.x * 4 * 16 * RT, nss);   // rotated K order (pcy_gemv_kshift): a multiple of 4 steps, so a 256-k x chunk never wraps
+  auto rss = [&](int ss) { const int r = ss + ksh; return r >= nss ? r - nss : r; };
   // DMA source of this lane: row (lane >> 4) of each group of four rows, piece (lane & 15) ^ row of the 256-byte segment
   const bf16_t* wsrc[RT][4];
 #pragma unroll
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
       wsrc[rt][q] = a.W + (size_t)r * K + kbeg + ((lane & 15) ^ row) * 8;
     }
   auto issue_w = [&](int ss) __attribute__((always_inline)) {   // (past the end: the last super-step again, so that the counts below stay uniform)
-    const int k = (ss < nss ? ss : nss - 1) * 128;
+    const int k = rss(ss < nss ? ss : nss - 1) * 128;
     char* dst = wring + (ss % S) * RT * WT;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(256) void gemv_mfma3_kernel(PcyGemvArgs a, int kspl
         __builtin_amdgcn_global_load_lds((gv_gptr_t)(wsrc[rt][q] + k), (gv_lds_ptr_t)(dst + rt * WT + q * 1024), 16, 0, 0);
   };
   auto stage_x = [&](int c) __attribute__((always_inline)) {
-    const int cc = c < nchunk ? c : nchunk - 1;
+    const int cc = rss(2 * (c < nchunk ? c : nchunk - 1)) >> 1;
     char* buf = xs + (c & 1) * XBUF;
 #pragma unroll
     for (int i = 0; i < BT * 4; ++i) {
@@ -848,6 +854,7 @@ __global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int kspl
   const int ks = K / ksplit;                   // multiple of 128
   const int kbeg = blockIdx.y * ks;
   const int nss = ks / 128;
+  const int ksh = pcy_gemv_kshift(blockIdx.x * 4 * 16 * RT, nss);   // rotated K order (pcy_gemv_kshift)
   const bf16_t* wsrc[RT][4];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -858,25 +865,33 @@ __global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int kspl
       r = r < nrows ? r : nrows - 1;
       wsrc[rt][q] = a.W + (size_t)r * K + kbeg + ((lane & 15) ^ row) * 8;
     }
-  // this wave's share of an x tile set: instructions wave*BT .. wave*BT + BT-1 of the BT*4 (tile bt = i >> 2, rows (i & 3)*4 .. +3)
+  // this wave's share of an x tile set: instructions wave*BT .. wave*BT + BT-1 of the BT*4 (tile bt = i >> 2, rows (i & 3)*4 .. +3).  Row groups
+  // beyond the batch are not copied at all (round 6: their MFMA columns are never stored, and every byte a CU fetches -- L2-served activations
+  // included -- goes through the same ~25 GB/s: 20 rows used to copy 32); nxw = this wave's copies per step
   const bf16_t* xsrc[BT];
   int xdst[BT];
+  bool xon[BT];
+  int nxw = 0;
 #pragma unroll
   for (int t = 0; t < BT; ++t) {
     const int i = wave * BT + t, bt = i >> 2, q = i & 3;
     const int row = q * 4 + (lane >> 4);
     int b = bt * 16 + row;
+    xon[t] = bt * 16 + q * 4 < a.B;
+    nxw += xon[t] ? 1 : 0;
     b = b < a.B ? b : a.B - 1;
     xsrc[t] = a.x + (size_t)b * a.ldx + kbeg + ((lane & 15) ^ row) * 8;
     xdst[t] = bt * WT + q * 1024;
   }
   auto issue = [&](int ss) __attribute__((always_inline)) {   // (past the end: the last super-step again, the counts stay uniform)
-    const int k = (ss < nss ? ss : nss - 1) * 128;
+    int rs = (ss < nss ? ss : nss - 1) + ksh;
+    rs = rs >= nss ? rs - nss : rs;
+    const int k = rs * 128;
     const int slot = ss % S;
     char* xb = xs + slot * BT * WT;
 #pragma unroll
     for (int t = 0; t < BT; ++t)
-      if (!(PCY_GEMV_ABL & 1)) __builtin_amdgcn_global_load_lds((gv_gptr_t)(xsrc[t] + k), (gv_lds_ptr_t)(xb + xdst[t]), 16, 0, 0);
+      if (!(PCY_GEMV_ABL & 1) && xon[t]) __builtin_amdgcn_global_load_lds((gv_gptr_t)(xsrc[t] + k), (gv_lds_ptr_t)(xb + xdst[t]), 16, 0, 0);
     char* dst = wring + slot * RT * WT;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -913,7 +928,10 @@ __global__ __launch_bounds__(256) void gemv_mfma4_kernel(PcyGemvArgs a, int kspl
 #pragma unroll
   for (int i = 0; i < S - 1; ++i) issue(i);
   for (int ss = 0; ss < nss; ++ss) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (((PCY_GEMV_ABL & 1) ? 0 : BT) + RT * 4)) : "memory");   // this wave's copies of pair ss have landed
+    // this wave's copies of pair ss have landed ((S - 2) younger pairs of nxw + 4 RT copies may be in flight)
+    if ((PCY_GEMV_ABL & 1) || nxw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (RT * 4)) : "memory");
+    else if (BT == 1 || nxw == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (1 + RT * 4)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (2 + RT * 4)) : "memory");
     if (!(PCY_GEMV_ABL & 2)) __builtin_amdgcn_s_barrier();                                                     // ... and everybody else's; slot (ss-1) % S is free
     issue(ss + S - 1);
     if (!(PCY_GEMV_ABL & 4)) mma(ss);

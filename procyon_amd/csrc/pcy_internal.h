@@ -32,6 +32,20 @@ struct PcyGemvArgs {
   int force_mfma;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
+
+// Rotated K order of the batched GEMVs (round 6).  Every workgroup of these kernels walks ITS K range front to back in step with all the
+// others, so at any moment every wave of the chip reads the same 256-byte window of its rows -- and with a power-of-two row stride (K = 4096:
+// 8 KB) those windows fall on the same few HBM channels: tools/probes/stream_rows.hip measures the gate/up stream at 4.86 TB/s, and 6.26 TB/s
+// when workgroups start at different places of the range (padding the rows by 256 B gives the same 6.3).  A workgroup therefore starts
+// `shift` 128-k steps into its range and wraps around: a function of the 192-row group of its FIRST weight row only (192 = lcm of the row
+// blocks the launches (64) and the mid-batch step (48 / 64) cut the qkv matrix into: a row gets the same order whoever computes it, whatever
+// the batch), in units of 512 k (the x chunk of gemv_mfma2_kernel), zero when the range is not a multiple of 512.  The summation order of a
+// row's dot product is rotated with it -- the same for every kernel of the family and for the fused step, so they stay bit-identical twins.
+__host__ __device__ inline int pcy_gemv_kshift(int r0_wg, int nss) {
+  const int nch = nss >> 2;
+  return ((nss & 3) == 0 && nch > 1) ? ((r0_wg / 192 * 5) % nch) * 4 : 0;
+}
+
 // y = bf16(bf16(sum of four interleaved K-block partial sums) [+ resid]): the down projection of the small-batch decode step's launch-per-stage
 // twin (pcy_decode_nb.hip); K % 2048 == 0, no bias / norm; false = not covered
 bool pcy_launch_gemv_kwin4(hipStream_t s, const PcyGemvArgs& a);

@@ -120,14 +120,19 @@ def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
     t_mean = prompt + 8 + n / 2.0
     kv_bytes = rows * t_mean * (2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2)
     gbps = (w_bytes + kv_bytes) / 1e9 / (ms / 1e3)
+    import os
+    mb_max = int(os.environ.get("PCY_MB_MAX", "16"))
+    off = os.environ.get("PCY_DISABLE", "").split(",")
     kernel = ("small-batch decode step (hipGraph: embed, decode_step_nb_kernel = all layers in one launch, lm_head, pick)" if 2 <= rows <= 8 else
+              "mid-batch decode step (hipGraph: embed, norm, decode_step_mb_kernel = all layers in one launch, lm_head, pick)"
+              if 9 <= rows <= min(mb_max, 32) and "decode_mb_step" not in off else
               "batched decode step (hipGraph: per layer qkv / attention (+ qkv finish) / o / finish+norm / gate-up / down / finish+norm launches, lm_head, pick)")
     return {"bound": "hbm", "kernel": kernel,
             "rows": rows, "mean_cache_len": round(t_mean, 1), "ms_per_step": round(ms, 4), "tokens_per_s_decode_only": round(rows * 1e3 / ms, 1),
             "bytes_per_step": int(w_bytes + kv_bytes), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
 
 
-def decode_batch_curve(model, rows_list=(2, 4, 5, 8, 16, 32), prompt=696, new_tokens=144):
+def decode_batch_curve(model, rows_list=(2, 4, 5, 8, 10, 16, 20, 32), prompt=696, new_tokens=144):
     """ms per decode step and fraction of the HBM peak for each batch size at a mean cache length of ~768 keys (beam search runs at
     batch = beam_size, /root/reference/procyon/model/model_unified.py:751-832; the N-GPU points of configs[3] at 32 / N rows per GPU)."""
     out = []
