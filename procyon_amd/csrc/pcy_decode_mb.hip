@@ -53,7 +53,8 @@ template <int BT> struct MbCfg {
   static constexpr int RING = BT == 2 ? 6 : 7;          // tiles of a GEMV wave's ring; kept full (a step refills the slots it has just read)
   static constexpr int WBYTES = 4 * RING * 4096;        // 96 / 112 KB
   static constexpr int XBYTES = 160 * 1024 - WBYTES;    // 64 / 48 KB: x ring | attention | finisher scratch
-  static constexpr int SX = 8;                          // x steps in the ring
+  static constexpr int SX = 8;                          // x steps in the ring (12 at <= 16 rows measured the same: the single-tile phases are
+                                                        // paced by two memory round trips -- 16 (Q) / 8 (O) tiles per wave against a ring of 7)
 };
 constexpr int MB_SMEM = 160 * 1024;
 #ifndef MB_NLW
@@ -236,6 +237,7 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // x(ss) is there for everybody; slot (ss - 1) % SX is free
+    if (c.tr && t_ready == 4 && ss == 0 && tid == 0) c.tr[12] = wall_clock64();
     if (wave < nact) {
       const char* wb0 = s.ring + s.cslot * 4096;
       const int cs1 = s.cslot + 1 == RING ? 0 : s.cslot + 1;
@@ -267,6 +269,7 @@ __device__ __forceinline__ void mb_gemv_phase(const MbCtx& c, MbStream& s, const
     }
   }
   // ---- epilogue: GEMV wave w -> LDS -> wave w + 4 stores (written through), drains and the item's flag goes up ----
+  if (c.tr && tid == 0 && (t_ready == 13 || t_ready == 4)) c.tr[t_ready == 13 ? 14 : 15] = wall_clock64();
   lds_barrier();                                    // everybody is done with the x ring
   uint4* stage = reinterpret_cast<uint4*>(xring);   // [4][BT][64]
   if (wave < nact) {

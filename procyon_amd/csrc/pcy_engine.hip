@@ -215,12 +215,14 @@ int decode_xmin() {   // cached keys from which the decode attention splits its 
   return xe ? atoi(xe) : 768;
 }
 
-// (17..32 rows -- two batch tiles -- stay on the launches: there the activations every CU has to fetch per weight byte double, every byte a CU
-// loads goes through the same ~25 GB/s, and the fused step measured 5.0 / 5.3 ms at 20 / 32 rows against 4.4 / 4.6 launch by launch;
-// PCY_MB_MAX=32 runs them fused all the same: tests, tools)
+// The mid-batch step is OFF by default (round 6): bit-identical to the launches, and -- once the launches' GEMVs walk their K ranges in rotated
+// order (pcy_gemv_kshift) -- no faster: 3.98 / 4.17 ms per step at 10 / 16 rows against 3.88 / 4.02 launch by launch, 4.8 / 5.1 against 4.1 / 4.3
+// at 20 / 32 rows (two batch tiles double the activation bytes every CU fetches per weight byte).  Its streaming phases run at the HBM rate
+// (G 6.3 TB/s, D 6.1); what it loses is the Q / O phases (16 / 8 tiles per wave against a ring of 7: two memory round trips whatever the
+// prefetch) and the flag hops.  PCY_MB_MAX=<rows> (9..32) runs it up to that batch size: tests, tools/bench_decode_mb.py.
 int decode_mb_max_rows() {
   const char* e = getenv("PCY_MB_MAX");
-  return e ? atoi(e) : 16;
+  return e ? atoi(e) : 0;
 }
 int decode_mode() {
   return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |

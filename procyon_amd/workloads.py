@@ -121,7 +121,7 @@ def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
     kv_bytes = rows * t_mean * (2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * 2)
     gbps = (w_bytes + kv_bytes) / 1e9 / (ms / 1e3)
     import os
-    mb_max = int(os.environ.get("PCY_MB_MAX", "16"))
+    mb_max = int(os.environ.get("PCY_MB_MAX", "0"))
     off = os.environ.get("PCY_DISABLE", "").split(",")
     kernel = ("small-batch decode step (hipGraph: embed, decode_step_nb_kernel = all layers in one launch, lm_head, pick)" if 2 <= rows <= 8 else
               "mid-batch decode step (hipGraph: embed, norm, decode_step_mb_kernel = all layers in one launch, lm_head, pick)"

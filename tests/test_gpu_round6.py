@@ -57,16 +57,19 @@ def test_decode_mb_step_bit_identical(eng2, monkeypatch, B, T, N):
             assert torch.equal(x, y), (B, T, use_graph)
 
 
-def test_decode_mb_default_covers_9_to_16_rows(eng2, monkeypatch):
-    """Without PCY_MB_MAX the fused step takes 9..16 rows and leaves 17..32 to the launches; either way the results are the launches' bits, and
-    a step of another batch size in between (its own epoch / flag state is shared: a flag holds the epoch of the step that raised it) changes
-    nothing."""
+def test_decode_mb_switches_inside_one_process(eng2, monkeypatch):
+    """The fused step is opt-in (PCY_MB_MAX=<rows>; off by default: the launches with the rotated K order are as fast).  Switching it on and off
+    and between batch sizes inside one process keeps the launches' bits: a flag holds the epoch of the step that raised it, the epoch word only
+    counts fused steps, and a captured step is keyed on the mode."""
     from procyon_amd.engine import Context, GenState
-    monkeypatch.delenv("PCY_MB_MAX", raising=False)
     torch.manual_seed(6)
 
-    def run(B, T, step):
-        pcy_disable(monkeypatch, "" if step else "decode_mb_step")
+    def run(B, T, mb_max):
+        if mb_max is None:
+            monkeypatch.delenv("PCY_MB_MAX", raising=False)
+        else:
+            monkeypatch.setenv("PCY_MB_MAX", str(mb_max))
+        pcy_disable(monkeypatch)
         emb = (torch.randn(B, T, 4096, generator=torch.Generator().manual_seed(B)) * 0.02).to(BF).cuda()
         cache = eng2.new_cache(B, T + 6)
         st = GenState(B, KW["vocab"], 6, "cuda")
@@ -77,11 +80,13 @@ def test_decode_mb_default_covers_9_to_16_rows(eng2, monkeypatch):
         Context.get().sync()
         return st.logits.cpu().clone()
 
-    ref10, ref20, ref12 = run(10, 90, False), run(20, 60, False), run(12, 70, False)
+    ref10, ref20, ref12 = run(10, 90, None), run(20, 60, None), run(12, 70, None)       # the launches
     for _ in range(2):
-        assert torch.equal(run(10, 90, True), ref10)
-        assert torch.equal(run(20, 60, True), ref20)
-        assert torch.equal(run(12, 70, True), ref12)
+        assert torch.equal(run(10, 90, 16), ref10)      # fused
+        assert torch.equal(run(20, 60, 16), ref20)      # launches (above the limit)
+        assert torch.equal(run(20, 60, 32), ref20)      # fused, two batch tiles
+        assert torch.equal(run(12, 70, 32), ref12)
+        assert torch.equal(run(10, 90, None), ref10)
 
 
 def test_decode_mb_beam10_loop_bit_identical(eng2, monkeypatch):

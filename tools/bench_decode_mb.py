@@ -11,6 +11,7 @@ from procyon_amd import synth
 from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 
 BF = torch.bfloat16
+os.environ.setdefault("PCY_MB_MAX", "32")   # the fused step is opt-in
 
 
 def set_disable(*names):
@@ -112,7 +113,7 @@ def timing():
                 tr = buf[n // 2:].reshape(128, 256, 16)[:32].astype(np.int64)
                 lay = tr[5]
                 t0 = lay[:, 0].min()
-                names = {0: "layer start", 13: "Q: xn seen", 1: "Q published", 2: "A: q/k/v partials seen", 3: "A published", 4: "O: ao seen", 5: "O published", 6: "F1 done",
+                names = {0: "layer start", 13: "Q: xn seen", 14: "Q: last step done", 1: "Q published", 2: "A: q/k/v partials seen", 3: "A published", 4: "O: ao seen", 12: "O: x(0) in LDS", 15: "O: last step done", 5: "O published", 6: "F1 done",
                          7: "G: xn seen", 8: "G published", 9: "D: act seen", 10: "D published", 11: "F2 done"}
                 for i, nm in names.items():
                     col = (lay[:, i] - t0) / 100.0
