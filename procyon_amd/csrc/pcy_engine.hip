@@ -224,15 +224,23 @@ int decode_mb_max_rows() {
   const char* e = getenv("PCY_MB_MAX");
   return e ? atoi(e) : 0;
 }
+int decode_nb_max_rows();
 int decode_mode() {
   return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
-         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16) |
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16) | (decode_nb_max_rows() == 8 ? (1 << 28) : 0) |
          (int)((((unsigned)decode_xmin() * 2654435761u) ^ ((unsigned)decode_xmin_nb(2) * 40503u) ^ ((unsigned)decode_xmin_nb(4) * 69069u)) & 0x3fu) << 22;
 }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 // geometry of the small-batch step: Llama-3-8B, 256 CUs
+// (8 rows: since the batched launches walk their K ranges in rotated order they take 3.84 ms per step against the fused step's 3.99 --
+// the fused step stops at 7 rows; PCY_NB_MAX=8 runs it at 8 all the same: tests, tools)
+int decode_nb_max_rows() {
+  const char* e = getenv("PCY_NB_MAX");
+  const int v = e ? atoi(e) : 7;
+  return v < 8 ? v : 8;
+}
 bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {
-  return B >= 2 && B <= 8 && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
+  return B >= 2 && B <= decode_nb_max_rows() && m->d == 4096 && m->ffn == 14336 && m->n_heads == 32 && m->n_kv_heads == 8 && m->head_dim == 128 &&
          c->n_cu >= 256 && m->n_layers <= AO_MAX_LAYERS / 2;   // (score-exchange flags: 2 x AO_FLAGS words per layer)
 }
 // geometry of the mid-batch step (9..32 rows): the same model and chip
@@ -358,7 +366,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
   bf16_t* xn = cv.take<bf16_t>((size_t)B * d);        // normalised x for the batched (MFMA) GEMV path
   const size_t sk_bytes = B >= pcy_mfma_min_batch() ? (size_t)8 * B * qkvw * 4 : 0;   // K-split partial sums of the batched GEMVs
   float* sk_ws = sk_bytes ? cv.take<float>(sk_bytes / 4) : nullptr;
-  const bool batched_head = B >= pcy_mfma_min_batch() && d % 512 == 0 && F % 512 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
+  const bool batched_head = B >= pcy_mfma_min_batch() && d % 128 == 0 && F % 128 == 0;   // skinny-MFMA GEMVs, 32 rows per pass over the weights
+                                                                                         // (F = 11008, Llama-2-7B / ProCyon-Split: 86 x 128)
   // 2..8 rows: the small-batch step (pcy_decode_nb.hip) -- one launch for all layers, or its launch-per-stage twin; lm_head as before
   const bool nb_on = decode_nb_enabled() && decode_nb_covers(c, m, B) && c->nb_tags[B] && c->nb_sync && c->dev_layers && c->ao_sync && c->xwg_err &&
                      pcy_decode_nb_launchable(c->device, B, kv->Tmax, c->n_cu);

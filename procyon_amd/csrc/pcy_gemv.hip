@@ -990,13 +990,16 @@ void launch_mfma(hipStream_t s, const PcyGemvArgs& a) {
     // workgroups: 4.46 / 4.21 / 4.28 / 4.56 ms); only with a plain / residual epilogue and a workspace
     int ksplit = 1;
     constexpr int kfill = 192;
+    // K that is a multiple of 128 but not of 512 (Llama-2-7B's down projection, K = 11008 = 86 x 128: ProCyon-Split): only gemv_mfma4_kernel
+    // steps in units of 128 -- the split is then counted in those units and the older kernels (the PCY_DISABLE twins) do not apply
+    const int kunit = a.K % 512 == 0 ? 512 : 128;
     if ((EPI == EPI_STORE || EPI == EPI_RESID) && a.splitk_ws && a.N % 4 == 0 && (a.ldy & 3) == 0)
-      while (ksplit < 8 && bx * ksplit < kfill && a.K % (ksplit * 2 * 512) == 0 &&
+      while (ksplit < 8 && bx * ksplit < kfill && a.K % (ksplit * 2 * kunit) == 0 &&
              (size_t)(ksplit * 2) * a.B * a.N * 4 <= a.splitk_ws_bytes) ksplit *= 2;
     // PCY_DISABLE=gemv_lds: weights through registers (gemv_mfma2_kernel) instead of LDS-DMA; read per call, same bits
-    const bool lds = !pcy_off("gemv_lds") && a.K % (ksplit * 256) == 0;
+    const bool lds = (!pcy_off("gemv_lds") && a.K % (ksplit * 256) == 0) || kunit == 128;
     // PCY_DISABLE=gemv_mfma4: the previous schedule (gemv_mfma3_kernel: x one chunk ahead); read per call, same bits
-    const bool v4 = lds && !pcy_off("gemv_mfma4") && a.K % (ksplit * 128) == 0;
+    const bool v4 = lds && (!pcy_off("gemv_mfma4") || kunit == 128) && a.K % (ksplit * 128) == 0;
     if (v4 && (a.B <= 16 ? launch_mfma4<EPI, 1>(s, a, bx, ksplit) : launch_mfma4<EPI, 2>(s, a, bx, ksplit))) {
     } else if (lds) {
       if (a.B <= 16) launch_mfma3<EPI, 1>(s, a, bx, ksplit);
@@ -1126,7 +1129,7 @@ void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a00) {
   a0.plain_loads = 0;
   // batches from pcy_mfma_min_batch() on MFMA, 32 rows per pass over the weights (x already normalised by the caller: the fused
   // RMSNorm prologue is a feature of the streaming kernel)
-  if (!a0.force_stream && (a0.B >= pcy_mfma_min_batch() || a0.force_mfma) && a0.K % 512 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
+  if (!a0.force_stream && (a0.B >= pcy_mfma_min_batch() || a0.force_mfma) && a0.K % 128 == 0 && a0.rms_w == nullptr && (a0.ldx % 8) == 0) {
     for (int b0 = 0; b0 < a0.B; b0 += 32) {
       PcyGemvArgs a = a0;
       a.B = (a0.B - b0) < 32 ? (a0.B - b0) : 32;

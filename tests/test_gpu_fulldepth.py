@@ -282,6 +282,7 @@ def test_llama8b_full_depth_ten_ragged_rows_compat_mode(llama, golden, monkeypat
     mid-batch step (pcy_decode_mb.hip); the first 8 / 5 rows as batches of their own on the small-batch step (pcy_decode_nb.hip: so far held
     to the oracle at 2 rows only).  Per (row, step): err(HIP, fp32) <= 1.25 x err(oracle, fp32); argmax on every clear-margin (row, step)."""
     monkeypatch.delenv("PCY_DISABLE", raising=False)
+    monkeypatch.setenv("PCY_NB_MAX", "8")        # (8 rows default to the batched launches since round 6; here the fused step is what is checked)
     g = golden("f7_llama8b_rows10_T64")
     ids, mask, toks = g["ids"].long()[:nrows], g["mask"].float()[:nrows], g["tokens"].long()[:, :nrows]
     got = _rows_compat_run(llama, ids, mask, toks, nrows, list(range(nrows)))

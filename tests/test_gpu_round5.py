@@ -29,6 +29,7 @@ def test_decode_nb_step_bit_identical(eng2, monkeypatch, B, T, N, xmin):
     384 and T = 1600 at 2 rows (default threshold 1536) put the attention's key split + score exchange on (2 / 4 column slices; 5 and 8 rows:
     the units on the projection workgroups too); no watchdog (Context.sync raises)."""
     from procyon_amd.engine import Context, GenState
+    monkeypatch.setenv("PCY_NB_MAX", "8")        # (round 6: 8 rows default to the batched launches, which are faster there)
     if xmin:
         monkeypatch.setenv("PCY_AO_XMIN", str(xmin))
     torch.manual_seed(B * 1000 + T)

@@ -154,3 +154,54 @@ def test_beam_search_prefills_each_prompt_once(monkeypatch):
     else:                                               # other GEMM tiles in the beam x larger prefill: the same search up to ties inside the noise
         assert (o1[:, :, 0] == o0[:, :, 0]).all()
         assert rel_err(c1.float(), c0.float()) < 5e-2
+
+
+def test_split_geometry_batched_decode_takes_the_mfma_path(monkeypatch):
+    """ProCyon-Split's decoder (Llama-2-7B geometry: ffn 11008 = 86 x 128, 32 kv heads; /root/reference/README.md:50-51,
+    /root/reference/procyon/training/training_args_IT.py:129-134) at beam-search batch sizes: until round 6 a K that is no multiple of 512 sent
+    EVERY projection of a >= 4-row step to the streaming kernel in groups of 4 rows (three passes over the weights at 10 rows).  Now the
+    skinny-MFMA GEMVs step in units of 128 (the down projection splits K in two halves of 43 steps).  A 10-row step against (a) the same rows
+    decoded one at a time (the 1-row arithmetic: bf16 noise apart) and (b) the oracle on the CPU (2 layers)."""
+    from oracle import llama_ref as LR
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=2048, d=4096, n_layers=2, n_heads=32, n_kv_heads=32, ffn=11008)
+    sd = synth.llama_state_dict(**kw)
+    eng = LlamaEngine(sd, LlamaConfig(**kw, max_pos=512))
+    pcy_disable(monkeypatch)
+    torch.manual_seed(4)
+    B, T, N = 10, 24, 3
+    emb = (torch.randn(B, T, 4096) * 0.02).to(BF)
+
+    def run(rows):
+        n = len(rows)
+        e = emb[rows].cuda().contiguous()
+        cache = eng.new_cache(n, T + N + 2)
+        st = GenState(n, kw["vocab"], N + 2, "cuda")
+        logits, _ = eng.prefill(e, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng.pick(cache, st, n, advance_pos=False)
+        out = [logits.float().cpu()]
+        for _ in range(N):
+            eng.greedy_steps(cache, st, n, 1)
+            out.append(st.logits.float().cpu())
+        Context.get().sync()
+        return torch.stack(out), st.tokens_out[:, :N + 1].cpu()
+
+    lg10, tok10 = run(list(range(B)))
+    assert torch.isfinite(lg10).all()
+    for b in (0, 7):
+        lg1, tok1 = run([b])
+        same = bool((tok1[0] == tok10[b]).all())
+        upto = N + 1 if same else int((tok1[0] != tok10[b]).nonzero()[0])     # (a different greedy token ends the comparable prefix)
+        for s_ in range(min(upto + 1, N + 1)):
+            assert rel_err(lg10[s_, b], lg1[s_, 0]) < 2e-2, (b, s_)
+    # the oracle: prefill + the same greedy tokens teacher-forced
+    geom = LR.LlamaGeom(**kw, max_pos=512)
+    r = LR.llama_forward(sd, geom, inputs_embeds=emb, attn_mask=torch.ones(B, T), logits_rows="last")
+    assert rel_err(lg10[0], r["logits"][:, -1].float()) < 2e-2
+    past = r["past_kv"]
+    for s_ in range(N):
+        r = LR.llama_forward(sd, geom, input_ids=tok10[:, s_:s_ + 1].long(), attn_mask=None, past_kv=past, logits_rows="last")
+        past = r["past_kv"]
+        assert rel_err(lg10[s_ + 1], r["logits"][:, -1].float()) < 2e-2, s_

@@ -7,6 +7,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("PCY_NB_MAX", "8")   # the fused step at 8 rows is opt-in since round 6
 from procyon_amd import synth
 from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 

@@ -4,6 +4,7 @@ difference or as a watchdog error.  MINUTES=<wall clock> (default 3), LAYERS=<n>
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault("PCY_NB_MAX", "8")   # the fused step at 8 rows is opt-in since round 6
 from procyon_amd import synth
 from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 kw = dict(vocab=4096, d=4096, n_layers=int(os.environ.get("LAYERS", 8)), n_heads=32, n_kv_heads=8, ffn=14336)
