@@ -15,7 +15,7 @@ os.environ.setdefault("PCY_MB_MAX", "32")   # the fused step is opt-in
 
 
 def set_disable(*names):
-    names = [n for n in names if n]
+    names = [n for n in names if n] + [n for n in os.environ.get("EXTRA_DISABLE", "").split(",") if n]   # EXTRA_DISABLE: switches held through the run (A/B)
     if names:
         os.environ["PCY_DISABLE"] = ",".join(names)
     else:
