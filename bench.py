@@ -248,7 +248,7 @@ def main():
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     traffic_ratio = None
     try:
-        pname = next(n for n in (("r06_pmc_decode_step.json", "r05_pmc_decode_step.json", "r04_pmc_decode_step.json") if all_layers else ("r02_pmc_decode_layer.json",))
+        pname = next(n for n in (("r06_pmc_decode_step.json", "r05_pmc_decode_step.json") if all_layers else ("archive/r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
         if a.geometry == "full" and one_launch:

@@ -22,7 +22,7 @@ Round 4: the same runs on DAMPED weights (`synth.damp_residual_branches`, residu
 f3_llama8b_damped_T64.npz, f4_esm650m_damped_1024.npz -- where the bf16 oracle agrees with the fp32 truth on (nearly) every argmax, so the
 GPU test can assert token agreement between the HIP path and the bf16 ORACLE itself and a bound on err(HIP, oracle_bf16).
 
-    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256] [split] [rows10] [config3]
+    python tests/golden/make_fulldepth.py [llama] [esm] [llama_damped] [esm_damped] [llama_leftpad] [llama256] [split] [rows10] [config3] [config4]
 """
 from __future__ import annotations
 
@@ -257,6 +257,53 @@ def make_config3_rows():
          top_ids_fp32=top_f.indices.to(torch.int32), top_vals_fp32=top_f.values, top_ids_bf16=top_b.indices.to(torch.int32), top_vals_bf16=top_b.values)
 
 
+@torch.no_grad()
+def make_config4_pair():
+    """f9 (round 6): ONE pair of BASELINE configs[4] at full geometry in bf16 -- six <|protein|> slots (receptor 805 residues + three peptides of
+    8 .. 40, slots [0, 1, 0, 2, 0, 3] like procyon_amd/workloads.config5_inputs), a 437-token prompt ending in [ANSWER]: ESM2-650M (33 layers)
+    -> mean pool -> 3-layer token projector -> splice -> Llama-3-8B prefill (32 layers) -> the answer row's logits, P(yes) / P(no); bf16 oracle
+    and the same pipeline in fp32."""
+    PROT, ANSWER, YES, NO = 128258, 128260, 9891, 2201
+    T = 437
+    plen = [805, 17, 33, 9]
+    prot = synth.protein_tokens(plen, seed=11)
+    slots = [0, 1, 0, 2, 0, 3]
+    ids = synth.prompt_ids(1, T, 128000, dict(protein=PROT, answer=ANSWER), n_protein=6, seed=41)
+    esd = synth.esm_state_dict(**ESM)
+    proj = synth.mlp_layers(3, 1280, 4096, 2560, 0)
+    lsd = synth.llama_state_dict(**LLAMA)
+    geom = LR.LlamaGeom(**LLAMA, max_pos=4096)
+    out = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        t0 = time.time()
+        z = PR.esm_plm_forward({k: v.to(dt) for k, v in esd.items()}, ER.EsmGeom(**ESM), prot)
+        soft = PR.mlp_forward(z[slots], [(w.to(dt), b.to(dt)) for w, b in proj])
+        emb, _ = PR.prepare_input_embeddings(lsd["model.embed_tokens.weight"].to(dt), ids, PROT, soft)
+        print(f"  config4 pair {name}: esm + projector {time.time() - t0:.0f}s", flush=True)
+        c = lambda t: t.to(dt)
+        h = emb
+        cos_t, sin_t = LR.rope_tables(geom, dt, T)
+        cos, sin = cos_t[None, :T], sin_t[None, :T]
+        add_mask = LR.build_additive_mask(None, 1, T, 0, dt)
+        for i in range(geom.n_layers):
+            lw = {k: c(v) for k, v in LR._layer_weights(lsd, i).items()}
+            h, _ = LR.layer_forward(h, lw, geom, cos, sin, add_mask, None)
+        h = LR.rms_norm(h[:, -1], c(lsd["model.norm.weight"]), geom.rms_eps, geom.rms_cast)
+        lg = F.linear(h, c(lsd["lm_head.weight"]))[0]
+        p = lg.softmax(-1)
+        out[name] = (z, soft, lg, p[YES], p[NO])
+        print(f"  config4 pair {name}: total {time.time() - t0:.0f}s  P(yes) {float(p[YES]):.3e} P(no) {float(p[NO]):.3e}", flush=True)
+    lb, lf = out["bf16"][2], out["fp32"][2]
+    cols = torch.tensor(sorted(set(range(0, lb.shape[0], 127)) | set(lf.topk(8).indices.tolist()) | set(lb.float().topk(8).indices.tolist()) | {YES, NO}))
+    print(f"  config4 pair: bf16-vs-fp32 logits {rel(lb.float(), lf):.3e} pooled {rel(out['bf16'][0].float(), out['fp32'][0]):.3e} soft {rel(out['bf16'][1].float(), out['fp32'][1]):.3e}")
+    save("f9_config4_pair", protein_tokens=prot.to(torch.int32), slots=torch.tensor(slots, dtype=torch.int32), ids=ids.to(torch.int32),
+         special=torch.tensor([PROT, ANSWER, YES, NO], dtype=torch.int32), cols=cols.to(torch.int32),
+         pooled_bf16=out["bf16"][0], pooled_fp32=out["fp32"][0], soft_bf16=out["bf16"][1], soft_fp32=out["fp32"][1],
+         logits_bf16=lb[cols], logits_fp32=lf[cols], err_bf16_full=torch.tensor(rel(lb.float(), lf)), norm_fp32=lf.double().norm().float(),
+         top_ids_fp32=lf.topk(8).indices.to(torch.int32), top_ids_bf16=lb.float().topk(8).indices.to(torch.int32),
+         p_yes_no_bf16=torch.stack([out["bf16"][3], out["bf16"][4]]).float(), p_yes_no_fp32=torch.stack([out["fp32"][3], out["fp32"][4]]))
+
+
 def make_llama(damped=False, long=False):
     global NDEC
     if long:       # round 5: the headline's generation length (256 tokens) at T = 512 -> f1_llama8b_T512_N256.npz
@@ -381,3 +428,5 @@ if __name__ == "__main__":
         make_llama_rows10()
     if "config3" in what:
         make_config3_rows()
+    if "config4" in what:
+        make_config4_pair()

@@ -300,6 +300,48 @@ def test_llama8b_full_depth_config3_ragged_batch32(llama, golden, monkeypatch):
     _rows_compat_check("fulldepth/llama8b_config3_ragged_batch32_rows_0_13_31", got, g, [0, 1, 2], min_clear=3)
 
 
+def test_config4_pair_answer_row_full_depth(llama, golden):
+    """BASELINE configs[4] at full geometry, bf16, ONE pair end to end (review: the pair-scoring path was oracle-checked in miniature only):
+    fixture f9 -- six <|protein|> slots (receptor 805 residues + three peptides, slots [0, 1, 0, 2, 0, 3]), a 437-token prompt ending in
+    [ANSWER]; ESM2-650M (33 layers) -> mean pool -> 3-layer token projector -> splice -> Llama-3-8B prefill (32 layers) -> the answer row.
+    Pooled embeddings, soft tokens and the answer row's logits: err(HIP, fp32) <= 1.25 x err(oracle_bf16, fp32); the yes / no logits within
+    4 x the bf16 logit noise of the truth; P(yes) / P(no) through pcy_qa_probs equal the softmax of the engine's own row."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, EsmConfig, EsmEngine, MlpEngine
+    g = golden("f9_config4_pair")
+    prot, slots, ids = g["protein_tokens"].long(), g["slots"].long(), g["ids"].long()
+    PROT, ANSWER, YES, NO = [int(v) for v in g["special"]]
+    esm = EsmEngine(synth.esm_state_dict(**ESM, workers=8), EsmConfig(**ESM))
+    token = MlpEngine([(w.cuda(), b.cuda()) for w, b in synth.mlp_layers(3, 1280, 4096, 2560, 0)])
+    z = esm.forward(prot)
+    soft = token(z[slots.cuda()].contiguous())
+    m = (ids == PROT).view(-1)
+    smap = torch.full((ids.numel(),), -1, dtype=torch.int32)
+    smap[m] = torch.arange(int(m.sum()), dtype=torch.int32)
+    emb = llama.embed_tokens(ids, soft, smap)
+    T = ids.shape[1]
+    assert int(ids[0, -1]) == ANSWER
+    logits, _ = llama.prefill(emb, None, llama.new_cache(1, T), "last")
+    lg = logits[0].float().cpu()
+    cols = g["cols"].long()
+    truth, ref = g["logits_fp32"], g["logits_bf16"].float()
+    rec = {}
+    for name, got, key in (("pooled", z.float().cpu(), "pooled"), ("soft_tokens", soft.float().cpu(), "soft"), ("answer_logits", lg[cols], "logits")):
+        e_hip, e_ref = rel_err(got, g[key + "_fp32"]), rel_err(g[key + "_bf16"].float(), g[key + "_fp32"])
+        rec.update({f"{name}_err_hip_fp32": e_hip, f"{name}_err_oracle_fp32": e_ref, f"{name}_err_hip_oracle": rel_err(got, g[key + "_bf16"].float())})
+        assert e_hip <= SLACK * e_ref, (name, e_hip, e_ref)
+    noise = float((ref - truth).pow(2).mean().sqrt())
+    iy, in_ = int((cols == YES).nonzero()[0]), int((cols == NO).nonzero()[0])
+    for tok, i in ((YES, iy), (NO, in_)):
+        assert abs(float(lg[tok]) - float(truth[i])) <= 4.0 * noise, (tok, float(lg[tok]), float(truth[i]), noise)
+    _, yn, _ = Context.get().qa_probs(logits, YES, NO, want_probs=False)
+    p = logits.float().softmax(-1)[0]
+    assert abs(float(yn[0, 0]) - float(p[YES])) <= 2.0 ** -8 * float(p[YES]) + 1e-12 and abs(float(yn[0, 1]) - float(p[NO])) <= 2.0 ** -8 * float(p[NO]) + 1e-12
+    rec.update(p_yes_hip=float(yn[0, 0]), p_yes_oracle=float(g["p_yes_no_bf16"][0]), p_yes_fp32=float(g["p_yes_no_fp32"][0]),
+               p_no_hip=float(yn[0, 1]), p_no_oracle=float(g["p_yes_no_bf16"][1]), p_no_fp32=float(g["p_yes_no_fp32"][1]), logit_noise_rms=noise)
+    record_parity("fulldepth/config4_pair_six_slots_answer_row", **rec)
+
+
 def test_llama8b_damped_full_depth(llama_damped, golden):
     """The same comparison on the DAMPED model (residual branches x 0.25, fixture f3): round 3's review asked for a trained-like regime in
     which the bf16 oracle agrees with fp32 on >= 63 / 65 steps.  Built and measured: damping does NOT produce that regime (the oracle
