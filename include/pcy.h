@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PCY_ABI_VERSION 9
+#define PCY_ABI_VERSION 10
 
 typedef struct pcy_ctx pcy_ctx;
 
@@ -285,12 +285,17 @@ int pcy_beam_step(pcy_ctx*, const void* logits, int vocab, int B, int beam, int 
                   const pcy_beam_state* state);
 /* KV rows gather for beam search: cache[:, dst] = cache[:, src[dst]] over slots [0,t) (model_unified.py:830-832) */
 int pcy_kv_reorder(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const int32_t* src_rows, int B, int t);
+/* ... over slots [t0, t) only: for callers that know the rows hold the same contents below t0 -- the beams of a prompt share its prefix (the
+ * reference moves the whole history of every row in every group of every step, model_unified.py:830-832; moving equal bytes changes nothing).
+ * src_rows[b] may be any row of the cache (rows >= B are read straight from memory). */
+int pcy_kv_reorder_range(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const int32_t* src_rows, int B, int t0, int t);
 /* n_steps iterations (steps >= 1) of the loop body of `_generate_beam_search` (model_unified.py:751-842): decode step for the B * beam
  * rows -> logits_rec[step][row][vocab] = the step's logits (NULL: no record) -> pcy_beam_step -> pcy_kv_reorder over the slots the state's
- * position counter names; each iteration is ONE replayed launch chain.  gen_state->pos / next_tok must be the beam state's arrays.  Same
+ * position counter names, from slot kv_t0 on (0: all of them; the prompt length when the beams of a prompt share its prefix rows: see
+ * pcy_kv_reorder_range); each iteration is ONE replayed launch chain.  gen_state->pos / next_tok must be the beam state's arrays.  Same
  * results as pcy_llama_decode_graph + a copy + pcy_beam_step + pcy_kv_reorder per step. */
 int pcy_llama_beam_steps(pcy_ctx*, const pcy_llama_desc*, const pcy_kv_cache*, const pcy_gen_state*, int B, int beam, int group_size,
-                         float diversity_penalty, const pcy_beam_state* state, void* logits_rec, int n_steps);
+                         float diversity_penalty, const pcy_beam_state* state, void* logits_rec, int n_steps, int kv_t0);
 
 /* ---- fp32 operator family: the arithmetic of the reference's callers that never call `.bfloat16()` ----
  * /root/reference/examples/paper_analyses/protpep_qa_scores.py:55-58 (`model.eval().to(device)`: fp32 weights, every torch op in

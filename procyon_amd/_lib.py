@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("PCY_LIB") or os.path.join(_HERE, "libpcy.so")   # PCY
 
 EPI_STORE, EPI_RESID, EPI_GELU_ERF, EPI_GELU_ESM, EPI_SWIGLU = range(5)
 POOL_MEAN, POOL_MEAN_CORRECTED, POOL_MAX = range(3)
-ABI_VERSION = 9
+ABI_VERSION = 10
 # pcy_debug_dispatch_count kinds
 DISPATCH_GEMM_128, DISPATCH_GEMM_64, DISPATCH_GEMM_BIG, DISPATCH_GEMM_BIG_PERSIST, DISPATCH_GEMM_SPLITK, DISPATCH_GEMM_FP8, DISPATCH_ATTN_FAST, _DISPATCH_UNUSED_7, DISPATCH_GEMM_MID, DISPATCH_ESM_GRAPH = range(10)
 
@@ -119,7 +119,8 @@ SIGNATURES = {
     "pcy_llama_sample": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, C.c_float, C.c_float, vp]),
     "pcy_beam_step": (ci, [vp, vp, ci, ci, ci, ci, C.c_float, C.POINTER(BeamState)]),
     "pcy_kv_reorder": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, ci, ci]),
-    "pcy_llama_beam_steps": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, ci, C.c_float, C.POINTER(BeamState), vp, ci]),
+    "pcy_kv_reorder_range": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), vp, ci, ci, ci]),
+    "pcy_llama_beam_steps": (ci, [vp, C.POINTER(LlamaDesc), C.POINTER(KvCache), C.POINTER(GenState), ci, ci, ci, C.c_float, C.POINTER(BeamState), vp, ci, ci]),
 }
 
 _lib = None

@@ -613,7 +613,7 @@ int ensure_sample_state(pcy_ctx* c, int B, int V) {
 // re-ranks most rows at every step: 3.87 -> see DESIGN.md ms per beam-5 step at a 570-token cache.
 template <int MAXB>
 __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, const int32_t* __restrict__ rows, int B,
-                                                         int Bcache, int Hkv, int Tmax, int t, int dh, const int32_t* __restrict__ t_dev) {
+                                                         int Bcache, int Hkv, int Tmax, int t, int dh, const int32_t* __restrict__ t_dev, int t0) {
   __shared__ uint4 stage[MAXB * 128];
   const int h = blockIdx.x, lw = blockIdx.y, l = lw >> 1;
   unsigned need = 0;                                       // rows some OTHER row takes its contents from (uniform)
@@ -627,7 +627,8 @@ __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kb
   bf16_t* cache = ((lw & 1) ? vbase : kbase) + (size_t)l * Bcache * Hkv * Tmax * dh + (size_t)h * Tmax * dh;
   const size_t rstride = (size_t)Hkv * Tmax * dh;          // elements between two rows of the slab
   const size_t n8 = (size_t)t * dh / 8;
-  for (size_t i = (size_t)blockIdx.z * 128 + threadIdx.x; i < n8; i += (size_t)gridDim.z * 128) {
+  // slots [t0, t) only: the caller knows that the rows hold the same contents below t0 (beam search: the beams of a prompt share its prefix)
+  for (size_t i = (size_t)t0 * dh / 8 + (size_t)blockIdx.z * 128 + threadIdx.x; i < n8; i += (size_t)gridDim.z * 128) {
 #pragma unroll 4
     for (int b = 0; b < B; ++b)
       if ((need >> b) & 1u) stage[b * 128 + threadIdx.x] = *reinterpret_cast<const uint4*>(cache + (size_t)b * rstride + i * 8);
@@ -642,13 +643,14 @@ __global__ __launch_bounds__(128) void kv_permute_kernel(bf16_t* __restrict__ kb
   }
 }
 // enqueue: the one-pass form for <= 32 rows (PCY_DISABLE=kv_permute: the two launches through the scratch copy; same result)
-static bool enqueue_kv_permute(hipStream_t s, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t, const int32_t* t_dev) {
+static bool enqueue_kv_permute(hipStream_t s, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t, const int32_t* t_dev,
+                               int t0 = 0) {
   if (B > 32 || pcy_off("kv_permute")) return false;
   const dim3 grid(m->n_kv_heads, 2 * m->n_layers, 4);
   if (B <= 8)
-    hipLaunchKernelGGL(kv_permute_kernel<8>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev);
+    hipLaunchKernelGGL(kv_permute_kernel<8>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev, t0);
   else
-    hipLaunchKernelGGL(kv_permute_kernel<32>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev);
+    hipLaunchKernelGGL(kv_permute_kernel<32>, grid, dim3(128), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, src_rows, B, kv->B, m->n_kv_heads, kv->Tmax, t, m->head_dim, t_dev, t0);
   return true;
 }
 
@@ -656,7 +658,7 @@ static bool enqueue_kv_permute(hipStream_t s, const pcy_llama_desc* m, const pcy
 // advanced) and the scratch rows are Tmax slots apart -- nothing in the launch depends on the step.
 __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict__ vbase, bf16_t* __restrict__ tmp,
                                  const int32_t* __restrict__ rows, int B, int Bcache, int Hkv, int Tmax, int t, int dh, int to_tmp,
-                                 const int32_t* __restrict__ t_dev) {
+                                 const int32_t* __restrict__ t_dev, int t0) {
   const int b = blockIdx.x, h = blockIdx.y, lw = blockIdx.z, l = lw >> 1;
   const int src_b = rows[b];
   if (src_b == b) return;
@@ -673,7 +675,7 @@ __global__ void kv_gather_kernel(bf16_t* __restrict__ kbase, bf16_t* __restrict_
     sp = reinterpret_cast<const uint4*>(scratch + ((size_t)b * Hkv + h) * ts * dh);
     dp = reinterpret_cast<uint4*>(cache + ((size_t)b * Hkv + h) * Tmax * dh);
   }
-  for (size_t i = threadIdx.x; i < n8; i += blockDim.x) dp[i] = sp[i];
+  for (size_t i = (size_t)t0 * dh / 8 + threadIdx.x; i < n8; i += blockDim.x) dp[i] = sp[i];
 }
 
 }  // namespace
@@ -1490,21 +1492,25 @@ int pcy_beam_step(pcy_ctx* c, const void* logits, int vocab, int B, int beam, in
 }
 
 int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t) {
+  return pcy_kv_reorder_range(c, m, kv, src_rows, B, 0, t);
+}
+int pcy_kv_reorder_range(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const int32_t* src_rows, int B, int t0, int t) {
   PCY_STICKY(c);
   const int Hkv = m->n_kv_heads, dh = m->head_dim, L = m->n_layers;
-  if (t <= 0) return 0;
-  if ((t * dh) % 8) return fail(1, "pcy_kv_reorder: t * head_dim must be a multiple of 8");
+  if (t <= 0 || t0 >= t) return 0;
+  if (t0 < 0) return fail(1, "pcy_kv_reorder_range: t0 < 0");
+  if ((t * dh) % 8 || (t0 * dh) % 8) return fail(1, "pcy_kv_reorder: t * head_dim (and t0 * head_dim) must be multiples of 8");
   // scratch sized for the cache capacity, not for t: a workspace that grows step by step would be re-allocated (and the
   // captured decode graph dropped) several times per beam search
   const size_t tmp_elems = (size_t)2 * L * B * Hkv * kv->Tmax * dh;
   if (int r = c->reserve(decode_ws_bytes(m, B, kv->Tmax) + align_up(tmp_elems * 2, 256) + 4096)) return r;
   bf16_t* tmp = reinterpret_cast<bf16_t*>(c->ws + align_up(decode_ws_bytes(m, B, kv->Tmax), 256));
-  if (enqueue_kv_permute(c->stream, m, kv, src_rows, B, t, nullptr)) return check_launch("pcy_kv_reorder");
+  if (enqueue_kv_permute(c->stream, m, kv, src_rows, B, t, nullptr, t0)) return check_launch("pcy_kv_reorder");
   const dim3 grid(B, Hkv, 2 * L);
   hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
-                     kv->Tmax, t, dh, 1, (const int32_t*)nullptr);
+                     kv->Tmax, t, dh, 1, (const int32_t*)nullptr, t0);
   hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, c->stream, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, src_rows, B, kv->B, Hkv,
-                     kv->Tmax, t, dh, 0, (const int32_t*)nullptr);
+                     kv->Tmax, t, dh, 0, (const int32_t*)nullptr, t0);
   return check_launch("pcy_kv_reorder");
 }
 
@@ -1513,8 +1519,9 @@ int pcy_kv_reorder(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, 
 // slots the position counter names.  Same kernels, same order, same bits as the four calls (PCY_DISABLE=beam_graph: the callers keep
 // them); it removes the ~12 launch boundaries of a step (3.43 -> see DESIGN.md ms per step at beam 5).
 int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv, const pcy_gen_state* st, int B, int beam, int group_size,
-                         float diversity_penalty, const pcy_beam_state* bs, void* logits_rec, int n_steps) {
+                         float diversity_penalty, const pcy_beam_state* bs, void* logits_rec, int n_steps, int kv_t0) {
   PCY_STICKY(c);
+  if (kv_t0 < 0 || (kv_t0 * m->head_dim) % 8) return fail(1, "pcy_llama_beam_steps: kv_t0 = %d (>= 0, kv_t0 * head_dim a multiple of 8)", kv_t0);
   const int BB = B * beam;
   if (B <= 0 || beam <= 0 || beam > 32 || group_size <= 0 || beam % group_size)
     return fail(1, "pcy_llama_beam_steps: beam=%d (1..32) must be a multiple of group_size=%d", beam, group_size);
@@ -1550,7 +1557,7 @@ int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache
   const void* key[pcy_ctx::GRAPH_KEY_N] = {m, m->layers, m->embed, kv->k, kv->v, st->pos, st->step, st->next_tok, bs->out, bs->cur,
                                            st->logits, logits_rec, bs->src, c->ws,
                                            (const void*)(intptr_t)(((int64_t)beam << 40) ^ ((int64_t)group_size << 32) ^ kv->Tmax),
-                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ pen_bits),
+                                           (const void*)(intptr_t)(((int64_t)kv->B << 32) ^ pen_bits ^ ((int64_t)kv_t0 << 44)),
                                            c->beam_ws, bs->anc, (const void*)(uintptr_t)(c->layers_fp ^ bsh ^ fold)};
   if (!c->graph || memcmp(key, c->graph_key, sizeof(key)) != 0 || c->graph_B != BB || c->graph_mode != decode_mode() || c->graph_kind != 2) {
     c->drop_graph();
@@ -1570,12 +1577,12 @@ int pcy_llama_beam_steps(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache
         hipLaunchKernelGGL(store_logits_kernel, dim3(BB >= 8 ? 256 : 64), dim3(256), 0, s, (const bf16_t*)st->logits, (bf16_t*)logits_rec, bs->step, BB,
                            m->vocab, m->vocab);
       pcy_launch_beam_step(s, (const bf16_t*)st->logits, m->vocab, B, beam, group_size, diversity_penalty, b, c->beam_ws);
-      if (!enqueue_kv_permute(s, m, kv, bs->src, BB, 0, (const int32_t*)bs->pos)) {
+      if (!enqueue_kv_permute(s, m, kv, bs->src, BB, 0, (const int32_t*)bs->pos, kv_t0)) {
         const dim3 grid(BB, Hkv, 2 * L);
         hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 1,
-                           (const int32_t*)bs->pos);
+                           (const int32_t*)bs->pos, kv_t0);
         hipLaunchKernelGGL(kv_gather_kernel, grid, dim3(256), 0, s, (bf16_t*)kv->k, (bf16_t*)kv->v, tmp, bs->src, BB, kv->B, Hkv, kv->Tmax, 0, dh, 0,
-                           (const int32_t*)bs->pos);
+                           (const int32_t*)bs->pos, kv_t0);
       }
       e0 = hipStreamEndCapture(c->cap_stream, &g);
     }

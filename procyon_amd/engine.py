@@ -595,11 +595,12 @@ class LlamaEngine:
         L.check(self.ctx.lib.pcy_beam_step(self.ctx.h, _p(logits), logits.shape[1], bs.B, bs.beam, group_size, float(diversity_penalty),
                                            C.byref(bs.c)), "pcy_beam_step")
 
-    def beam_steps(self, cache: KVCache, st: GenState, bs: "BeamState", group_size, diversity_penalty, logits_rec, n_steps):
-        """n_steps iterations of the beam loop body (decode -> record -> beam step -> KV reorder), each ONE replayed launch chain
-        (pcy_llama_beam_steps); st.pos / st.next_tok are the beam state's arrays."""
+    def beam_steps(self, cache: KVCache, st: GenState, bs: "BeamState", group_size, diversity_penalty, logits_rec, n_steps, kv_t0=0):
+        """n_steps iterations of decode -> record -> beam step -> KV reorder, each ONE replayed launch chain
+        (pcy_llama_beam_steps); st.pos / st.next_tok are the beam state's arrays.  kv_t0: first cache slot the reorder moves (the prompt
+        length when the beams of a prompt hold the same prefix rows)."""
         L.check(self.ctx.lib.pcy_llama_beam_steps(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), bs.B, bs.beam, group_size,
-                                                  float(diversity_penalty), C.byref(bs.c), _p(logits_rec), n_steps), "pcy_llama_beam_steps")
+                                                  float(diversity_penalty), C.byref(bs.c), _p(logits_rec), n_steps, int(kv_t0)), "pcy_llama_beam_steps")
 
     def pick(self, cache: KVCache, st: GenState, B, advance_pos):
         L.check(self.ctx.lib.pcy_greedy_pick(self.ctx.h, C.byref(self.desc), C.byref(cache.c), C.byref(st.c), B, int(advance_pos)),
@@ -637,9 +638,10 @@ class LlamaEngine:
         la = None if st.logits_all is None else st.logits_all.transpose(0, 1)
         return st.tokens_out.long(), st.logprob, la, (st, cache, u)
 
-    def kv_reorder(self, cache, src_rows, t):
+    def kv_reorder(self, cache, src_rows, t, t0=0):
+        """cache[:, b] = cache[:, src_rows[b]] over slots [t0, t) (t0 > 0: the rows are known to hold the same contents below t0)"""
         src = src_rows.to(self.device, torch.int32).contiguous()
-        L.check(self.ctx.lib.pcy_kv_reorder(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(src), src.numel(), t), "pcy_kv_reorder")
+        L.check(self.ctx.lib.pcy_kv_reorder_range(self.ctx.h, C.byref(self.desc), C.byref(cache.c), _p(src), src.numel(), int(t0), t), "pcy_kv_reorder")
 
     def generate_greedy(self, embeds, attn_mask, max_len, keep_logits=False, clean_decode_mask=False, use_graph=True):
         """`_generate_sampling(greedy=True)` (model_unified.py:861-921): prefill, then max_len-1 cached decode

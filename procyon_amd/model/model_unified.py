@@ -601,6 +601,12 @@ class UnifiedProCyon:
                     logit_positions=torch.full((BB,), T - 1), want_hidden=False)
             cache = o.past_key_values.cache
             logits = o.logits[:, -1, :].contiguous()
+        # The beams of a prompt hold the SAME K / V rows in slots [0, T): the reference re-indexes the whole history of every row in every group
+        # of every step (:830-832); moving equal bytes changes nothing, so the reorder starts at slot T (pcy_kv_reorder_range; at 10 beams and a
+        # 512-token prompt the reorder was 0.4-0.6 ms of a 4.5 ms step).  PCY_DISABLE=beam_kv_suffix: every slot, as the reference (same result).
+        kv_t0 = 0 if "beam_kv_suffix" in os.environ.get("PCY_DISABLE", "").split(",") else T
+        if (kv_t0 * self.text_encoder.cfg.head_dim) % 8:
+            kv_t0 = 0
         bs = BeamState(B, beam_size, max_len, self.tokenizer.eos_token_id, prompt_len=T, device=dev)
         st = GenState(BB, V, 1, dev)
         st.pos, st.next_tok = bs.pos, bs.next_tok                  # the decode graph reads what the beam step writes
@@ -615,7 +621,7 @@ class UnifiedProCyon:
                     logits = st.logits
                 rec[i].copy_(logits)
                 eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
-                eng.kv_reorder(cache, bs.src, T + i)
+                eng.kv_reorder(cache, bs.src, T + i, t0=kv_t0)
                 if (i & 7) == 7 and int(bs.done):
                     break
         else:
@@ -623,13 +629,13 @@ class UnifiedProCyon:
             # chain (pcy_llama_beam_steps), enqueued up to the next multiple of 8 steps, where the host looks at the EOS flag
             rec[0].copy_(logits)
             eng.beam_step(logits, bs, beam_group_size, diversity_penalty)
-            eng.kv_reorder(cache, bs.src, T)
+            eng.kv_reorder(cache, bs.src, T, t0=kv_t0)
             i = 1
             while i < max_len:
                 if T + i > cache.Tmax:
                     raise ValueError(f"KV cache capacity {cache.Tmax} exhausted; raise max_new_tokens")
                 n = min(8 - (i & 7), max_len - i, cache.Tmax - T - i + 1)
-                eng.beam_steps(cache, st, bs, beam_group_size, diversity_penalty, rec, n)
+                eng.beam_steps(cache, st, bs, beam_group_size, diversity_penalty, rec, n, kv_t0=kv_t0)
                 i += n
                 if (i & 7) == 0 and int(bs.done):
                     break

@@ -205,3 +205,29 @@ def test_split_geometry_batched_decode_takes_the_mfma_path(monkeypatch):
         r = LR.llama_forward(sd, geom, input_ids=tok10[:, s_:s_ + 1].long(), attn_mask=None, past_kv=past, logits_rows="last")
         past = r["past_kv"]
         assert rel_err(lg10[s_ + 1], r["logits"][:, -1].float()) < 2e-2, s_
+
+
+def test_beam_search_reorders_only_the_suffix(monkeypatch):
+    """The beams of a prompt share its prefix rows, so the per-step K / V reorder moves slots [T, t) only (pcy_kv_reorder_range;
+    PCY_DISABLE=beam_kv_suffix: every slot, what /root/reference/procyon/model/model_unified.py:830-832 does).  Both forms, through the replayed
+    chain and through the four calls per step, on a two-prompt ragged batch: tokens, scores and the logits record EQUAL."""
+    from procyon_amd import synth
+    from procyon_amd import synthetic_model as SM
+    from procyon_amd.engine import Context
+    model = SM.build("small", device="cuda", max_new_tokens=48)
+    prot = synth.protein_tokens([90, 41], seed=3)
+    instr = ["w5 w6 <|protein|> w7 [ANSWER]", "w1 w2 <|protein|> and w3 w4 w8 w9 w2 w3 [ANSWER]"]
+    inputs = lambda: {"data": {"seq": prot, "seq_idx": torch.arange(2), "text": [], "drug": None},
+                      "input": {"seq": [[0], [1]], "text": [[], []], "drug": None},
+                      "target": {"seq": None, "text": None, "drug": None}, "instructions": list(instr)}
+    outs = []
+    for beam, group, max_len in ((6, 2, 21), (10, 2, 12), (5, 5, 9)):
+        kw = dict(max_len=max_len, method="beam", beam_size=beam, beam_group_size=group, diversity_penalty=0.8)
+        res = []
+        for off in ("", "beam_kv_suffix", "beam_graph", "beam_graph,beam_kv_suffix"):
+            pcy_disable(monkeypatch, *[o for o in off.split(",") if o])
+            res.append(model.generate(inputs(), **kw)[:3])
+            Context.get().sync()
+        for r in res[1:]:
+            for x, y in zip(r, res[0]):
+                assert torch.equal(x, y), (beam, group)
