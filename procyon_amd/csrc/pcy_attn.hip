@@ -1144,6 +1144,7 @@ bool pcy_launch_attn_o(hipStream_t s, const PcyDecAttnArgs& a, const PcyGemvArgs
 bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
                              const unsigned* step_epoch, unsigned* xflags) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256) return false;
+  if (pcy_launch_decode_mha(s, a, p, mc, nullptr, n_cu, step_epoch, xflags)) return true;   // 32 kv heads, ffn 11008 (pcy_decode_mha.hip)
   switch (a.H / a.Hkv) {
     case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, xflags, n_cu);
     case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, xflags, n_cu);
@@ -1158,6 +1159,7 @@ bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAt
 bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs& st,
                             int n_cu, const unsigned* step_epoch) {
   if (a.B != 1 || a.dh != 128 || a.dbg || n_cu < 256 || st.n_layers < 1) return false;
+  if (pcy_launch_decode_mha(s, a, p, mc, &st, n_cu, step_epoch, a.xflags)) return true;
   switch (a.H / a.Hkv) {
     case 1: return launch_decode_layer<128, 1>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);
     case 2: return launch_decode_layer<128, 2>(s, a, p, mc, step_epoch, a.xflags, n_cu, &st);

@@ -467,6 +467,8 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.keep = st->keep; t.ld_keep = kv->Tmax; t.scratch = scores; t.B = B; t.H = H; t.Hkv = Hkv; t.dh = dh; t.Tmax = kv->Tmax;
     t.scale = 1.0f / sqrtf((float)dh);
     t.force_ds = nb_on ? pcy_decode_nb_ds(B) : 0;
+    // (multi-head geometry, one row: the column split of the fused step's attention workgroups, whatever the launch mix -- one set of bits)
+    if (B == 1 && pcy_decode_mha_covers(d, H, Hkv, dh, F, c->n_cu)) t.force_ds = pcy_decode_mha_ds();
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
     o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes; o.force_stream = nb_on;

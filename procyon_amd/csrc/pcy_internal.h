@@ -241,6 +241,13 @@ bool pcy_launch_decode_step(hipStream_t s, const PcyDecAttnArgs& a, const PcyAtt
                             int n_cu, const unsigned* step_epoch);
 bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, int n_cu,
                              const unsigned* step_epoch, unsigned* xflags);
+// The same for the multi-head geometry (pcy_decode_mha.hip: 32 kv heads of 128, d 4096, 7168 < ffn <= 14336 -- Llama-2-7B / ProCyon-Split):
+// one layer (st == nullptr) or all layers in one launch; tried first by the two launchers above.  The launch-per-stage twin's attention must
+// cut its output into pcy_decode_mha_ds() columns per workgroup (the summation order of P.V).
+bool pcy_decode_mha_covers(int d, int H, int Hkv, int dh, int F, int n_cu);
+int pcy_decode_mha_ds();
+bool pcy_launch_decode_mha(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs* st, int n_cu,
+                           const unsigned* step_epoch, unsigned* xflags);
 // Small-batch decode step (pcy_decode_nb.hip): every decoder layer for 2..8 rows in ONE launch, the weights streamed once.  Hand-over slots
 // per layer: pcy_decode_nb_tag_words(B) words (act | qkv | attention output | x after o, B rows each), residual stream between two layers:
 // pcy_decode_nb_line_words(B) words; p.epoch = the tag counter of THIS batch size's slots.  false = not covered, nothing launched.

@@ -15,17 +15,18 @@ constexpr int MC_LDS_IT0 = 4;      // the gate/up batch (k-iterations 4, 5 of a 
 // before_batch(it0) runs ahead of the arithmetic of every batch (the down stage waits there for the second half of its input).
 // LDS_IT0 >= 0 and lds_batch != nullptr: the batch (u0, LDS_IT0) waits in LDS (this wave's own 16 KB, image of mc_lds_prefetch: register j of lane l at
 // j * 1024 + l * 16) and is taken from there instead of from memory.
-template <int RW, int UNB, int LDS_IT0 = -1, typename RowOff, typename Finish, typename Before>
+// KTAIL: K % 512 may be 256 (ffn 11008 = 21.5 x 512, Llama-2-7B): the last k-iteration is cut per lane, as gemv_stream_kernel cuts it.
+template <int RW, int UNB, int LDS_IT0 = -1, bool KTAIL = false, typename RowOff, typename Finish, typename Before>
 __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, const bf16_t* xs, int lane, int u0, int ustride, int uend,
                                           uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch,
                                           const char* lds_batch = nullptr) {
   static_assert(RW * UNB <= 16, "batch size");
-  const int nit = K >> 9;
+  const int nit = KTAIL ? (K + 511) >> 9 : K >> 9;
   auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int un = 0; un < UNB; ++un) {
       const int k = ((it0 + un) * 64 + lane) * 8;
-      const bool ok = (it0 + un) < nit;
+      const bool ok = KTAIL ? k < K : (it0 + un) < nit;
 #pragma unroll
       for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
     }
@@ -36,7 +37,7 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
   auto compute = [&](int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int un = 0; un < UNB; ++un) {
-      if ((it0 + un) < nit) {
+      if (KTAIL ? ((it0 + un) * 64 + lane) * 8 < K : (it0 + un) < nit) {
         const uint4 xv = *reinterpret_cast<const uint4*>(xs + ((it0 + un) * 64 + lane) * 8);
 #pragma unroll
         for (int i = 0; i < RW; ++i) acc[i] = dot8(w[un * RW + i], xv, acc[i]);
