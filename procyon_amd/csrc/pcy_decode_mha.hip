@@ -54,6 +54,26 @@ __device__ __forceinline__ void mh_fetch_finish(const uint32_t* src, int w0, int
           make_uint2((pre[j].x & 0xffffu) | (pre[j].y << 16), (pre[j].z & 0xffffu) | (pre[j].w << 16));
 }
 
+// mc_fetch_vector (pcy_handover.h) with barriers that leave the weight requests in flight alone (lds_barrier: no vmcnt drain)
+__device__ __forceinline__ void mh_fetch_vector(const uint32_t* src, int n, int watch_wave, uint32_t tag, bf16_t* dst, unsigned* err, unsigned code) {
+  const int tid_ = pcy_tid(), lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  if (wave == watch_wave) {
+    unsigned spins = 0;
+    for (;;) {
+      const uint4 v = ld16_agent(src + n - 256 + lane * 4);
+      const bool ok = (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
+      if (__builtin_amdgcn_readfirstlane(__all(ok))) break;
+      if (pcy_wait_give_up(spins, 1u << 19, err, code, lane)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  lds_barrier();
+  uint4 t[2];
+  mc_fetch_issue<2>(src, wave * 512, lane, t);
+  mc_fetch_finish<2>(src, wave * 512, lane, tag, dst, t, err, code);
+  lds_barrier();
+}
+
 // Stages 1 and 2 of the MLP for one of 256 workgroups (mc_mlp_body of pcy_mlp_chain.h for 7168 < F <= 14336, F % 256 == 0, x in LDS):
 //   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) handed over as tagged words, x_out = x + act . Wdown^T.
 // LDS: [d] normalised x | [F] act | [d] x (already there) | red.  primed: bit 0 / 1 = the first / second batch of the wave's first gate/up
@@ -188,9 +208,9 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
     {
       uint4 wa[16], wb[16];
       if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, true);   // 32 KB per wave while x is on its way
-      __syncthreads();                                   // the attention's LDS is dead
+      lds_barrier();                                     // the attention's LDS is dead
       bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
-      mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);
+      mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);
       MH_T(3)
       mh_mlp_body(mc, smem, vthr_gu, tag, blockIdx.x, 3, wa, wb, tr ? tr + 8 : nullptr, x_out_lines);
       MH_T(5)
@@ -207,12 +227,10 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   uint4 wa[16], wb[16], ga[16], gb[16];
   const int rq0 = pw * 64 + wave * 4;
   auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(rq0 + u * 32 + i) * d; };
-  const bf16_t* xsrc = p.x;
   if (x_in_lines) {
     // the first batch in front of the loads that fetch x, the second behind them (a CU's loads return in order)
     mc_prime<4, 4, 1>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q);
     mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 2>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q); });
-    xsrc = xin;
     mc_rms_stage(xin, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, []() __attribute__((always_inline)) {});
   } else {
     mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 3>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q); });
@@ -225,6 +243,12 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       for (int i = 0; i < 4; ++i) line[u * 32 + wave * 4 + i] = (tag << 16) | f2bf(rbf(acc[i]));
     }
   }, [](int) __attribute__((always_inline)) {});
+  // the workgroup's 64 qkv rows = two 128-byte lines of the tagged vector, stored by one instruction -- in FRONT of the weight requests below
+  // and behind a barrier that does not drain them (__syncthreads() waits for vmcnt(0): with the Wo rows requested first the rows were
+  // published 7 us later, in-kernel stamps)
+  lds_barrier();
+  if (wave == 0) __hip_atomic_store(p.qkv_tag + pw * 64 + lane, line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  MH_T(1)
   // o rows [r0, r0 + 4) (the first d / 32 projection workgroups): into the same registers while the attention runs; the first batch of the
   // wave's gate/up rows beside them
   const int r0 = pw * 32 + wave * 4;
@@ -233,13 +257,16 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   float res[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     mc_prime<4, 4, 3>(p.wo, K, lane, 0, 1, 1, wa, wb, row_o);
+    // (two address spaces, two branches: through one pointer these would be flat loads, which count in vmcnt AND lgkmcnt)
+    if (x_in_lines) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) res[i] = bf2f(xsrc[r0 + i]);
+      for (int i = 0; i < 4; ++i) res[i] = bf2f(xin[r0 + i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res[i] = bf2f(p.x[r0 + i]);
+    }
   }
   if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, ga, gb, false);   // (both batches for the workgroups without o rows: 210 spilled VGPRs)
-  __syncthreads();   // the workgroup's 64 qkv rows = two 128-byte lines of the tagged vector, stored by one instruction
-  if (wave == 0) __hip_atomic_store(p.qkv_tag + pw * 64 + lane, line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  MH_T(1)
   // the attention output: one wave watches a 1 KB sample, then every wave takes its share
   if (wave == 0) {
     unsigned spins = 0;
@@ -251,14 +278,14 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       __builtin_amdgcn_s_sleep(4);
     }
   }
-  __syncthreads();
+  lds_barrier();
   MH_T(2)
   {
     uint4 tq[2];
     mc_fetch_issue<2>(p.ao_tag, wave * 512, lane, tq);
     mc_fetch_finish<2>(p.ao_tag, wave * 512, lane, tag, xa, tq, p.err, 11u);
   }
-  __syncthreads();
+  lds_barrier();
   MH_T(3)
   if (active) {
     uint32_t* oline = reinterpret_cast<uint32_t*>(red);   // the workgroup's 32 results, stored as one line by one wave
@@ -272,15 +299,15 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
         }
       }
     }, [](int) __attribute__((always_inline)) {});
-    __syncthreads();
+    lds_barrier();
     if (wave == 0 && lane < 32) __hip_atomic_store(p.xo_tag + pw * 32 + lane, (tag << 16) | oline[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   MH_T(4)
   // the second batch of this wave's gate/up rows while the residual stream is on its way
   if (wave < 7) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, 1, (mc.F + 3) / 4, ga, gb, McRowG{mc.F, mc.d});
-  __syncthreads();                                     // every wave is done with the attention output in LDS
+  lds_barrier();                                       // every wave is done with the attention output in LDS
   bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
-  mc_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
+  mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
   mh_mlp_body(mc, smem, vthr_gu, tag, blockIdx.x, 3, ga, gb, tr ? tr + 8 : nullptr, x_out_lines);
   MH_T(5)
 #undef MH_T
