@@ -229,7 +229,8 @@ def main():
 
     off = set(os.environ.get("PCY_DISABLE", "").split(","))   # procyon_amd/csrc/pcy_switch.h
     # ---- roofline of the dominant kernel: the decode LAYER launch (qkv + attention + o + gate/up + down of one layer, one per layer per token)
-    one_launch = (cfg.d == 4096 and cfg.ffn == 14336 and cfg.n_heads * cfg.head_dim == 4096 and
+    mha = cfg.n_kv_heads == cfg.n_heads == 32 and cfg.ffn == 11008   # ProCyon-Split (Llama-2-7B): decode_step_mha_kernel, pcy_decode_mha.hip
+    one_launch = (cfg.d == 4096 and (cfg.ffn == 14336 or mha) and cfg.n_heads * cfg.head_dim == 4096 and
                   not (off & {"decode_layer", "attn_o"}))
     all_layers = one_launch and "decode_step" not in off   # decode_step_kernel: the 32 layers in ONE launch
     t_mid = int(st.pos.item())                     # cache length of the measured launches (the timed decode ended here)
@@ -261,8 +262,9 @@ def main():
                               f"{v['hbm_bytes_per_launch']} B against {v['algorithmic_bytes']} algorithmic; that ratio x this launch's algorithmic bytes")
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": ("decode_step_kernel<128,4> (all 32 Llama decoder layers of a decode step in one launch: per layer qkv, attention, o, gate/up, down)"
-                                           if all_layers else "decode_layer_kernel<128,4> (one Llama decoder layer per launch; 32 launches/token)"
+    kname = ("decode_step_mha_kernel", "decode_layer_mha_kernel") if mha else ("decode_step_kernel<128,4>", "decode_layer_kernel<128,4>")
+    roofline = {"bound": "hbm", "kernel": (f"{kname[0]} (all {cfg.n_layers} Llama decoder layers of a decode step in one launch: per layer qkv, attention, o, gate/up, down)"
+                                           if all_layers else f"{kname[1]} (one Llama decoder layer per launch; {cfg.n_layers} launches/token)"
                                            if one_launch else "decoder layer as separate launches (average per layer)"),
                 "achieved": round(k_bytes / 1e9 / (k_ms / 1e3), 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(k_bytes / 1e9 / (k_ms / 1e3) / 8000.0, 4), "traffic": traffic, "traffic_over_algorithmic": None if traffic_ratio is None else round(traffic_ratio, 4),

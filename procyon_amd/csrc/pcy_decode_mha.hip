@@ -8,12 +8,16 @@
 //     register batches (mc_stream), the first unit requested around the fetch of x;
 //   * 32 kv heads, one query head each: an attention unit = (kv head, 64 output columns), 2 x 32 = 64 units on workgroups [0, 64) -- the
 //     head's keys split between its two slices above PCY_AO_XMIN keys (the score exchange of attn_dec_body);
-//   * ffn = 11008 = 21.5 x 512: the gate/up stage has 2752 units of 4 features for 1792 waves -- round one is exactly the first 7168 features
-//     (the first 14 k-iterations of the down projection, as on Llama-3), the 960 units of round two are dealt one per (wave, workgroup) with
-//     the wave index major, so that every CU keeps 3-4 waves streaming; the down projection's last k-iteration is half a one (KTAIL).
-// Per-row arithmetic, accumulation order and rounding points are those of gemv_stream_kernel (RMSNorm statistics summed with the
+//   * ffn = 11008 = 21.5 x 512: the gate/up stage deals feature PAIRS (4 weight rows) to all 2048 waves, 5504 pairs in three rounds, the
+//     1408 pairs of the last one wave-major so that every CU keeps 5-6 waves streaming; the down projection starts on the first 7168 act
+//     words (14 k-iterations, as on Llama-3) and its last k-iteration is half a one (KTAIL);
+//   * every projection walks its k-iterations in the rotated order of PcyGemvArgs::krot (K = 4096: 8 KB row stride, see there);
+//   * barriers inside the layer are lds_barrier (no vmcnt drain): a __syncthreads() behind a weight request waits for the weights.
+// Per-row arithmetic, accumulation order and rounding points are those of gemv_stream_kernel with krot (RMSNorm statistics summed with the
 // stand-alone launches' thread counts) and of attn_dec_kernel<128, 1, 64>: bit-identical to the launch-per-stage step with 64-column
-// attention workgroups (PCY_DISABLE=decode_step,decode_layer; tests/test_gpu_round6.py).
+// attention workgroups (PCY_DISABLE=decode_step,decode_layer; tests/test_gpu_round6.py).  In-kernel stamps (tools/bench_decode_mha.py,
+// PCY_MC_TRACE=1), one layer at t ~ 600: x arrives at 11 us (48 MB of Wqkv requested at 3), qkv rows published at 20, attention 22 -> 30,
+// o rows stored at 34, gate/up from 39, down from ~63, end at 76-78 us: 417 MB at 5.4 TB/s.
 #include <stdlib.h>
 #include "pcy_internal.h"
 #include "pcy_handover.h"
@@ -23,9 +27,20 @@
 namespace {
 
 constexpr int MH_DH = 128, MH_DS = 64, MH_HKV = 32, MH_NATTN = (MH_DH / MH_DS) * MH_HKV;   // 64 attention workgroups
-constexpr int MH_R1 = 256 * 7;                                                             // gate/up units of round one (one per wave)
-constexpr int MH_HALF = MH_R1 * 4;                                                         // act words of round one = 14 k-iterations of the down rows
+constexpr int MH_NW = 256 * 8;       // waves of the launch: the gate/up stage deals PAIRS of features (4 weight rows) to all of them, three rounds
+constexpr int MH_D = 4096;           // hidden size; LDS of every workgroup: [d] normalised x / attention output | [d] x | red [128] | act [F]
+constexpr int MH_OFF_X = MH_D * 2, MH_OFF_RED = 2 * MH_D * 2, MH_OFF_ACT = MH_OFF_RED + 512;
+constexpr int MH_HALF = 7168;        // act words the down rows start on = 14 k-iterations (pairs [0, 3584): rounds one and two, mostly)
 
+// weight row i (0, 1: gate, 2, 3: up) of feature pair h (16-row gate/up interleave of the packed matrix)
+struct MhRowPair {
+  int F, d;
+  __device__ __forceinline__ size_t operator()(int h, int i) const {
+    const int f = h * 2 + (i & 1);
+    const int fc = f < F ? f : F - 1;
+    return (size_t)((fc >> 4) * 32 + (fc & 15) + (i >= 2 ? 16 : 0)) * d;
+  }
+};
 // this wave's share of a tagged vector, `nj` (wave-uniform, <= NV) loads of 256 words: mc_fetch_issue / mc_fetch_finish with a ragged end
 template <int NV>
 __device__ __forceinline__ void mh_fetch_issue(const uint32_t* src, int w0, int lane, uint4 (&pre)[NV], int nj) {
@@ -74,18 +89,69 @@ __device__ __forceinline__ void mh_fetch_vector(const uint32_t* src, int n, int 
   lds_barrier();
 }
 
+// first (WHICH & 1) / second (WHICH & 2) half (k-iterations 0-3 / 4-7 in the rotated order) of the 4 rows of feature pair gw (round one)
+// -> wa / wb: what mh_mlp_body(primed) expects
+template <int WHICH>
+__device__ __forceinline__ void mh_prime_gate_up(const PcyMlpChainArgs& a, int lane, int gw, uint4 (&wa)[16], uint4 (&wb)[16]) {
+  const int nit_g = a.d >> 9;
+  mc_prime<4, 4, WHICH>(a.wgu, a.d, lane, gw, 1, a.F / 2, wa, wb, MhRowPair{a.F, a.d}, [&](int h) __attribute__((always_inline)) { return (h >> 1) % nit_g; });
+}
+
+// mc_rms_stage (pcy_handover.h) for x in LDS, with barriers that leave the weight requests in flight alone: xs[0..K) = bf16(RMSNorm(x) * w),
+// the statistic summed like gemv_stream_kernel launched with `vthr` threads.  K <= 8 * 512.  All threads; ends with a barrier.
+__device__ __forceinline__ void mh_rms_stage(const bf16_t* x, const bf16_t* __restrict__ w, int K, int vthr, float eps, int cast, bf16_t* xs, float* red) {
+  const int tid = pcy_tid();
+  const int ks = tid * 8;
+  uint4 g = make_uint4(0, 0, 0, 0);
+  if (ks < K) g = ldg16(w + ks);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (tid + i * vthr) * 8;
+    if (tid < vthr && k < K) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(x + k);
+      const uint32_t w4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float f0 = lo_bf(w4[j]), f1 = hi_bf(w4[j]); ss += f0 * f0 + f1 * f1; }
+    }
+  }
+  {   // block_sum_rt(ss, red, vthr >> 6)
+    ss = wave_sum(ss);
+    lds_barrier();
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    lds_barrier();
+    float t = 0.f;
+    for (int i = 0; i < (vthr >> 6); ++i) t += red[i];
+    ss = t;
+  }
+  const float rs = rsqrtf(ss / (float)K + eps);
+  if (ks < K) {
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + ks);
+    const uint32_t xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x0 = lo_bf(xin[j]) * rs, x1 = hi_bf(xin[j]) * rs;
+      if (cast == 0) { x0 = rbf(x0); x1 = rbf(x1); }
+      o[j] = pack_bf(lo_bf(gin[j]) * x0, hi_bf(gin[j]) * x1);
+    }
+    *reinterpret_cast<uint4*>(xs + ks) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  lds_barrier();
+}
+
 // Stages 1 and 2 of the MLP for one of 256 workgroups (mc_mlp_body of pcy_mlp_chain.h for 7168 < F <= 14336, F % 256 == 0, x in LDS):
 //   act = SwiGLU(RMSNorm(x) * ln2 . Wgu^T) handed over as tagged words, x_out = x + act . Wdown^T.
-// LDS: [d] normalised x | [F] act | [d] x (already there) | red.  primed: bit 0 / 1 = the first / second batch of the wave's first gate/up
+// LDS: [d] normalised x | [d] x (already there) | red | [F] act.  primed: bit 0 / 1 = the first / second batch of the wave's first gate/up
 // unit is already in wa / wb.  x_out_lines as mc_mlp_body.
 __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem, int vthr_gu, uint32_t tag, int wg, int primed, uint4 (&wa)[16],
                                             uint4 (&wb)[16], unsigned long long* tr, uint32_t* x_out_lines) {
   constexpr int G = 256;
   const int d = a.d, F = a.F;
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* xa = xs + d;
-  bf16_t* xr = xa + F;
-  float* red = reinterpret_cast<float*>(xr + d);
+  bf16_t* xr = reinterpret_cast<bf16_t*>(smem + MH_OFF_X);
+  float* red = reinterpret_cast<float*>(smem + MH_OFF_RED);
+  bf16_t* xa = reinterpret_cast<bf16_t*>(smem + MH_OFF_ACT);
   const int tid = pcy_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = G * MC_WV, gw = wg * MC_WV + wave;
   uint4 tq[4];
@@ -93,39 +159,39 @@ __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem
   const bf16_t* xin = xr;
   const int units_d = d / 2, r0 = gw * 2;
   auto row_d = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(u * 2 + i) * F; };
-  // ---- stage 1: units of 4 features (8 weight rows), 7 waves per workgroup; local unit 0 = round one, 1 = round two ----
-  const int units_g = (F + 3) / 4, gidx = wg * 7 + wave;
-  const int u2 = MH_R1 + wave * G + wg;
-  const int nloc = u2 < units_g ? 2 : 1;
-  const McRowG row_g{F, d};
-  auto row_gl = [&](int u, int i) __attribute__((always_inline)) -> size_t { return row_g(u == 0 ? gidx : u2, i); };
-  mc_rms_stage(xin, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
-    if (wave < 7) {
-      if (primed == 0) mc_prime<8, 2, 3>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl);
-      else if (primed == 1) mc_prime<8, 2, 2>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl);
-    }
-  });
-  if (wave < 7) {
-    mc_stream<8, 2>(a.wgu, d, xs, lane, 0, 1, nloc, wa, wb, true, row_gl, [&](int u, const float (&acc)[8]) __attribute__((always_inline)) {
-      if (lane == 0) {
-        const int unit = u == 0 ? gidx : u2;
-        uint32_t o[4];
+  // ---- stage 1: feature pairs (4 weight rows, two batches of 4 k-iterations), every wave: pair gw in round one, 2048 + gw in round two, and
+  // the 1408 pairs of round three dealt wave-major (5-6 waves of every CU).  In units of 4 features on 7 waves (the Llama-3 body) 960 units
+  // were left for a second round that ran on 3-4 waves per CU with 32 KB in flight each: 13.6 us for 63 MB (in-kernel stamps).
+  const int n_pairs = F >> 1;
+  const int h3 = 2 * MH_NW + wave * G + wg;
+  const int nloc = h3 < n_pairs ? 3 : 2;
+  const MhRowPair row_p{F, d};
+  auto pair_of = [&](int u) __attribute__((always_inline)) { return u == 0 ? gw : (u == 1 ? MH_NW + gw : h3); };
+  auto row_gl = [&](int u, int i) __attribute__((always_inline)) -> size_t { return row_p(pair_of(u), i); };
+  const int nit_g = d >> 9;
+  auto shift_g = [&](int u) __attribute__((always_inline)) { return (pair_of(u) >> 1) % nit_g; };   // rotated k order (PcyGemvArgs::krot)
+  mh_rms_stage(xin, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red);
+  if (primed == 0) mc_prime<4, 4, 3>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
+  else if (primed == 1) mc_prime<4, 4, 2>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
+  MH_T(5)
+  mc_stream<4, 4>(a.wgu, d, xs, lane, 0, 1, nloc, wa, wb, true, row_gl, [&](int u, const float (&acc)[4]) __attribute__((always_inline)) {
+    if (u == 0) { MH_T(4) }
+    if (lane == 0) {
+      uint32_t o[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float g = rbf(acc[i]), up = rbf(acc[i + 4]);
-          o[i] = (tag << 16) | f2bf(rbf(silu_f(g)) * up);
-        }
-        st8_agent(a.act_tag + unit * 4, o[0], o[1]);
-        st8_agent(a.act_tag + unit * 4 + 2, o[2], o[3]);
+      for (int i = 0; i < 2; ++i) {
+        const float g = rbf(acc[i]), up = rbf(acc[i + 2]);
+        o[i] = (tag << 16) | f2bf(rbf(silu_f(g)) * up);
       }
-    }, [](int) __attribute__((always_inline)) {});
-    MH_T(1)
-    // ---- stage 2 begins for this wave: round one's part of act, then (once it is there) the first two batches of its down rows ----
-    mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);
-  }
+      st8_agent(a.act_tag + pair_of(u) * 2, o[0], o[1]);
+    }
+  }, [](int) __attribute__((always_inline)) {}, nullptr, shift_g);
+  MH_T(1)
+  // ---- stage 2 begins for this wave: the first part of act, then (once it is there) the first two batches of its down rows ----
+  if (wave < 7) mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);
   if (wave < 7) mc_fetch_finish<4>(a.act_tag, wave * 1024, lane, tag, xa, tq, a.err, 6u);
   mc_prime<2, MC_UNB_D>(a.wdown, F, lane, gw, NW, units_d, wa, wb, row_d);
-  // round two's part: words [MH_HALF, F), 1024 per wave in loads of 256
+  // the second part: words [MH_HALF, F), 1024 per wave in loads of 256
   int nj2 = (F - MH_HALF - wave * 1024) / 256;
   nj2 = wave < 7 ? (nj2 < 0 ? 0 : (nj2 > 4 ? 4 : nj2)) : 0;
   mh_fetch_issue<4>(a.act_tag, MH_HALF + wave * 1024, lane, tq, nj2);
@@ -207,9 +273,9 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
     MH_T(2)
     {
       uint4 wa[16], wb[16];
-      if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, true);   // 32 KB per wave while x is on its way
+      mh_prime_gate_up<3>(mc, lane, (int)blockIdx.x * 8 + wave, wa, wb);   // 32 KB per wave while x is on its way
       lds_barrier();                                     // the attention's LDS is dead
-      bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
+      bf16_t* xr = reinterpret_cast<bf16_t*>(smem + MH_OFF_X);
       mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 12u);
       MH_T(3)
       mh_mlp_body(mc, smem, vthr_gu, tag, blockIdx.x, 3, wa, wb, tr ? tr + 8 : nullptr, x_out_lines);
@@ -219,21 +285,23 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   }
   // ---- projection workgroups: 64 qkv rows each (two units of 4 per wave), the first 128 of them 32 o rows each ----
   const int d = p.d, K = a.H * DH;
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);             // [d]  RMSNorm(x) * ln1
-  bf16_t* xa = xs + d;                                      // [K]  attention output
-  float* red = reinterpret_cast<float*>(xa + K);            // [64] + a 64-word line
-  bf16_t* xin = reinterpret_cast<bf16_t*>(red + 128);       // [d]  the layer's input when it arrives as a tagged vector
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                   // [d]  RMSNorm(x) * ln1, then (the qkv rows done) ...
+  bf16_t* xa = xs;                                                // [K]  ... the attention output
+  bf16_t* xin = reinterpret_cast<bf16_t*>(smem + MH_OFF_X);       // [d]  the layer's input when it arrives as a tagged vector, then x after o
+  float* red = reinterpret_cast<float*>(smem + MH_OFF_RED);       // [64] + a 64-word line
   const int pw = (int)blockIdx.x - MH_NATTN;
   uint4 wa[16], wb[16], ga[16], gb[16];
   const int rq0 = pw * 64 + wave * 4;
   auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(rq0 + u * 32 + i) * d; };
+  const int nit_q = d >> 9;
+  auto shift_q = [&](int u) __attribute__((always_inline)) { return ((rq0 + u * 32) >> 2) % nit_q; };   // rotated k order (PcyGemvArgs::krot)
   if (x_in_lines) {
     // the first batch in front of the loads that fetch x, the second behind them (a CU's loads return in order)
-    mc_prime<4, 4, 1>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q);
-    mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 2>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q); });
+    mc_prime<4, 4, 1>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q);
+    mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 2>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q); });
     mc_rms_stage(xin, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, []() __attribute__((always_inline)) {});
   } else {
-    mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 3>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q); });
+    mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 3>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q); });
   }
   MH_T(14)
   uint32_t* line = reinterpret_cast<uint32_t*>(red) + 64;
@@ -242,7 +310,7 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
 #pragma unroll
       for (int i = 0; i < 4; ++i) line[u * 32 + wave * 4 + i] = (tag << 16) | f2bf(rbf(acc[i]));
     }
-  }, [](int) __attribute__((always_inline)) {});
+  }, [](int) __attribute__((always_inline)) {}, nullptr, shift_q);
   // the workgroup's 64 qkv rows = two 128-byte lines of the tagged vector, stored by one instruction -- in FRONT of the weight requests below
   // and behind a barrier that does not drain them (__syncthreads() waits for vmcnt(0): with the Wo rows requested first the rows were
   // published 7 us later, in-kernel stamps)
@@ -250,13 +318,16 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   if (wave == 0) __hip_atomic_store(p.qkv_tag + pw * 64 + lane, line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   MH_T(1)
   // o rows [r0, r0 + 4) (the first d / 32 projection workgroups): into the same registers while the attention runs; the first batch of the
-  // wave's gate/up rows beside them
+  // wave's gate/up rows beside them.  (The second batch by LDS-DMA as well, 16 KB per wave into the idle act region: 100 MB instead of 67 in
+  // flight during the ~9 us of the attention, the polls for its output queue behind them -- 2.47 -> 2.62 ms per token.)
   const int r0 = pw * 32 + wave * 4;
   const bool active = r0 < d;                 // (workgroup-uniform: d % 32 == 0)
   auto row_o = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(r0 + i) * K; };
+  const int nit_o = K >> 9;
+  auto shift_o = [&](int) __attribute__((always_inline)) { return (r0 >> 2) % nit_o; };
   float res[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
-    mc_prime<4, 4, 3>(p.wo, K, lane, 0, 1, 1, wa, wb, row_o);
+    mc_prime<4, 4, 3>(p.wo, K, lane, 0, 1, 1, wa, wb, row_o, shift_o);
     // (two address spaces, two branches: through one pointer these would be flat loads, which count in vmcnt AND lgkmcnt)
     if (x_in_lines) {
 #pragma unroll
@@ -266,7 +337,7 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
       for (int i = 0; i < 4; ++i) res[i] = bf2f(p.x[r0 + i]);
     }
   }
-  if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, ga, gb, false);   // (both batches for the workgroups without o rows: 210 spilled VGPRs)
+  mh_prime_gate_up<1>(mc, lane, (int)blockIdx.x * 8 + wave, ga, gb);
   // the attention output: one wave watches a 1 KB sample, then every wave takes its share
   if (wave == 0) {
     unsigned spins = 0;
@@ -298,16 +369,15 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
           oline[wave * 4 + i] = f2bf(v);
         }
       }
-    }, [](int) __attribute__((always_inline)) {});
+    }, [](int) __attribute__((always_inline)) {}, nullptr, shift_o);
     lds_barrier();
     if (wave == 0 && lane < 32) __hip_atomic_store(p.xo_tag + pw * 32 + lane, (tag << 16) | oline[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   MH_T(4)
   // the second batch of this wave's gate/up rows while the residual stream is on its way
-  if (wave < 7) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, 1, (mc.F + 3) / 4, ga, gb, McRowG{mc.F, mc.d});
+  mh_prime_gate_up<2>(mc, lane, (int)blockIdx.x * 8 + wave, ga, gb);
   lds_barrier();                                       // every wave is done with the attention output in LDS
-  bf16_t* xr = reinterpret_cast<bf16_t*>(smem) + mc.d + mc.F;
-  mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xr, p.err, 13u);
+  mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xin, p.err, 13u);
   mh_mlp_body(mc, smem, vthr_gu, tag, blockIdx.x, 3, ga, gb, tr ? tr + 8 : nullptr, x_out_lines);
   MH_T(5)
 #undef MH_T
@@ -344,7 +414,7 @@ __global__ __launch_bounds__(512) void decode_step_mha_kernel(PcyDecAttnArgs a, 
 
 // Geometry the multi-head step covers (what pcy_engine.hip asks before it forces the launch-per-stage twin's attention to 64 columns).
 bool pcy_decode_mha_covers(int d, int H, int Hkv, int dh, int F, int n_cu) {
-  return dh == MH_DH && H == MH_HKV && Hkv == MH_HKV && d == 4096 && F > MH_HALF && F <= 2 * MH_HALF && F % 256 == 0 && n_cu >= 256;
+  return dh == MH_DH && H == MH_HKV && Hkv == MH_HKV && d == MH_D && F / 2 > 2 * 2048 && F / 2 <= 3 * 2048 && F % 256 == 0 && n_cu >= 256;
 }
 int pcy_decode_mha_ds() { return MH_DS; }
 
@@ -361,8 +431,8 @@ bool pcy_launch_decode_mha(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockAr
   a.xmin = xmin;
   a.unit_map = 1;
   const size_t stage_off = (attn_dec_smem_bytes(1, MH_DS, MH_DH, a.Tmax) + 15) & ~(size_t)15;
-  const size_t smem_attn = stage_off + (size_t)3 * MH_DH * 2, smem_o = (size_t)(2 * p.d + a.H * MH_DH) * 2 + 512;
-  const size_t smem_mlp = (size_t)(2 * mc.d + mc.F) * 2 + 128;
+  const size_t smem_attn = stage_off + (size_t)3 * MH_DH * 2, smem_o = (size_t)MH_OFF_ACT;
+  const size_t smem_mlp = (size_t)MH_OFF_ACT + (size_t)mc.F * 2 + 128;
   size_t smem = smem_attn > smem_o ? smem_attn : smem_o;
   smem = smem > smem_mlp ? smem : smem_mlp;
   if (smem > 160 * 1024) return false;

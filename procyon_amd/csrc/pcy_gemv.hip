@@ -213,11 +213,14 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
     }
     return (size_t)r * K;
   };
+  // a.krot (K % 512 == 0): the unit of output row r walks its k-iterations rotated by (r / 4) % nit -- see PcyGemvArgs::krot
+  const bool krot = a.krot && (K & 511) == 0;
+  auto rot = [&](int u, int it) { if (!krot) return it; const int r = it + ((u * R) >> 2) % nit; return r >= nit ? r - nit : r; };
   auto issue = [&](int u, int it0, uint4 (&wv)[UN][RW]) {
 #pragma unroll
     for (int un = 0; un < UN; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
-      const bool ok = k < K;
+      const int k = (rot(u, it0 + un) * 64 + lane) * 8;
+      const bool ok = k < K && it0 + un < nit;
 #pragma unroll
       for (int i = 0; i < RW; ++i)
         wv[un][i] = ok ? (a.plain_loads ? *reinterpret_cast<const uint4*>(a.W + row_off(u, i) + k) : ldg_nt(a.W + row_off(u, i) + k))
@@ -231,11 +234,11 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
   };
-  auto compute = [&](int it0, const uint4 (&wv)[UN][RW]) {
+  auto compute = [&](int u, int it0, const uint4 (&wv)[UN][RW]) {
 #pragma unroll
     for (int un = 0; un < UN; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
-      if (k < K) {
+      const int k = (rot(u, it0 + un) * 64 + lane) * 8;
+      if (k < K && it0 + un < nit) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const uint4 xv = DIRECTX ? *reinterpret_cast<const uint4*>(a.x + (size_t)b * a.ldx + k)
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
     // take batch i+2
 #define PCY_GEMV_STEP2(CUR, NXT)                                 \
   {                                                              \
-    compute(it0, CUR);                                           \
+    compute(u, it0, CUR);                                        \
     if (it0 + UN >= nit) finish(u);                              \
     int u2, it2;                                                 \
     next_pos(u1, it1, u2, it2);                                  \
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(512) void gemv_stream_kernel(PcyGemvArgs a, int uni
     if (nit0 >= nit) { nit0 = 0; nu = u + nw; }                  \
     const bool nhave = nu < units;                               \
     if (nhave) issue(nu, nit0, NXT);                             \
-    compute(it0, CUR);                                           \
+    compute(u, it0, CUR);                                        \
     if (nit0 == 0) finish(u);                                    \
     u = nu; it0 = nit0; have = nhave;                            \
   }

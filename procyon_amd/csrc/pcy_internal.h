@@ -30,6 +30,11 @@ struct PcyGemvArgs {
   // 1: the MFMA kernel (x already normalised, rms_w == NULL) whatever the batch, one row included -- the prefill's lm_head, so that a row's
   // logits are the same bits for every number of rows asked for AND 32 rows share a pass over the 1 GB matrix
   int force_mfma;
+  // 1 (streaming kernel, one row, K % 512 == 0): the dot product of output row r (feature r for EPI_SWIGLU) walks its 512-element k-iterations
+  // rotated by (r / 4) % (K / 512).  All waves of the chip otherwise read the same 1 KB window of their rows at the same moment, and with the
+  // 8 KB row stride of K = 4096 those windows fall on the same HBM channels (round 6, tools/probes/stream_rows.hip).  The order of the sum is
+  // a function of the row alone: the fused multi-head decode step (pcy_decode_mha.hip) uses the same one, so the two stay bit-identical twins.
+  int krot;
 };
 void pcy_launch_gemv(hipStream_t s, const PcyGemvArgs& a);
 

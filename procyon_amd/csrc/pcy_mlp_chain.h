@@ -3,6 +3,7 @@
 #pragma once
 #include "pcy_common.h"
 #include "pcy_internal.h"
+#include <type_traits>
 #include "pcy_handover.h"
 
 namespace {
@@ -16,16 +17,21 @@ constexpr int MC_LDS_IT0 = 4;      // the gate/up batch (k-iterations 4, 5 of a 
 // LDS_IT0 >= 0 and lds_batch != nullptr: the batch (u0, LDS_IT0) waits in LDS (this wave's own 16 KB, image of mc_lds_prefetch: register j of lane l at
 // j * 1024 + l * 16) and is taken from there instead of from memory.
 // KTAIL: K % 512 may be 256 (ffn 11008 = 21.5 x 512, Llama-2-7B): the last k-iteration is cut per lane, as gemv_stream_kernel cuts it.
-template <int RW, int UNB, int LDS_IT0 = -1, bool KTAIL = false, typename RowOff, typename Finish, typename Before>
+// shift(u) (McNoShift: none): unit u walks its k-iterations rotated, it -> (it + shift(u)) % nit (K % 512 == 0) -- see PcyGemvArgs::krot.
+struct McNoShift { __device__ __forceinline__ int operator()(int) const { return 0; } };
+template <int RW, int UNB, int LDS_IT0 = -1, bool KTAIL = false, typename RowOff, typename Finish, typename Before, typename Shift = McNoShift>
 __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, const bf16_t* xs, int lane, int u0, int ustride, int uend,
                                           uint4 (&wa)[16], uint4 (&wb)[16], bool primed, RowOff row_off, Finish finish, Before before_batch,
-                                          const char* lds_batch = nullptr) {
+                                          const char* lds_batch = nullptr, Shift shift = Shift()) {
   static_assert(RW * UNB <= 16, "batch size");
+  constexpr bool ROT = !std::is_same<Shift, McNoShift>::value;
+  static_assert(!(ROT && KTAIL), "rotated order: whole k-iterations only");
   const int nit = KTAIL ? (K + 511) >> 9 : K >> 9;
+  auto rot = [&](int u, int it) __attribute__((always_inline)) { if (!ROT) return it; const int r = it + shift(u); return r >= nit ? r - nit : r; };
   auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int un = 0; un < UNB; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
+      const int k = (rot(u, it0 + un) * 64 + lane) * 8;
       const bool ok = KTAIL ? k < K : (it0 + un) < nit;
 #pragma unroll
       for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);
@@ -34,11 +40,11 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
   float acc[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) acc[i] = 0.f;
-  auto compute = [&](int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
+  auto compute = [&](int u, int it0, const uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int un = 0; un < UNB; ++un) {
       if (KTAIL ? ((it0 + un) * 64 + lane) * 8 < K : (it0 + un) < nit) {
-        const uint4 xv = *reinterpret_cast<const uint4*>(xs + ((it0 + un) * 64 + lane) * 8);
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + (rot(u, it0 + un) * 64 + lane) * 8);
 #pragma unroll
         for (int i = 0; i < RW; ++i) acc[i] = dot8(w[un * RW + i], xv, acc[i]);
       }
@@ -60,17 +66,17 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
     static_assert(LDS_IT0 < 0 || (UNB == 2 && LDS_IT0 == 4), "prologue written for 4 batches of 2 k-iterations per unit");
     if (lds_batch != nullptr && nit == 8 && have && u0 + ustride < uend) {
       before_batch(0);
-      compute(0, wa);
+      compute(u0, 0, wa);
       issue(u0, 6, wa);
       before_batch(2);
-      compute(2, wb);
+      compute(u0, 2, wb);
       // LDS-DMA copies are not covered by the compiler's wait insertion.  They are older than b3's 16 loads (and b1's before them); loads
       // return in order, so "at most 16 outstanding" means they have landed -- and b3 stays in flight.
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
       for (int j = 0; j < 16; ++j) wb[j] = *reinterpret_cast<const uint4*>(lds_batch + j * 1024 + lane * 16);
       before_batch(4);
-      compute(4, wb);
+      compute(u0, 4, wb);
       issue(u0 + ustride, 0, wb);
       u = u0; it0 = 6; u1 = u0 + ustride; it1 = 0; have = true; have1 = true;
     }
@@ -78,7 +84,7 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
 #define PCY_MC_STEP(CUR)                                   \
   {                                                        \
     before_batch(it0);                                     \
-    compute(it0, CUR);                                     \
+    compute(u, it0, CUR);                                  \
     if (it0 + UNB >= nit) {                                \
       _Pragma("unroll") for (int i = 0; i < RW; ++i) acc[i] = wave_sum(acc[i]); \
       finish(u, acc);                                      \
@@ -100,14 +106,16 @@ __device__ __forceinline__ void mc_stream(const bf16_t* __restrict__ W, int K, c
 }
 // request the first two batches of unit u0 (what mc_stream(primed = true) expects to find)
 // WHICH: 1 = the first batch only, 2 = the second only, 3 = both
-template <int RW, int UNB, int WHICH = 3, typename RowOff>
+template <int RW, int UNB, int WHICH = 3, typename RowOff, typename Shift = McNoShift>
 __device__ __forceinline__ void mc_prime(const bf16_t* __restrict__ W, int K, int lane, int u0, int ustride, int uend, uint4 (&wa)[16], uint4 (&wb)[16],
-                                         RowOff row_off) {
+                                         RowOff row_off, Shift shift = Shift()) {
   const int nit = K >> 9;
+  constexpr bool ROT = !std::is_same<Shift, McNoShift>::value;
+  auto rot = [&](int u, int it) __attribute__((always_inline)) { if (!ROT) return it; const int r = it + shift(u); return r >= nit ? r - nit : r; };
   auto issue = [&](int u, int it0, uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
     for (int un = 0; un < UNB; ++un) {
-      const int k = ((it0 + un) * 64 + lane) * 8;
+      const int k = (rot(u, it0 + un) * 64 + lane) * 8;
       const bool ok = (it0 + un) < nit;
 #pragma unroll
       for (int i = 0; i < RW; ++i) w[un * RW + i] = ok ? ldg_nt(W + row_off(u, i) + k) : make_uint4(0, 0, 0, 0);

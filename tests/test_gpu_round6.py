@@ -231,3 +231,73 @@ def test_beam_search_reorders_only_the_suffix(monkeypatch):
         for r in res[1:]:
             for x, y in zip(r, res[0]):
                 assert torch.equal(x, y), (beam, group)
+
+
+@pytest.mark.parametrize("T,N", [(40, 6), (300, 6), (764, 8), (1100, 4)])
+def test_split_decode_step_bit_identical(monkeypatch, T, N):
+    """ProCyon-Split's decoder (Llama-2-7B geometry: 32 kv heads, ffn 11008; /root/reference/README.md:50-51) at one row: every layer of a decode
+    step in ONE launch (decode_step_mha_kernel, pcy_decode_mha.hip) against one launch per layer (PCY_DISABLE=decode_step) and against the
+    launch-per-stage step (PCY_DISABLE=decode_step,decode_layer: streaming GEMVs in the rotated k order, 64-column attention workgroups), launched
+    one by one and replayed: logits, tokens and the appended K / V rows EQUAL -- across the key-split threshold of the attention (768 keys)."""
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=4096, d=4096, n_layers=2, n_heads=32, n_kv_heads=32, ffn=11008)
+    eng = LlamaEngine(synth.llama_state_dict(**kw), LlamaConfig(**kw, max_pos=2048))
+    torch.manual_seed(T)
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF).cuda()
+
+    def run(off, use_graph):
+        pcy_disable(monkeypatch, *[o for o in off.split(",") if o])
+        cache = eng.new_cache(1, T + N + 2)
+        st = GenState(1, kw["vocab"], N + 2, "cuda")
+        logits, _ = eng.prefill(emb, None, cache, "last")
+        st.logits.copy_(logits); st.pos.fill_(T)
+        eng.pick(cache, st, 1, advance_pos=False)
+        out = []
+        for _ in range(N):
+            eng.greedy_steps(cache, st, 1, 1, use_graph=use_graph)
+            out.append(st.logits.clone())
+        Context.get().sync()
+        return torch.stack(out).cpu(), st.tokens_out[:, :N + 1].cpu(), cache.k[:, :, :, T:T + N].cpu(), cache.v[:, :, :, T:T + N].cpu()
+
+    ref = run("decode_step,decode_layer", False)
+    assert torch.isfinite(ref[0].float()).all()
+    for off, g in (("", False), ("", True), ("", True), ("decode_step", False), ("decode_step", True), ("decode_step,decode_layer", True)):
+        got = run(off, g)
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), (off, g)
+
+
+def test_split_decode_step_against_the_oracle(monkeypatch):
+    """The one-launch Split step held to the oracle directly (2 layers, teacher-forced on the step's own greedy tokens), not only to its twin:
+    /root/reference/procyon/model/pmc_llama.py:571-588 restated in oracle/llama_ref.py.  Bar: the bf16 pipeline's own noise (rel. error of the
+    logits row < 2e-2, as the batched Split test above; full depth: f6, tests/test_gpu_fulldepth.py)."""
+    from oracle import llama_ref as LR
+    from procyon_amd import synth
+    from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
+    kw = dict(vocab=2048, d=4096, n_layers=2, n_heads=32, n_kv_heads=32, ffn=11008)
+    sd = synth.llama_state_dict(**kw)
+    eng = LlamaEngine(sd, LlamaConfig(**kw, max_pos=512))
+    pcy_disable(monkeypatch)
+    torch.manual_seed(11)
+    T, N = 37, 5
+    emb = (torch.randn(1, T, 4096) * 0.02).to(BF)
+    cache = eng.new_cache(1, T + N + 2)
+    st = GenState(1, kw["vocab"], N + 2, "cuda")
+    logits, _ = eng.prefill(emb.cuda(), None, cache, "last")
+    st.logits.copy_(logits); st.pos.fill_(T)
+    eng.pick(cache, st, 1, advance_pos=False)
+    out = [logits.float().cpu()]
+    for _ in range(N):
+        eng.greedy_steps(cache, st, 1, 1)
+        out.append(st.logits.float().cpu())
+    Context.get().sync()
+    tok = st.tokens_out[:, :N + 1].cpu()
+    geom = LR.LlamaGeom(**kw, max_pos=512)
+    r = LR.llama_forward(sd, geom, inputs_embeds=emb, attn_mask=torch.ones(1, T), logits_rows="last")
+    assert rel_err(out[0], r["logits"][:, -1].float()) < 2e-2
+    past = r["past_kv"]
+    for s_ in range(N):
+        r = LR.llama_forward(sd, geom, input_ids=tok[:, s_:s_ + 1].long(), attn_mask=None, past_kv=past, logits_rows="last")
+        past = r["past_kv"]
+        assert rel_err(out[s_ + 1], r["logits"][:, -1].float()) < 2e-2, s_

@@ -98,7 +98,7 @@ def timing():
                 lay = tr[l]
                 t0 = lay[:, 0].min()
                 names = {0: "start", 14: "RMSNorm(x) in LDS", 1: "qkv stored / q,k,v staged", 2: "attention done / ao seen", 3: "ao in LDS / xo in LDS", 4: "o stored",
-                         9: "gate/up done", 10: "act part 1 in LDS", 11: "act part 2 in LDS", 5: "layer end"}
+                         13: "RMSNorm(xo) in LDS", 12: "gate/up round one done", 9: "gate/up done", 10: "act part 1 in LDS", 11: "act part 2 in LDS", 5: "layer end"}
                 for grp, sl in (("attention wgs", slice(0, 64)), ("o-row wgs", slice(64, 192)), ("qkv-only wgs", slice(192, 256))):
                     print(f"  -- layer {l} {grp}")
                     for i, nm in names.items():
