@@ -374,7 +374,9 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
     if (wave == 0 && lane < 32) __hip_atomic_store(p.xo_tag + pw * 32 + lane, (tag << 16) | oline[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   MH_T(4)
-  // the second batch of this wave's gate/up rows while the residual stream is on its way
+  // the second batch of this wave's gate/up rows while the residual stream is on its way.  (BEHIND the loads that fetch it -- they wait for
+  // whatever was requested in front of them -- the first fetch often finds a line of another workgroup not yet current, and the retry then
+  // queues behind the batch: 2.47 -> 2.59 ms per token.)
   mh_prime_gate_up<2>(mc, lane, (int)blockIdx.x * 8 + wave, ga, gb);
   lds_barrier();                                       // every wave is done with the attention output in LDS
   mh_fetch_vector(p.xo_tag, mc.d, 7, tag, xin, p.err, 13u);
