@@ -249,11 +249,12 @@ def main():
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     traffic_ratio = None
     try:
-        pname = next(n for n in (("r06_pmc_decode_step.json", "r05_pmc_decode_step.json") if all_layers else ("archive/r02_pmc_decode_layer.json",))
+        pname = next(n for n in ((("r06_pmc_decode_step_mha.json",) if mha else ("r06_pmc_decode_step.json", "r05_pmc_decode_step.json")) if all_layers
+                                 else ("archive/r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]
-        if a.geometry == "full" and one_launch:
-            v = [v for k, v in pm.items() if "decode_step_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
+        if one_launch and (a.geometry == "full" or (mha and all_layers)):
+            v = [v for k, v in pm.items() if "decode_step_kernel" in k or "decode_step_mha_kernel" in k or "decode_layer_kernel" in k or "attn_block_kernel" in k][0]
             # the counters were taken at another cache length (t = 512..536) than this run's timed region: the measured / algorithmic
             # RATIO carries over, the byte count is scaled to this run's launch (review, round 4: not two numbers from different lengths)
             traffic_ratio = v["hbm_bytes_per_launch"] / v["algorithmic_bytes"]

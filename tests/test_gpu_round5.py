@@ -199,7 +199,8 @@ def test_split_geometry_config0_full_depth(golden):
     protein, a 128-token prompt, 64 greedy tokens.  Fixture f6 = the oracle in fp32 (the reference's CPU arithmetic for this config).
     (a) the fp32 operator family (what a caller that never calls .bfloat16() gets): SAME 64 tokens, every logit <= 1e-4;
     (b) the bf16 engine on the bf16-rounded weights: pooled / soft token within bf16 noise, tokens equal up to the first step whose top-2
-        margin lies inside 4 x the logit noise (the margin rule), decode on the launch-per-stage path (the fused steps are Llama-3-8B's)."""
+        margin lies inside 4 x the logit noise (the margin rule); since round 6 the 64 decode steps run in the one-launch step of this geometry
+        (decode_step_mha_kernel, pcy_decode_mha.hip)."""
     from conftest import record_parity, rel_err
     from procyon_amd import synth
     from procyon_amd.engine import EsmConfig, EsmEngine, LlamaConfig, LlamaEngine, MlpEngine
