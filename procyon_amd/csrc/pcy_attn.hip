@@ -536,21 +536,30 @@ __global__ __launch_bounds__(512) void attn_dec_splitk_kernel(PcyDecAttnArgs a, 
   const float* ws = a.qkv_partials;
   const int splits = a.qkv_splits, H = a.H, Hkv = a.Hkv, B = a.B, ld = a.ld;
   a.staged = stage;
-  auto hook = [=]() __attribute__((always_inline)) {
-    const int tid = pcy_tid();
-    constexpr int NV4 = (G + 2) * DH / 4;
-    static_assert(NV4 <= 512, "one quad per thread");
-    if (tid < NV4) {
-      const int seg = tid / (DH / 4), e4 = tid % (DH / 4);
-      const int n = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)b * ld + n);
-      for (int s_ = 1; s_ < splits; ++s_) {
+  // The first two splits are requested HERE, in front of the cache rows the body asks for (a CU's loads return in order: requested from the
+  // hook, behind ~200 KB of K tiles and V rows, they came back last and the rope -- the head of the chain -- waited for every prefetched
+  // cache row), and the barrier of the hook leaves the cache rows in flight (round 6).
+  const int tid0 = pcy_tid();
+  constexpr int NV4 = (G + 2) * DH / 4;
+  static_assert(NV4 <= 512, "one quad per thread");
+  const int seg = tid0 / (DH / 4), e4 = tid0 % (DH / 4);
+  const int n = (seg < G ? (kvh * G + seg) : (seg == G ? H + kvh : H + Hkv + kvh)) * DH + e4 * 4;
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+  if (tid0 < NV4) {
+    p0 = *reinterpret_cast<const f32x4*>(ws + (size_t)b * ld + n);
+    if (splits > 1) p1 = *reinterpret_cast<const f32x4*>(ws + ((size_t)B + b) * ld + n);
+  }
+  auto hook = [&]() __attribute__((always_inline)) {
+    if (tid0 < NV4) {
+      f32x4 v = p0;
+      if (splits > 1) { v[0] += p1[0]; v[1] += p1[1]; v[2] += p1[2]; v[3] += p1[3]; }
+      for (int s_ = 2; s_ < splits; ++s_) {
         const f32x4 p = *reinterpret_cast<const f32x4*>(ws + ((size_t)s_ * B + b) * ld + n);
         v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
       }
       *reinterpret_cast<uint2*>(stage + seg * DH + e4 * 4) = make_uint2(pack_bf(rbf(v[0]), rbf(v[1])), pack_bf(rbf(v[2]), rbf(v[3])));
     }
-    __syncthreads();
+    lds_barrier();
   };
   attn_dec_body<DH, G, DS>(a, smem, blockIdx.x, kvh, b, hook);
 }
