@@ -295,22 +295,56 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(rq0 + u * 32 + i) * d; };
   const int nit_q = d >> 9;
   auto shift_q = [&](int u) __attribute__((always_inline)) { return ((rq0 + u * 32) >> 2) % nit_q; };   // rotated k order (PcyGemvArgs::krot)
+  // The wave's 8 rows = four batches of 4 rows x 4 k-iterations; THREE of them are requested before x is there (wa, wb, and ga, which is idle
+  // until the attention): 72 MB of the 100 MB of Wqkv in flight from the first cycle of the layer (two batches: 48 MB had landed 2.5 us before x
+  // arrived and the fourth was one more round trip).  The first in front of the loads that fetch x, the others behind them (a CU's loads return
+  // in order).  Same k order per row as mc_stream<4, 4> with shift_q.
+  auto q_it = [&](int u, int it) __attribute__((always_inline)) { const int r = it + shift_q(u); return r >= nit_q ? r - nit_q : r; };
+  auto q_issue = [&](int u, int half, uint4 (&w)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int un = 0; un < 4; ++un) {
+      const int k = (q_it(u, half * 4 + un) * 64 + lane) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[un * 4 + i] = ldg_nt(p.wqkv + row_q(u, i) + k);
+    }
+  };
   if (x_in_lines) {
-    // the first batch in front of the loads that fetch x, the second behind them (a CU's loads return in order)
-    mc_prime<4, 4, 1>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q);
-    mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 2>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q); });
+    q_issue(0, 0, wa);
+    mc_fetch_vector_lines(x_in_lines, d, 7, tag, xin, p.err, 14u, [&]() __attribute__((always_inline)) { q_issue(0, 1, wb); q_issue(1, 0, ga); });
     mc_rms_stage(xin, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, []() __attribute__((always_inline)) {});
   } else {
-    mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) { mc_prime<4, 4, 3>(p.wqkv, d, lane, 0, 1, 2, wa, wb, row_q, shift_q); });
+    mc_rms_stage(p.x, p.ln1, d, vthr_qkv, p.rms_eps, p.rms_cast, xs, red, [&]() __attribute__((always_inline)) { q_issue(0, 0, wa); q_issue(0, 1, wb); q_issue(1, 0, ga); });
   }
   MH_T(14)
   uint32_t* line = reinterpret_cast<uint32_t*>(red) + 64;
-  mc_stream<4, 4>(p.wqkv, d, xs, lane, 0, 1, 2, wa, wb, true, row_q, [&](int u, const float (&acc)[4]) __attribute__((always_inline)) {
-    if (lane == 0) {
+  {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto q_compute = [&](int u, int half, const uint4 (&w)[16]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) line[u * 32 + wave * 4 + i] = (tag << 16) | f2bf(rbf(acc[i]));
-    }
-  }, [](int) __attribute__((always_inline)) {}, nullptr, shift_q);
+      for (int un = 0; un < 4; ++un) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + (q_it(u, half * 4 + un) * 64 + lane) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = dot8(w[un * 4 + i], xv, acc[i]);
+      }
+    };
+    auto q_finish = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) line[u * 32 + wave * 4 + i] = (tag << 16) | f2bf(rbf(acc[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = 0.f;
+    };
+    q_compute(0, 0, wa);
+    q_issue(1, 1, wa);
+    q_compute(0, 1, wb);
+    q_finish(0);
+    q_compute(1, 0, ga);
+    q_compute(1, 1, wa);
+    q_finish(1);
+  }
   // the workgroup's 64 qkv rows = two 128-byte lines of the tagged vector, stored by one instruction -- in FRONT of the weight requests below
   // and behind a barrier that does not drain them (__syncthreads() waits for vmcnt(0): with the Wo rows requested first the rows were
   // published 7 us later, in-kernel stamps)
