@@ -173,6 +173,9 @@ __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem
   mh_rms_stage(xin, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red);
   if (primed == 0) mc_prime<4, 4, 3>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
   else if (primed == 1) mc_prime<4, 4, 2>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
+  // (Three register buffers here -- the qkv / Wo registers are idle in the MLP -- put 48 KB per wave in flight instead of 32: wave 0 was
+  // through its pairs 10 us earlier and the act hand-over took 20 us: 100 MB in the chip's queues is 19 us of latency for every poll behind
+  // them.  2.40 -> 2.54 ms per token; reverted.)
   MH_T(5)
   mc_stream<4, 4>(a.wgu, d, xs, lane, 0, 1, nloc, wa, wb, true, row_gl, [&](int u, const float (&acc)[4]) __attribute__((always_inline)) {
     if (u == 0) { MH_T(4) }
