@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=512)
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/ ratio instead of two rocprofv3 --pmc passes run now")
     ap.add_argument("--retrieval-proteins", type=int, default=250, help="proteins per rank in the retrieval leg (10 engine batches: the first batch's host packing is the only one the GPU waits for)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] block (batch-32 generation, pair scoring)")
     return ap.parse_args()
@@ -109,6 +110,33 @@ def cpu_baseline(tokens, residues, prompt):
             "sample": f"oracle (torch-CPU bf16): 2/33 ESM2-650M layers S={residues + 2}, 2/32 Llama-3-8B layers (1- and 2-layer runs differenced) prefill T={prompt} "
                       f"+ {nd} decode steps + lm_head, scaled to 32 layers; esm {t_esm:.2f}s prefill {t_prefill:.2f}s "
                       f"decode {t_step * 1e3:.0f} ms/token"}
+
+
+def live_pmc_traffic(kernel_sub, geometry):
+    """HBM bytes per launch of the decode-step kernel from two rocprofv3 --pmc passes (separate passes, --kernel-trace only: MI355X_MICROARCH.md,
+    HBM section) over tools/pmc_decode.py, run NOW on this box.  None when rocprofv3 is missing, this process is itself being profiled, or a pass
+    fails / times out -- the committed ratio of profiles/ is used then."""
+    import shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_hbm_summary import summarise
+        d = tempfile.mkdtemp(prefix="pcy_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        if geometry == "split":
+            env["GEO"] = "split"
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            subprocess.run(["rocprofv3", "--pmc", c, "--kernel-trace", "-d", os.path.join(d, c), "-o", "p", "--output-format", "csv", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "pmc_decode.py")], cwd="/tmp", env=env, timeout=300, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        alg = 13227261952 if geometry == "split" else 14029094912   # 32 layers x (weights + cached K/V at t = 512..536), tools/r6_profiles.sh
+        r = summarise(os.path.join(d, "FETCH_SIZE"), os.path.join(d, "WRITE_SIZE"), kernel_sub, alg, "live")
+        shutil.rmtree(d, ignore_errors=True)
+        v = next(iter(r["kernels"].values()))
+        return v if v["launches"][0] >= 8 and 0.5 < v["ratio"] < 3.0 else None
+    except Exception:
+        return None
 
 
 def main():
@@ -248,7 +276,19 @@ def main():
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     traffic_ratio = None
+    live = None
+    if all_layers and rank == 0 and world == 1 and not a.no_live_pmc and a.geometry in ("full", "split"):
+        live = live_pmc_traffic("decode_step_mha_kernel" if mha else "decode_step_kernel", a.geometry)
+    if live is not None:
+        traffic_ratio = live["hbm_bytes_per_launch"] / live["algorithmic_bytes"]
+        traffic = int(round(traffic_ratio * k_bytes))
+        traffic_source = (f"LIVE: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --kernel-trace only) over tools/pmc_decode.py run by this bench.py "
+                          f"invocation on this box, 24 launches of the same kernel at t = 512..536: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = "
+                          f"{live['hbm_bytes_per_launch']} B against {live['algorithmic_bytes']} algorithmic (FETCH_SIZE doubled per MI355X_MICROARCH.md); "
+                          f"that ratio x this launch's algorithmic bytes")
     try:
+        if live is not None:
+            raise StopIteration
         pname = next(n for n in ((("r06_pmc_decode_step_mha.json",) if mha else ("r06_pmc_decode_step.json", "r05_pmc_decode_step.json")) if all_layers
                                  else ("archive/r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))

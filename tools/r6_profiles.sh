@@ -44,3 +44,15 @@ CHECK=0 BATCHES=10 PCY_MC_TRACE=1 python tools/bench_decode_mb.py > $O/decode_mb
 ./tools/probes/stream_rows > $O/probe_stream_rows.log 2>&1
 ./tools/probes/stream_cus > $O/probe_stream_cus.log 2>&1
 ls -la $O
+# 9. round 6: ProCyon-Split (Llama-2-7B geometry) -- the bench line, its kernel table, HBM traffic of decode_step_mha_kernel, bit-identity + in-kernel stamps
+python bench.py --geometry split --steps 5 --warmup 2 > $O/bench_split.json 2> $O/bench_split.err
+rocprofv3 --kernel-trace --stats -d $O/prof_split -o b -- python bench.py --geometry split --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/prof_summary.py $O/prof_split > $O/split_kernel_stats.csv 2>/dev/null; rm -rf $O/prof_split
+for c in FETCH_SIZE WRITE_SIZE; do
+  GEO=split rocprofv3 --pmc $c --kernel-trace -d $O/pmc_mha_$c -o p --output-format csv -- python tools/pmc_decode.py > /dev/null 2>&1
+done
+python tools/pmc_hbm_summary.py $O/pmc_mha_FETCH_SIZE $O/pmc_mha_WRITE_SIZE decode_step_mha_kernel 13227261952 "all 32 decoder layers of a ProCyon-Split (Llama-2-7B) decode step at t = 512..536: 32 x (404.8 MB of weights + 8.6 MB of cached K/V)" > $O/pmc_decode_step_mha.json 2>$O/pmc_decode_step_mha.err; rm -rf $O/pmc_mha_FETCH_SIZE $O/pmc_mha_WRITE_SIZE
+python tools/bench_decode_mha.py > $O/decode_mha.log 2>&1
+CHECK=0 MODES=step GRAPH=0 PCY_MC_TRACE=1 python tools/bench_decode_mha.py > $O/decode_mha_trace.log 2>&1
+python tools/bench_gemm_ref.py > $O/gemm_ref.txt 2>&1
+ls -la $O
