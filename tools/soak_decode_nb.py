@@ -1,6 +1,6 @@
 """Soak of the fused decode steps (1 row and 2..8 rows): batch sizes in random order on ONE context, eager and replayed, every run compared
 bit for bit with the first run of its (batch, prompt) -- a stale tag, a slot shared between batch sizes or a lost hand-over shows as a
-difference or as a watchdog error.  MINUTES=<wall clock> (default 3), LAYERS=<n> (default 8)."""
+difference or as a watchdog error.  MINUTES=<wall clock> (default 3), LAYERS=<n> (default 8), GEO=split (the Llama-2-7B geometry: one-launch step at 1 row), ROWS=<max batch> (default 8)."""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,11 +8,13 @@ os.environ.setdefault("PCY_NB_MAX", "8")   # the fused step at 8 rows is opt-in 
 from procyon_amd import synth
 from procyon_amd.engine import Context, GenState, LlamaConfig, LlamaEngine
 kw = dict(vocab=4096, d=4096, n_layers=int(os.environ.get("LAYERS", 8)), n_heads=32, n_kv_heads=8, ffn=14336)
+if os.environ.get("GEO") == "split":   # ProCyon-Split (Llama-2-7B): the one-launch step at 1 row (pcy_decode_mha.hip), launches above
+    kw.update(n_kv_heads=32, ffn=11008)
 eng = LlamaEngine(synth.llama_state_dict(**kw, device="cuda"), LlamaConfig(**kw, max_pos=4096), free_source=True)
 ctx = Context.get()
 random.seed(0)
 N = 12
-cases = [(B, T) for B in range(1, 9) for T in (40, 333, 900, 1700)]
+cases = [(B, T) for B in range(1, int(os.environ.get("ROWS", 8)) + 1) for T in (40, 333, 900, 1700)]
 embs = {}
 for B, T in cases:
     torch.manual_seed(B * 10007 + T)
