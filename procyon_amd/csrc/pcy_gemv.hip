@@ -524,6 +524,70 @@ __global__ __launch_bounds__(256) void gemv_splitk_finish_norm_kernel(PcyGemvArg
   __shared__ float red[4];
   constexpr int MAXI = 4;                       // N <= 8192
   const int b = blockIdx.x;
+  if (a.N == 4096 && ksplit <= 4 && !a.bias) {
+    // The decode step's case (d = 4096, K split <= 4): EVERY load of the launch -- 16 partial-sum quads, the residual, the norm weights --
+    // is requested before the first is used.  The general loop below asks per 2048-column block and fetches the norm weights behind the
+    // block reduction: three dependent memory round trips in a launch of ~6.5 us, twice per decoder layer (round 6).  Same element
+    // assignment, same order of every sum: same bits.
+    f32x4 part[2][2][4];
+    uint2 res[2][2];
+    uint4 g[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int k = threadIdx.x * 8 + it * 2048;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = k + h * 4;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+          part[it][h][s_] = s_ < ksplit ? *reinterpret_cast<const f32x4*>(a.splitk_ws + ((size_t)s_ * a.B + b) * a.N + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        res[it][h] = *reinterpret_cast<const uint2*>(a.resid + (size_t)b * a.ldy + n);
+      }
+      g[it] = *reinterpret_cast<const uint4*>(a.next_rms_w + k);
+    }
+    float xq[2][8];
+    float ssq = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int k = threadIdx.x * 8 + it * 2048;
+      uint32_t packed[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 v = part[it][h][0];
+#pragma unroll
+        for (int s_ = 1; s_ < 4; ++s_)
+          if (s_ < ksplit) { v[0] += part[it][h][s_][0]; v[1] += part[it][h][s_][1]; v[2] += part[it][h][s_][2]; v[3] += part[it][h][s_][3]; }
+        const uint32_t rw[2] = {res[it][h].x, res[it][h].y};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float o = rbf(v[r] + 0.f);
+          o = rbf(o + ((r & 1) ? hi_bf(rw[r >> 1]) : lo_bf(rw[r >> 1])));
+          xq[it][h * 4 + r] = o;
+        }
+        packed[h * 2] = pack_bf(xq[it][h * 4], xq[it][h * 4 + 1]);
+        packed[h * 2 + 1] = pack_bf(xq[it][h * 4 + 2], xq[it][h * 4 + 3]);
+      }
+      *reinterpret_cast<uint4*>(a.y + (size_t)b * a.ldy + k) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float p = xq[it][2 * j], q = xq[it][2 * j + 1]; ssq += p * p + q * q; }
+    }
+    ssq = block_sum<256>(ssq, red);
+    const float rstd = rsqrtf(ssq / (float)a.N + a.rms_eps);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int k = threadIdx.x * 8 + it * 2048;
+      const uint32_t gg[4] = {g[it].x, g[it].y, g[it].z, g[it].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float p = xq[it][2 * j] * rstd, q = xq[it][2 * j + 1] * rstd;
+        if (a.rms_cast == 0) { p = rbf(p); q = rbf(q); }
+        o[j] = pack_bf(lo_bf(gg[j]) * p, hi_bf(gg[j]) * q);
+      }
+      *reinterpret_cast<uint4*>(a.next_xn + (size_t)b * a.N + k) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
   float xv[MAXI][8];
   float ss = 0.f;
 #pragma unroll
