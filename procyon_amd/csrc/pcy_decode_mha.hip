@@ -24,6 +24,10 @@
 #include "pcy_mlp_chain.h"
 #include "pcy_attn_dec.h"
 
+#ifndef MH_KROT_MASK
+#define MH_KROT_MASK 7   // projections that walk k rotated (PcyGemvArgs::krot): 1 qkv, 2 o, 4 gate/up -- the twin's launches ask pcy_decode_mha_krot()
+#endif
+
 namespace {
 
 constexpr int MH_DH = 128, MH_DS = 64, MH_HKV = 32, MH_NATTN = (MH_DH / MH_DS) * MH_HKV;   // 64 attention workgroups
@@ -94,7 +98,7 @@ __device__ __forceinline__ void mh_fetch_vector(const uint32_t* src, int n, int 
 template <int WHICH>
 __device__ __forceinline__ void mh_prime_gate_up(const PcyMlpChainArgs& a, int lane, int gw, uint4 (&wa)[16], uint4 (&wb)[16]) {
   const int nit_g = a.d >> 9;
-  mc_prime<4, 4, WHICH>(a.wgu, a.d, lane, gw, 1, a.F / 2, wa, wb, MhRowPair{a.F, a.d}, [&](int h) __attribute__((always_inline)) { return (h >> 1) % nit_g; });
+  mc_prime<4, 4, WHICH>(a.wgu, a.d, lane, gw, 1, a.F / 2, wa, wb, MhRowPair{a.F, a.d}, [&](int h) __attribute__((always_inline)) { return (MH_KROT_MASK & 4) ? (h >> 1) % nit_g : 0; });
 }
 
 // mc_rms_stage (pcy_handover.h) for x in LDS, with barriers that leave the weight requests in flight alone: xs[0..K) = bf16(RMSNorm(x) * w),
@@ -169,7 +173,7 @@ __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem
   auto pair_of = [&](int u) __attribute__((always_inline)) { return u == 0 ? gw : (u == 1 ? MH_NW + gw : h3); };
   auto row_gl = [&](int u, int i) __attribute__((always_inline)) -> size_t { return row_p(pair_of(u), i); };
   const int nit_g = d >> 9;
-  auto shift_g = [&](int u) __attribute__((always_inline)) { return (pair_of(u) >> 1) % nit_g; };   // rotated k order (PcyGemvArgs::krot)
+  auto shift_g = [&](int u) __attribute__((always_inline)) { return (MH_KROT_MASK & 4) ? (pair_of(u) >> 1) % nit_g : 0; };   // rotated k order (PcyGemvArgs::krot)
   mh_rms_stage(xin, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red);
   if (primed == 0) mc_prime<4, 4, 3>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
   else if (primed == 1) mc_prime<4, 4, 2>(a.wgu, d, lane, 0, 1, nloc, wa, wb, row_gl, shift_g);
@@ -297,7 +301,7 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   const int rq0 = pw * 64 + wave * 4;
   auto row_q = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(rq0 + u * 32 + i) * d; };
   const int nit_q = d >> 9;
-  auto shift_q = [&](int u) __attribute__((always_inline)) { return ((rq0 + u * 32) >> 2) % nit_q; };   // rotated k order (PcyGemvArgs::krot)
+  auto shift_q = [&](int u) __attribute__((always_inline)) { return (MH_KROT_MASK & 1) ? ((rq0 + u * 32) >> 2) % nit_q : 0; };   // rotated k order (PcyGemvArgs::krot)
   // The wave's 8 rows = four batches of 4 rows x 4 k-iterations; THREE of them are requested before x is there (wa, wb, and ga, which is idle
   // until the attention): 72 MB of the 100 MB of Wqkv in flight from the first cycle of the layer (two batches: 48 MB had landed 2.5 us before x
   // arrived and the fourth was one more round trip).  The first in front of the loads that fetch x, the others behind them (a CU's loads return
@@ -361,7 +365,7 @@ __device__ __forceinline__ void mh_layer_body(PcyDecAttnArgs a, const PcyAttnBlo
   const bool active = r0 < d;                 // (workgroup-uniform: d % 32 == 0)
   auto row_o = [&](int u, int i) __attribute__((always_inline)) -> size_t { return (size_t)(r0 + i) * K; };
   const int nit_o = K >> 9;
-  auto shift_o = [&](int) __attribute__((always_inline)) { return (r0 >> 2) % nit_o; };
+  auto shift_o = [&](int) __attribute__((always_inline)) { return (MH_KROT_MASK & 2) ? (r0 >> 2) % nit_o : 0; };
   float res[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
     mc_prime<4, 4, 3>(p.wo, K, lane, 0, 1, 1, wa, wb, row_o, shift_o);
@@ -456,6 +460,7 @@ bool pcy_decode_mha_covers(int d, int H, int Hkv, int dh, int F, int n_cu) {
   return dh == MH_DH && H == MH_HKV && Hkv == MH_HKV && d == MH_D && F / 2 > 2 * 2048 && F / 2 <= 3 * 2048 && F % 256 == 0 && n_cu >= 256;
 }
 int pcy_decode_mha_ds() { return MH_DS; }
+int pcy_decode_mha_krot() { return MH_KROT_MASK; }
 
 // One layer (st == nullptr) or all layers of a batch-1 decode step; false = not covered, nothing launched.  Arguments as
 // pcy_launch_decode_layer / pcy_launch_decode_step (pcy_attn.hip).
