@@ -646,9 +646,13 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int r = r0 + i < o.N ? r0 + i : o.N - 1;
+      // (rotated k order of row r, PcyGemvArgs::krot: register c holds k-iteration (c + r / 4) % 8)
       const bf16_t* p = o.W + (size_t)r * K + lane * 8;
-      ld4_asm_nt(p, wv[i][0], wv[i][1], wv[i][2], wv[i][3]);
-      ld4_asm_nt(p + 2048, wv[i][4], wv[i][5], wv[i][6], wv[i][7]);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const uint4 t = ldg_nt(p + ((c + (r >> 2)) & 7) * 512);
+        wv[i][c] = (u32x4_t){t.x, t.y, t.z, t.w};
+      }
       res[i] = o.resid ? bf2f(o.resid[r]) : 0.f;
       bia[i] = o.bias ? bf2f(o.bias[r]) : 0.f;
     }
@@ -666,7 +670,6 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
     }
   }
   __syncthreads();
-  if (!active) return;
   u32x4_t xv[KC];
   ld4_asm_sc1(o.x + lane * 8, xv[0], xv[1], xv[2], xv[3]);
   ld4_asm_sc1(o.x + 2048 + lane * 8, xv[4], xv[5], xv[6], xv[7]);
@@ -677,14 +680,26 @@ __global__ __launch_bounds__(512) void attn_o_kernel(PcyDecAttnArgs a, PcyGemvAr
 #pragma unroll
     for (int i = 0; i < RW; ++i) asm volatile("" : "+v"(wv[i][c]));
   }
+  // x through LDS (the attention's buffers are not used by these workgroups): row i wants chunk (c + r_i / 4) % 8 beside weight register c,
+  // an index that is not known at compile time
+  uint4* xl = reinterpret_cast<uint4*>(smem);   // [KC][64] = 8 KB, one copy for the workgroup (every wave holds the same x)
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) xl[c * 64 + lane] = make_uint4(xv[c][0], xv[c][1], xv[c][2], xv[c][3]);
+  }
+  __syncthreads();
+  if (!active) return;
   float acc[RW];
 #pragma unroll
   for (int i = 0; i < RW; ++i) acc[i] = 0.f;
 #pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    const uint4 x4 = make_uint4(xv[c][0], xv[c][1], xv[c][2], xv[c][3]);
+  for (int i = 0; i < RW; ++i) {
+    const int r = r0 + i < o.N ? r0 + i : o.N - 1;
 #pragma unroll
-    for (int i = 0; i < RW; ++i) acc[i] = dot8(make_uint4(wv[i][c][0], wv[i][c][1], wv[i][c][2], wv[i][c][3]), x4, acc[i]);
+    for (int c = 0; c < KC; ++c) {
+      const uint4 x4 = xl[((c + (r >> 2)) & 7) * 64 + lane];
+      acc[i] = dot8(make_uint4(wv[i][c][0], wv[i][c][1], wv[i][c][2], wv[i][c][3]), x4, acc[i]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < RW; ++i) acc[i] = wave_sum(acc[i]);
@@ -722,7 +737,8 @@ bool launch_attn_o_rw(hipStream_t s, PcyDecAttnArgs a, const PcyGemvArgs& o, int
   // workgroups therefore start ~5 us late: decode step 3.335 (no delay) -> 3.285 (4 us) -> 3.277 ms (8 us) at t = 512..768;
   // 5 us still leaves the stream (~6 us) inside the shortest attention.
   constexpr int dbg = 0, delay = 500;   // delay in 10 ns ticks
-  const size_t smem = attn_dec_smem_bytes(G, 16, DH, a.Tmax);
+  size_t smem = attn_dec_smem_bytes(G, 16, DH, a.Tmax);
+  if (smem < 8192) smem = 8192;   // (the o workgroups keep x in 8 KB of it)
   const dim3 grid(n_attn + (o.N + rw * 8 - 1) / (rw * 8)), block(512);
 #define PCY_AO_LAUNCH(RWV)                                                                                          \
   do {                                                                                                              \
@@ -833,7 +849,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + (it * 64 + lane) * 8);
+      for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + ((((it + (rq0 >> 2)) & 7) * 64 + lane) * 8));
   };
   const bf16_t* xsrc = p.x;
   if (x_in_lines) {
@@ -843,7 +859,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
 #pragma unroll
       for (int i = i0; i < i0 + 2; ++i)
 #pragma unroll
-        for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + (it * 64 + lane) * 8);
+        for (int it = 0; it < 8; ++it) w[i * 8 + it] = ldg_nt(p.wqkv + (size_t)(rq0 + i) * d + ((((it + (rq0 >> 2)) & 7) * 64 + lane) * 8));
     };
     if (PCY_STEP_SPLIT_WQKV) {
       load_rows(0);
@@ -861,7 +877,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(xs + (it * 64 + lane) * 8);
+      const uint4 xv = *reinterpret_cast<const uint4*>(xs + (((it + (rq0 >> 2)) & 7) * 64 + lane) * 8);   // (rotated k order, PcyGemvArgs::krot)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = dot8(w[i * 8 + it], xv, acc[i]);
     }
@@ -891,7 +907,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
     for (int i = 0; i < 4; ++i) {
       const int r = r0 + i;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (c * 64 + lane) * 8);
+      for (int c = 0; c < 8; ++c) w[i * 8 + c] = ldg_nt(p.wo + (size_t)r * K + (((c + (r0 >> 2)) & 7) * 64 + lane) * 8);
       res[i] = bf2f(xsrc[r]);
     }
   } else if (wave < 7) {   // no o rows here: the SECOND 16 KB of the wave's gate/up rows wait in the Wo registers instead
@@ -900,7 +916,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
 #pragma unroll
     for (int un = 0; un < 2; ++un)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) w[un * 8 + i] = ldg_nt(mc.wgu + row_g(gidx, i) + ((2 + un) * 64 + lane) * 8);
+      for (int i = 0; i < 8; ++i) w[un * 8 + i] = ldg_nt(mc.wgu + row_g(gidx, i) + (mc_rot(2 + un, gidx & 7, 8) * 64 + lane) * 8);
   }
   // gate/up rows of the MLP while the attention runs: 16 KB per wave beside the Wo rows (both batches: 256 VGPRs and spills)
   if (wave < 7) mc_prime_gate_up(mc, lane, (int)blockIdx.x * 7 + wave, wa, wb, false);
@@ -934,7 +950,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const uint4 xv = *reinterpret_cast<const uint4*>(xa + (c * 64 + lane) * 8);
+      const uint4 xv = *reinterpret_cast<const uint4*>(xa + (((c + (r0 >> 2)) & 7) * 64 + lane) * 8);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = dot8(w[i * 8 + c], xv, acc[i]);
     }
@@ -959,7 +975,7 @@ __device__ __forceinline__ void decode_layer_body(PcyDecAttnArgs a, const PcyAtt
   {
     // the Wo registers are free: the second 16 KB of this wave's gate/up rows while the residual stream is on its way
     if (wave < 7) {
-      if (active) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, (int)gridDim.x * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d});
+      if (active) mc_prime<8, 2, 2>(mc.wgu, mc.d, lane, (int)blockIdx.x * 7 + wave, (int)gridDim.x * 7, (mc.F + 3) / 4, wa, wb, McRowG{mc.F, mc.d}, McShiftG{mc.d >> 9});
       else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) wb[i] = w[i];

@@ -25,7 +25,7 @@
 #include "pcy_attn_dec.h"
 
 #ifndef MH_KROT_MASK
-#define MH_KROT_MASK 7   // projections that walk k rotated (PcyGemvArgs::krot): 1 qkv, 2 o, 4 gate/up -- the twin's launches ask pcy_decode_mha_krot()
+#define MH_KROT_MASK 7   // projections that walk k rotated (PcyGemvArgs::krot): 1 qkv, 2 o, 4 gate/up; anything but 7 is a measurement build (no twin)
 #endif
 
 namespace {
@@ -460,7 +460,6 @@ bool pcy_decode_mha_covers(int d, int H, int Hkv, int dh, int F, int n_cu) {
   return dh == MH_DH && H == MH_HKV && Hkv == MH_HKV && d == MH_D && F / 2 > 2 * 2048 && F / 2 <= 3 * 2048 && F % 256 == 0 && n_cu >= 256;
 }
 int pcy_decode_mha_ds() { return MH_DS; }
-int pcy_decode_mha_krot() { return MH_KROT_MASK; }
 
 // One layer (st == nullptr) or all layers of a batch-1 decode step; false = not covered, nothing launched.  Arguments as
 // pcy_launch_decode_layer / pcy_launch_decode_step (pcy_attn.hip).

@@ -469,11 +469,14 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     t.force_ds = nb_on ? pcy_decode_nb_ds(B) : 0;
     // (multi-head geometry, one row: the column split of the fused step's attention workgroups, whatever the launch mix -- one set of bits)
     const bool mha1 = B == 1 && pcy_decode_mha_covers(d, H, Hkv, dh, F, c->n_cu);
-    const int mha_krot = mha1 ? pcy_decode_mha_krot() : 0;
-    if (mha1) { t.force_ds = pcy_decode_mha_ds(); g.krot = mha_krot & 1; }   // (+ the rotated k order of its projections, PcyGemvArgs::krot)
+    if (mha1) t.force_ds = pcy_decode_mha_ds();
+    // one row: the projections over d walk their k-iterations rotated (PcyGemvArgs::krot) -- in the streaming launches, in the launches that
+    // fuse them (attn_o, mlp_chain) and in the one-launch steps alike: one set of bits
+    const int krot1 = B == 1 ? 1 : 0;
+    g.krot = krot1;   // (+ the rotated k order of its projections, PcyGemvArgs::krot)
     PcyGemvArgs o{};
     o.W = (const bf16_t*)L.wo; o.x = ao; o.y = x; o.resid = x; o.N = d; o.K = H * dh; o.B = B; o.ldx = H * dh; o.ldy = d; o.epi = EPI_RESID;
-    o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes; o.force_stream = nb_on; o.krot = (mha_krot >> 1) & 1;
+    o.splitk_ws = sk_ws; o.splitk_ws_bytes = sk_bytes; o.force_stream = nb_on; o.krot = krot1;
     // attention and o projection in one launch (Wo rows wait in registers while the attention runs) where covered
     if (batched && B <= 32) { o.next_rms_w = (const bf16_t*)L.ln2; o.next_xn = xn; o.fused_next = &xn_ready; o.rms_eps = m->rms_eps; o.rms_cast = m->rms_cast; }
     if (try_layer) {   // the whole layer as one launch
@@ -505,7 +508,7 @@ void enqueue_decode(pcy_ctx* c, const pcy_llama_desc* m, const pcy_kv_cache* kv,
     }
     PcyGemvArgs u{};
     u.W = (const bf16_t*)L.wgu; u.x = x; u.y = act; u.rms_w = (const bf16_t*)L.ln2; u.rms_eps = m->rms_eps; u.rms_cast = m->rms_cast;
-    u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU; u.force_stream = nb_on; u.krot = (mha_krot >> 2) & 1;
+    u.N = F; u.K = d; u.B = B; u.ldx = d; u.ldy = F; u.epi = EPI_SWIGLU; u.force_stream = nb_on; u.krot = krot1;
     if (batched) {
       if (!xn_ready) pcy_launch_rmsnorm(s, x, (const bf16_t*)L.ln2, xn, B, d, m->rms_eps, m->rms_cast);
       xn_ready = 0;
@@ -793,7 +796,7 @@ int pcy_decode_mlp(pcy_ctx* c, void* x, const void* ln2, const void* wgu, const 
   if (int r = c->reserve((size_t)ffn * 2 + 256)) return r;
   PcyGemvArgs u{};
   u.W = (const bf16_t*)wgu; u.x = (const bf16_t*)x; u.y = (bf16_t*)c->ws; u.rms_w = (const bf16_t*)ln2; u.rms_eps = rms_eps; u.rms_cast = rms_cast;
-  u.N = ffn; u.K = d; u.B = 1; u.ldx = d; u.ldy = ffn; u.epi = EPI_SWIGLU;
+  u.N = ffn; u.K = d; u.B = 1; u.ldx = d; u.ldy = ffn; u.epi = EPI_SWIGLU; u.krot = 1;   // (as mlp_chain_kernel walks it)
   pcy_launch_gemv(c->stream, u);
   PcyGemvArgs w{};
   w.W = (const bf16_t*)wdown; w.x = (const bf16_t*)c->ws; w.y = (bf16_t*)x; w.resid = (const bf16_t*)x; w.N = d; w.K = ffn; w.B = 1; w.ldx = ffn; w.ldy = d;

@@ -251,7 +251,6 @@ bool pcy_launch_decode_layer(hipStream_t s, const PcyDecAttnArgs& a, const PcyAt
 // cut its output into pcy_decode_mha_ds() columns per workgroup (the summation order of P.V).
 bool pcy_decode_mha_covers(int d, int H, int Hkv, int dh, int F, int n_cu);
 int pcy_decode_mha_ds();
-int pcy_decode_mha_krot();   // which of its projections walk k rotated (1 qkv, 2 o, 4 gate/up): PcyGemvArgs::krot of the twin's launches
 bool pcy_launch_decode_mha(hipStream_t s, PcyDecAttnArgs a, const PcyAttnBlockArgs& p, const PcyMlpChainArgs& mc, const PcyDecodeStepArgs* st, int n_cu,
                            const unsigned* step_epoch, unsigned* xflags);
 // Small-batch decode step (pcy_decode_nb.hip): every decoder layer for 2..8 rows in ONE launch, the weights streamed once.  Hand-over slots

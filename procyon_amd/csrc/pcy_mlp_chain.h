@@ -139,6 +139,12 @@ struct McRowG {
     return (size_t)((fc >> 4) * 32 + (fc & 15) + (i >= 4 ? 16 : 0)) * d;
   }
 };
+// rotated k order of the gate/up unit u (4 features = output rows 4u ..: (r / 4) % nit, PcyGemvArgs::krot)
+struct McShiftG {
+  int nit;
+  __device__ __forceinline__ int operator()(int u) const { return u % nit; }
+};
+__device__ __forceinline__ int mc_rot(int it, int sh, int nit) { const int r = it + sh; return r >= nit ? r - nit : r; }
 // LDS-DMA of the batch (k-iterations it0, it0 + 1) of this wave's first gate/up unit into the wave's own 16 KB at dst (register j of lane l
 // at j * 1024 + l * 16): what mc_stream<.., LDS_IT0 = it0>(lds_batch = dst) expects.  Issued by the projection workgroups of the decode layer
 // while the attention runs: their registers are full (Wo rows + the first batch), their LDS is idle.
@@ -150,7 +156,8 @@ __device__ __forceinline__ void mc_lds_prefetch(const PcyMlpChainArgs& a, int la
   for (int un = 0; un < 2; ++un)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((mc_gptr_t)(a.wgu + row_g(gidx, i) + ((it0 + un) * 64 + lane) * 8), (mc_lds_ptr_t)(dst + (un * 8 + i) * 1024), 16, 0, 2);
+      __builtin_amdgcn_global_load_lds((mc_gptr_t)(a.wgu + row_g(gidx, i) + (mc_rot(it0 + un, gidx % (a.d >> 9), a.d >> 9) * 64 + lane) * 8),
+                                       (mc_lds_ptr_t)(dst + (un * 8 + i) * 1024), 16, 0, 2);
 }
 // first batch (k-iterations 0, 1) of this wave's first gate/up unit -> wa, and with `both` the second (2, 3) -> wb: what
 // mc_mlp_body(primed = 1 / 3) expects to find
@@ -161,12 +168,12 @@ __device__ __forceinline__ void mc_prime_gate_up(const PcyMlpChainArgs& a, int l
 #pragma unroll
     for (int un = 0; un < 2; ++un)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) wa[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + (un * 64 + lane) * 8);
+      for (int i = 0; i < 8; ++i) wa[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + (mc_rot(un, gidx % (a.d >> 9), a.d >> 9) * 64 + lane) * 8);
     if (both) {
 #pragma unroll
       for (int un = 0; un < 2; ++un)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wb[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + ((2 + un) * 64 + lane) * 8);
+        for (int i = 0; i < 8; ++i) wb[un * 8 + i] = ldg_nt(a.wgu + row_g(gidx, i) + (mc_rot(2 + un, gidx % (a.d >> 9), a.d >> 9) * 64 + lane) * 8);
     }
   }
 }
@@ -203,8 +210,8 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
   const McRowG row_g{F, d};
   mc_rms_stage(xin, a.ln2, d, vthr_gu, a.rms_eps, a.rms_cast, xs, red, [&]() __attribute__((always_inline)) {
     if (wave < 7) {
-      if (primed == 0) mc_prime<8, 2, 3>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g);
-      else if (primed == 1) mc_prime<8, 2, 2>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g);
+      if (primed == 0) mc_prime<8, 2, 3>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g, McShiftG{d >> 9});
+      else if (primed == 1) mc_prime<8, 2, 2>(a.wgu, d, lane, gidx, NWG7, units_g, wa, wb, row_g, McShiftG{d >> 9});
     }
   });
   if (wave < 7) {
@@ -220,7 +227,7 @@ __device__ __forceinline__ void mc_mlp_body(const PcyMlpChainArgs& a, char* smem
         st8_agent(a.act_tag + u * 4, o[0], o[1]);
         st8_agent(a.act_tag + u * 4 + 2, o[2], o[3]);
       }
-    }, [](int) __attribute__((always_inline)) {}, lds_batch);
+    }, [](int) __attribute__((always_inline)) {}, lds_batch, McShiftG{d >> 9});
     MC_T(1)
     // ---- stage 2 begins for this wave: first half of act, then (once it is there) the first two batches of its down rows ----
     mc_fetch_issue<4>(a.act_tag, wave * 1024, lane, tq);
