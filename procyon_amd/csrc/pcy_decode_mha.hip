@@ -202,7 +202,7 @@ __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem
   int nj2 = (F - MH_HALF - wave * 1024) / 256;
   nj2 = wave < 7 ? (nj2 < 0 ? 0 : (nj2 > 4 ? 4 : nj2)) : 0;
   mh_fetch_issue<4>(a.act_tag, MH_HALF + wave * 1024, lane, tq, nj2);
-  __syncthreads();
+  lds_barrier();   // (every wave's part of act is in LDS; the down rows just requested stay in flight)
   MH_T(2)
   float acc[2] = {0.f, 0.f};
   constexpr int it_half = MH_HALF / 512;   // 14 = two batches of MC_UNB_D
@@ -212,7 +212,7 @@ __device__ __forceinline__ void mh_mlp_body(const PcyMlpChainArgs& a, char* smem
                                    [&](int it0) __attribute__((always_inline)) {
                                      if (it0 == it_half) {   // (workgroup-uniform: every wave walks the same batches of its one unit)
                                        mh_fetch_finish<4>(a.act_tag, MH_HALF + wave * 1024, lane, tag, xa, tq, nj2, a.err, 7u);
-                                       __syncthreads();
+                                       lds_barrier();
                                        MH_T(3)
                                      }
                                    });
