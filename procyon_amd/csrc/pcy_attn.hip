@@ -1072,7 +1072,7 @@ void launch_dec(hipStream_t s, const PcyDecAttnArgs& a) {
   if constexpr (DH == 128) {
     const int units = a.Hkv * a.B;
     if (units >= 128) ds = 128;
-    else if (units >= 64) ds = 64;
+    else if (units >= 32) ds = 64;   // (from 4 rows of 8 kv heads on: 16-column workgroups score every key 8 times -- 5-7 rows 4.17-4.23 -> 3.68-3.69 ms per step)
     if (force == 16 || force == 64 || force == 128) ds = force;
     if (a.force_ds == 16 || a.force_ds == 32 || a.force_ds == 64 || a.force_ds == 128) ds = a.force_ds;   // (the twin of the small-batch step)
     if (ds == 128) return launch_dec_ds<DH, G, 128>(s, a);

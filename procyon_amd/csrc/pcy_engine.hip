@@ -227,16 +227,17 @@ int decode_mb_max_rows() {
 int decode_nb_max_rows();
 int decode_mode() {
   return (pcy_off("kv_permute") ? 2048 : 0) | (attn_o_enabled() ? 2 : 0) | (decode_layer_enabled() ? 32 : 0) | (decode_step_enabled() ? 64 : 0) | (qkv_finish_launch() ? 128 : 0) |
-         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16) | (decode_nb_max_rows() == 8 ? (1 << 28) : 0) |
+         (pcy_off("lds_prefetch") ? 256 : 0) | (decode_nb_enabled() ? 512 : 0) | (decode_nb_step_enabled() ? 1024 : 0) | (decode_mb_step_enabled() ? 4096 : 0) | (decode_mb_max_rows() << 16) | ((decode_nb_max_rows() & 3) << 28) |
          (int)((((unsigned)decode_xmin() * 2654435761u) ^ ((unsigned)decode_xmin_nb(2) * 40503u) ^ ((unsigned)decode_xmin_nb(4) * 69069u)) & 0x3fu) << 22;
 }
 constexpr int AO_MAX_LAYERS = 128, AO_FLAGS = 64;
 // geometry of the small-batch step: Llama-3-8B, 256 CUs
-// (8 rows: since the batched launches walk their K ranges in rotated order they take 3.84 ms per step against the fused step's 3.99 --
-// the fused step stops at 7 rows; PCY_NB_MAX=8 runs it at 8 all the same: tests, tools)
+// (7 and 8 rows: since the batched launches walk their K ranges in rotated order, ask for their finish loads at once and cut the attention
+// into 64-column workgroups from 4 rows on, they take 3.69 / 3.70 ms per step against the fused step's 3.81 / 3.97 -- the fused step stops
+// at 6 rows (3.65 against 3.69); PCY_NB_MAX=7 / 8 runs it there all the same: tests, tools)
 int decode_nb_max_rows() {
   const char* e = getenv("PCY_NB_MAX");
-  const int v = e ? atoi(e) : 7;
+  const int v = e ? atoi(e) : 6;
   return v < 8 ? v : 8;
 }
 bool decode_nb_covers(const pcy_ctx* c, const pcy_llama_desc* m, int B) {

@@ -7,7 +7,7 @@
 //                         decode_mb_step  beam_prefill_once  beam_kv_suffix   (decode_step / decode_layer also select the twins of the
 //                         ProCyon-Split step, pcy_decode_mha.hip)
 //                         (decode_nb: batches of 2..8 rows back on the round-4 launches -- another arithmetic, compared to bf16 noise)
-//   PCY_NB_MAX=<rows>     largest batch on the small-batch decode step (default 7; 8: tests, tools)
+//   PCY_NB_MAX=<rows>     largest batch on the small-batch decode step (default 6; 7, 8: tests, tools)
 //   PCY_MB_MAX=<rows>     largest batch on the opt-in mid-batch decode step, 9..32 (default 0: off);  PCY_MB_ABL=<mask>  its timing ablations (tools)
 //   PCY_ESM_ATTN=exact    the two-pass attention with the reference's bf16 rounding points (default: the single-pass kernel)
 //   PCY_GEMM_PERM=<mask>  256 x 256 epilogues on the permuted W row order (1 STORE, 2 RESID, 4 ESM GELU, 8 SwiGLU, 16 fp8; default 7)

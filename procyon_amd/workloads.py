@@ -123,7 +123,7 @@ def batched_decode_roofline(model, rows=32, prompt=512, new_tokens=512):
     import os
     mb_max = int(os.environ.get("PCY_MB_MAX", "0"))
     off = os.environ.get("PCY_DISABLE", "").split(",")
-    nb_max = min(int(os.environ.get("PCY_NB_MAX", "7")), 8)
+    nb_max = min(int(os.environ.get("PCY_NB_MAX", "6")), 8)
     kernel = ("small-batch decode step (hipGraph: embed, decode_step_nb_kernel = all layers in one launch, lm_head, pick)" if 2 <= rows <= nb_max else
               "mid-batch decode step (hipGraph: embed, norm, decode_step_mb_kernel = all layers in one launch, lm_head, pick)"
               if 9 <= rows <= min(mb_max, 32) and "decode_mb_step" not in off else
