@@ -237,3 +237,35 @@ def test_init_tokenizer_on_a_real_pretrained_tokenizer_fast(tmp_path):
                                                             no_pad=no_pad, left_pad=left_pad)
         assert out_ids.tolist() == g[f"prep_ids_{nm}"] and mask.tolist() == g[f"prep_mask_{nm}"], nm
     assert tk.batch_decode(torch.tensor(g["prep_ids_leftpad"])[:, -12:]) == g["decode"]
+
+
+def test_bench_live_pmc_declines_without_a_profiler(monkeypatch, tmp_path):
+    """bench.py measures roofline.traffic with two rocprofv3 --pmc passes of its own (round 6).  Without rocprofv3 on PATH, or when the bench is
+    itself being profiled (ROCPROF* / ROCP_* in the environment), it must decline -- None -- so that the caller falls back to the committed ratio
+    of profiles/; and the summary the passes are reduced to (tools/pmc_hbm_summary.py) applies the guide's gfx950 correction: bytes =
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, outlier dispatches dropped."""
+    import importlib, shutil, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.live_pmc_traffic("decode_step_kernel", "full") is None
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    monkeypatch.setenv("ROCPROFILER_OUTPUT_PATH", "/tmp/x")
+    assert bench.live_pmc_traffic("decode_step_kernel", "full") is None
+    # the reduction of two counter passes
+    sys.path.insert(0, os.path.join(root, "tools"))
+    summ = importlib.import_module("pmc_hbm_summary")
+    for name, counter, val in (("f", "FETCH_SIZE", 1000.0), ("w", "WRITE_SIZE", 10.0)):
+        d = tmp_path / name / "x"
+        d.mkdir(parents=True)
+        with open(d / "p_counter_collection.csv", "w") as f:
+            f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+            for disp in range(4):
+                f.write(f'{disp},"(anonymous namespace)::decode_step_kernel<128, 4>(X)",{counter},{val / 2}\n')
+                f.write(f'{disp},"(anonymous namespace)::decode_step_kernel<128, 4>(X)",{counter},{val / 2}\n')   # (two XCD rows of one dispatch add up)
+                f.write(f'{disp},"other_kernel(Y)",{counter},7\n')
+    r = summ.summarise(str(tmp_path / "f"), str(tmp_path / "w"), "decode_step_kernel", 2_000_000, "t")
+    v = next(iter(r["kernels"].values()))
+    assert v["hbm_bytes_per_launch"] == int((2 * 1000.0 + 10.0) * 1024) and v["launches"] == [4, 4]
+    assert abs(v["ratio"] - (2 * 1000.0 + 10.0) * 1024 / 2_000_000) < 1e-3
