@@ -276,19 +276,10 @@ def main():
     # HBM bytes per launch cannot be read inside the timed process: they come from separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over tools/bench_decode.py (the same kernel, the same shapes), committed under profiles/
     traffic_ratio = None
-    live = None
-    if all_layers and rank == 0 and world == 1 and not a.no_live_pmc and a.geometry in ("full", "split"):
-        live = live_pmc_traffic("decode_step_mha_kernel" if mha else "decode_step_kernel", a.geometry)
-    if live is not None:
-        traffic_ratio = live["hbm_bytes_per_launch"] / live["algorithmic_bytes"]
-        traffic = int(round(traffic_ratio * k_bytes))
-        traffic_source = (f"LIVE: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --kernel-trace only) over tools/pmc_decode.py run by this bench.py "
-                          f"invocation on this box, 24 launches of the same kernel at t = 512..536: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = "
-                          f"{live['hbm_bytes_per_launch']} B against {live['algorithmic_bytes']} algorithmic (FETCH_SIZE doubled per MI355X_MICROARCH.md); "
-                          f"that ratio x this launch's algorithmic bytes")
+    # (the live counter passes run at the very END of the bench, behind every timed leg -- see live_traffic below: run here, in front of the
+    # retrieval leg, they cost its single timed pass 5-20 % on two of three boxes; the committed ratio is the value until then)
+    want_live = all_layers and rank == 0 and world == 1 and not a.no_live_pmc and a.geometry in ("full", "split")
     try:
-        if live is not None:
-            raise StopIteration
         pname = next(n for n in ((("r06_pmc_decode_step_mha.json",) if mha else ("r06_pmc_decode_step.json", "r05_pmc_decode_step.json")) if all_layers
                                  else ("archive/r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
@@ -426,6 +417,17 @@ def main():
             out["batched_decode_roofline"] = batched_roofline
         if not a.no_cpu_baseline and a.geometry == "full" and world == 1:   # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.tokens, a.residues, a.prompt)
+        if want_live:   # roofline.traffic from two rocprofv3 --pmc passes run NOW (nothing timed is left to disturb)
+            live = live_pmc_traffic("decode_step_mha_kernel" if mha else "decode_step_kernel", a.geometry)
+            if live is not None:
+                ratio = live["hbm_bytes_per_launch"] / live["algorithmic_bytes"]
+                roofline["traffic"] = int(round(ratio * roofline["bytes_per_launch"]))
+                roofline["traffic_over_algorithmic"] = round(ratio, 4)
+                roofline["traffic_source"] = (
+                    f"LIVE: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --kernel-trace only) over tools/pmc_decode.py run by this bench.py "
+                    f"invocation on this box behind its timed legs, 24 launches of the same kernel at t = 512..536: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = "
+                    f"{live['hbm_bytes_per_launch']} B against {live['algorithmic_bytes']} algorithmic (FETCH_SIZE doubled per MI355X_MICROARCH.md); "
+                    f"that ratio x this launch's algorithmic bytes")
         print(json.dumps(out))
     if dist:
         td.destroy_process_group()
