@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--geometry", default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed profiles/ ratio instead of two rocprofv3 --pmc passes run now")
-    ap.add_argument("--retrieval-proteins", type=int, default=250, help="proteins per rank in the retrieval leg (10 engine batches: the first batch's host packing is the only one the GPU waits for)")
+    ap.add_argument("--retrieval-proteins", type=int, default=750, help="proteins per rank in the retrieval leg (30 engine batches, ~1.2 s per pass -- a 0.4 s pass of 10 batches moved by a fifth with one host or clock event: the first batch's host packing is the only one the GPU waits for)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] block (batch-32 generation, pair scoring)")
     return ap.parse_args()
 
