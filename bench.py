@@ -280,7 +280,7 @@ def main():
     # retrieval leg, they cost its single timed pass 5-20 % on two of three boxes; the committed ratio is the value until then)
     want_live = all_layers and rank == 0 and world == 1 and not a.no_live_pmc and a.geometry in ("full", "split")
     try:
-        pname = next(n for n in ((("r06_pmc_decode_step_mha.json",) if mha else ("r06_pmc_decode_step.json", "r05_pmc_decode_step.json")) if all_layers
+        pname = next(n for n in ((("r06_pmc_decode_step_mha.json",) if mha else ("r06_pmc_decode_step.json", "archive/r05_pmc_decode_step.json")) if all_layers
                                  else ("archive/r02_pmc_decode_layer.json",))
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pm = json.load(open(os.path.join(ROOT, "profiles", pname)))["kernels"]

@@ -758,7 +758,7 @@ class EsmEngine:
     # = the engine's own bound (pcy_esm_encode; PCY_DISABLE=esm_graph switches the replay off).  Round 5: raised from 4200 (one long protein) to
     # 40 000 tokens (the retrieval batch: 25 x 1026).  A bulk batch is ~230 launches of 25-300 us; on an idle host they are enqueued in 2.4 ms,
     # far ahead of the GPU, but a GPU box whose host cores were busy (other tenants) took ~50 ms per batch for them and the retrieval leg
-    # dropped from 634 to 434 proteins/s with the encoder's own time unchanged (profiles/r05_bench.json history in DESIGN.md): one graph
+    # dropped from 634 to 434 proteins/s with the encoder's own time unchanged (profiles/archive/r05_bench.json, history in DESIGN.md): one graph
     # launch per batch takes the host out of the loop.
     GRAPH_MAX_TOKENS = 40000
 
