@@ -40,7 +40,8 @@ CHECK=0 BATCHES=10,16,20,32 python tools/bench_decode_mb.py > $O/decode_mb.log 2
 CHECK=0 BATCHES=10,20,32 PCY_MB_MAX=0 rocprofv3 --kernel-trace --stats -d $O/prof_b -o p -- python tools/bench_decode_mb.py > /dev/null 2>&1
 python tools/prof_summary.py $O/prof_b > $O/decode_batched_kernel_stats.csv 2>/dev/null; rm -rf $O/prof_b
 CHECK=0 BATCHES=10 PCY_MC_TRACE=1 python tools/bench_decode_mb.py > $O/decode_mb_trace.log 2>&1
-# 8. the probes behind the rotated K order
+# 8. the probes behind the rotated K order (built here when the binaries did not travel)
+for pr in stream_rows stream_cus; do [ -x tools/probes/$pr ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/$pr tools/probes/$pr.hip; done
 ./tools/probes/stream_rows > $O/probe_stream_rows.log 2>&1
 ./tools/probes/stream_cus > $O/probe_stream_cus.log 2>&1
 ls -la $O
